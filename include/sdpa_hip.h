@@ -1,0 +1,145 @@
+/*
+ * sdpa_hip.h -- C ABI of the MI355X (gfx950) scaled-dot-product-attention engine.
+ *
+ * This is the drop-in boundary for the one hot path of the reference
+ * (paths relative to the reference tree):
+ *
+ *     attention()                  attention.c:20-21      (serial, fp64)
+ *     attention()                  attention-mpi.c:191-192 (K/V-sharded, fp32 compute)
+ *       online_softmax_attention   attention-mpi.c:168-189
+ *       dot_avx512 / axpy_avx512 / memset_zero_scale   :103-166
+ *       cvt_d2f_avx512 / cvt_f2d_avx512                :31-101
+ *       owner_count / owner_disp                       :19-27
+ *       two-phase merge + reduce                       :340-399
+ *
+ * Everything here is plain C: pointers, ints, sizes.  No C++ or torch types
+ * cross the boundary and no C++ exception escapes it.  Every entry point
+ * returns 0 on success or a negative SDPA_E* code (sdpa_strerror() names it).
+ * There is NO CPU fallback: without a usable gfx950 device every compute
+ * entry point fails with SDPA_ENODEV.
+ *
+ * Two layers:
+ *   1. host level  -- sdpa_attention_f64(): host fp64 in / host fp64 out, the
+ *      body of the reference's attention(); drives 1..8 GPUs from one process.
+ *   2. device level -- sdpa_dev_*(): the individual stages on DEVICE pointers
+ *      and a caller-supplied hipStream_t (passed as void*), for hosts that own
+ *      device memory and collectives themselves (one process per GPU with RCCL
+ *      through torch.distributed: bench.py, the package's Python host).
+ */
+#ifndef SDPA_HIP_H
+#define SDPA_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDPA_API __attribute__((visibility("default")))
+
+/* error codes */
+#define SDPA_OK        0
+#define SDPA_EINVAL   -1   /* bad argument (null pointer, non-positive dim, bad ld) */
+#define SDPA_ENODEV   -2   /* no usable HIP device / engine not initialised        */
+#define SDPA_EHIP     -3   /* a HIP runtime call failed (message on stderr)         */
+#define SDPA_ERCCL    -4   /* an RCCL call failed                                    */
+#define SDPA_ENOMEM   -5   /* device or pinned-host allocation failed                */
+#define SDPA_EUNSUP   -6   /* shape not supported by this build                      */
+
+/* flags for sdpa_attention_f64 */
+#define SDPA_F_DEFAULT     0
+#define SDPA_F_NO_PIPELINE 1   /* one Q batch, no copy/compute overlap (debug)     */
+
+/* Per-call wall-clock breakdown of the last sdpa_attention_f64(), microseconds. */
+struct sdpa_timing {
+    double total_us;      /* entry -> exit of sdpa_attention_f64                   */
+    double kv_stage_us;   /* K/V host->device copy + fp64->fp32 convert (all GPUs)  */
+    double pipeline_us;   /* Q batches: H2D, kernels, merge collectives, D2H        */
+    double kernel_us;     /* sum of fused-kernel time on GPU 0 (HIP events)         */
+    int    n_gpus;        /* GPUs the call used                                     */
+    int    q_batches;     /* Q batches the pipeline ran                             */
+    int    kv_splits;     /* in-GPU K/V splits the fused kernel used                */
+};
+
+/* ---- lifecycle ---------------------------------------------------------- */
+
+/* Create the engine on `n_gpus` devices (0 = every visible device).  Separate
+ * from the compute call so a bench can keep one-time HIP/RCCL start-up out of
+ * the timed region (the reference's timer brackets attention() itself,
+ * attention.c:179-182).  sdpa_attention_f64() calls it lazily with
+ * $SDPA_GPUS (default 0) when it has not been called.                        */
+SDPA_API int sdpa_init(int n_gpus);
+SDPA_API void sdpa_shutdown(void);
+SDPA_API int sdpa_device_count(void);          /* visible HIP devices, <0 on error */
+SDPA_API const char *sdpa_strerror(int code);
+SDPA_API const char *sdpa_version(void);
+
+/* ---- host level: replaces the body of attention() ------------------------ */
+
+/* result[m x dv] = softmax(Q K^T / sqrt(dk)) V.
+ * Q[m x dk], K[n x dk], V[n x dv], result[m x dv]: dense row-major fp64 host
+ * arrays owned by the caller (attention.c:14-21); inputs are not written,
+ * result is fully overwritten, no pointer is retained.
+ * Compute is fp32 (fp64 inputs rounded to nearest-even as cvt_d2f_avx512,
+ * attention-mpi.c:31-64; scale = 1/sqrtf((float)dk), :208), output widened to
+ * fp64 (:373,:396).  K/V rows are sharded over the engine's GPUs with
+ * owner_count/owner_disp (:19-27) and merged with all-reduce(MAX),
+ * all-reduce(SUM) and reduce(SUM) as :340-380.                               */
+SDPA_API int sdpa_attention_f64(const double *Q, const double *K, const double *V,
+                                double *result, int m, int n, int dk, int dv,
+                                int flags);
+SDPA_API int sdpa_last_timing(struct sdpa_timing *out);
+
+/* K/V row partition, attention-mpi.c:19-27. */
+SDPA_API int sdpa_owner_count(int n, int size, int rank);
+SDPA_API int sdpa_owner_disp(int n, int size, int rank);
+
+/* ---- device level -------------------------------------------------------- */
+/* All pointers below are DEVICE pointers on the current HIP device; `stream`
+ * is a hipStream_t (NULL = the default stream).  Calls only enqueue work.
+ * Leading dimensions are in elements, must be multiples of 4 and >= the column
+ * count; columns [cols, ld) of every fp32 matrix handed to
+ * sdpa_dev_shard_partial_f32 must be zero (sdpa_dev_cvt_d2f writes them so).  */
+
+/* fp64 -> fp32, round-to-nearest-even; dst[r*ld + c], pad columns zeroed.
+ * Replaces cvt_d2f_avx512 (attention-mpi.c:31-64).                           */
+SDPA_API int sdpa_dev_cvt_d2f(const double *src, float *dst, long rows, int cols,
+                              int ld, void *stream);
+/* fp32 -> fp64 (exact).  Replaces cvt_f2d_avx512 (:68-101).                   */
+SDPA_API int sdpa_dev_cvt_f2d(const float *src, int ld, double *dst, long rows,
+                              int cols, void *stream);
+
+/* Number of in-GPU K/V splits the fused kernel will use for this shape, and the
+ * scratch it needs (0 bytes when the answer is 1 split).                      */
+SDPA_API int    sdpa_dev_kv_splits(int m, int n_local, int dk, int dv);
+SDPA_API size_t sdpa_dev_workspace_bytes(int m, int n_local, int dk, int dv);
+
+/* The fused kernel: online_softmax_attention (attention-mpi.c:168-189) for ALL
+ * m query rows against one K/V shard of n_local rows:
+ *   contrib[m x dv] (ld ldo) = sum_j exp(s_ij - lmax_i) V_j     (UN-normalised)
+ *   lmax[m] = max_j s_ij,  lsum[m] = sum_j exp(s_ij - lmax_i),
+ *   s_ij = dot(Q_i, K_j) / sqrtf(dk).
+ * n_local == 0 gives contrib = 0, lmax = -inf, lsum = 0 (:172-173).
+ * `workspace` must hold sdpa_dev_workspace_bytes() bytes (may be NULL if 0). */
+SDPA_API int sdpa_dev_shard_partial_f32(const float *Qf, int ldq, const float *Kf, int ldk,
+                                        const float *Vf, int ldv, float *contrib, int ldo,
+                                        float *lmax, float *lsum, int m, int n_local,
+                                        int dk, int dv, void *workspace, size_t workspace_bytes,
+                                        void *stream);
+
+/* Merge step 3 (attention-mpi.c:346-351): corr = expf(lmax - gmax);
+ * lsum *= corr; contrib row *= corr.                                          */
+SDPA_API int sdpa_dev_merge_rescale(float *contrib, int ldo, float *lsum, const float *lmax,
+                                    const float *gmax, int m, int dv, void *stream);
+/* Merge step 5 (:358-362): inv = gsum==0 ? 0 : 1/gsum; contrib row *= inv.    */
+SDPA_API int sdpa_dev_merge_normalise(float *contrib, int ldo, const float *gsum, int m,
+                                      int dv, void *stream);
+/* Single-shard finish: step 5 with gsum = lsum fused with the fp32->fp64
+ * writeback of :373,:396.  result[m x dv] dense fp64.                         */
+SDPA_API int sdpa_dev_finish_f64(const float *contrib, int ldo, const float *lsum,
+                                 double *result, int m, int dv, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDPA_HIP_H */

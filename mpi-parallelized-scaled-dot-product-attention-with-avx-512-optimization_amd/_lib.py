@@ -1,0 +1,95 @@
+"""ctypes binding of lib/libsdpa_hip.so -- the C ABI of include/sdpa_hip.h.
+
+Nothing in here computes: it loads the shared library built from csrc/ and
+declares the prototypes.  There is no fallback of any kind: if the library is
+missing `load()` raises, and on a machine without a gfx950 device every compute
+entry point returns SDPA_ENODEV, which `check()` turns into an exception.
+"""
+import ctypes
+import os
+import re
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_DIR = os.path.dirname(PKG_DIR)
+LIB_PATH = os.path.join(PKG_DIR, "lib", "libsdpa_hip.so")
+HEADER_PATH = os.path.join(REPO_DIR, "include", "sdpa_hip.h")
+
+SDPA_OK, SDPA_EINVAL, SDPA_ENODEV, SDPA_EHIP, SDPA_ERCCL, SDPA_ENOMEM, SDPA_EUNSUP = 0, -1, -2, -3, -4, -5, -6
+
+_c_int, _c_long, _c_size_t, _c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_size_t, ctypes.c_void_p
+
+
+class SdpaTiming(ctypes.Structure):
+    _fields_ = [("total_us", ctypes.c_double), ("kv_stage_us", ctypes.c_double),
+                ("pipeline_us", ctypes.c_double), ("kernel_us", ctypes.c_double),
+                ("n_gpus", _c_int), ("q_batches", _c_int), ("kv_splits", _c_int)]
+
+
+class SdpaError(RuntimeError):
+    def __init__(self, code, what):
+        self.code = code
+        super().__init__("%s failed: %s (code %d)" % (what, strerror(code), code))
+
+
+_PROTOS = {
+    "sdpa_init": (_c_int, [_c_int]),
+    "sdpa_shutdown": (None, []),
+    "sdpa_device_count": (_c_int, []),
+    "sdpa_strerror": (ctypes.c_char_p, [_c_int]),
+    "sdpa_version": (ctypes.c_char_p, []),
+    "sdpa_attention_f64": (_c_int, [_c_void_p] * 4 + [_c_int] * 5),
+    "sdpa_last_timing": (_c_int, [ctypes.POINTER(SdpaTiming)]),
+    "sdpa_owner_count": (_c_int, [_c_int] * 3),
+    "sdpa_owner_disp": (_c_int, [_c_int] * 3),
+    "sdpa_dev_cvt_d2f": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p]),
+    "sdpa_dev_cvt_f2d": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_long, _c_int, _c_void_p]),
+    "sdpa_dev_kv_splits": (_c_int, [_c_int] * 4),
+    "sdpa_dev_workspace_bytes": (_c_size_t, [_c_int] * 4),
+    "sdpa_dev_shard_partial_f32": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int,
+                                            _c_void_p, _c_int, _c_void_p, _c_void_p,
+                                            _c_int, _c_int, _c_int, _c_int,
+                                            _c_void_p, _c_size_t, _c_void_p]),
+    "sdpa_dev_merge_rescale": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p,
+                                        _c_int, _c_int, _c_void_p]),
+    "sdpa_dev_merge_normalise": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p]),
+    "sdpa_dev_finish_f64": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p]),
+}
+
+_lib = None
+
+
+def header_symbols():
+    """Every entry point include/sdpa_hip.h declares (SDPA_API ... name(...))."""
+    text = open(HEADER_PATH).read()
+    return sorted(set(re.findall(r"SDPA_API\s+[\w\s\*]+?\b(sdpa_\w+)\s*\(", text)))
+
+
+def load():
+    """Load the library (once).  PyTorch is imported first when available so that its
+    libamdhip64.so.7 is the one HIP runtime of the process (same SONAME as ROCm's)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: build it with `make -C %s` (hipcc, gfx950). "
+                          "There is no CPU fallback." % (LIB_PATH, os.path.join(PKG_DIR, "csrc")))
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def strerror(code):
+    return load().sdpa_strerror(code).decode()
+
+
+def check(code, what):
+    if code != SDPA_OK:
+        raise SdpaError(code, what)

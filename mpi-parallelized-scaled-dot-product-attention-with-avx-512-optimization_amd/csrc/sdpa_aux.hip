@@ -1,0 +1,154 @@
+// sdpa_aux.hip -- the bandwidth-bound helpers around the fused kernel.
+//
+// Replaces (paths relative to the reference tree):
+//   cvt_d2f_avx512            attention-mpi.c:31-64    -> cvt_d2f_kernel
+//   cvt_f2d_avx512            attention-mpi.c:68-101   -> cvt_f2d_kernel / finish_f64_kernel
+//   merge step 3              attention-mpi.c:346-351  -> merge_rescale_kernel
+//   merge step 5              attention-mpi.c:358-362  -> merge_normalise_kernel / finish_f64_kernel
+// All are streaming kernels: 16-byte accesses per lane, grid-stride, no LDS.
+#include "sdpa_internal.h"
+
+#include <math.h>
+
+namespace sdpa {
+
+static inline unsigned stream_grid(long work_items, int block = 256) {
+    long g = (work_items + block - 1) / block;
+    const long cap = 256L * 8;            // 8 workgroups per CU, grid-stride beyond
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+// dst[r*ld + c] = (float)src[r*cols + c], c < cols; zero for cols <= c < ld.
+// __double2float_rn == RNE == what _mm512_cvtpd_ps does under the default MXCSR.
+__global__ void cvt_d2f_kernel(const double *__restrict__ src, float *__restrict__ dst, long rows,
+                               int cols, int ld) {
+    const int c4n = ld / 4;
+    const long total = rows * c4n;
+    const bool flat = (cols == ld);       // dense and a multiple of 4: 2 x 16-byte loads
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        float4 o;
+        if (flat) {
+            const double2 a = reinterpret_cast<const double2 *>(src)[2 * idx];
+            const double2 b = reinterpret_cast<const double2 *>(src)[2 * idx + 1];
+            o = make_float4(__double2float_rn(a.x), __double2float_rn(a.y),
+                            __double2float_rn(b.x), __double2float_rn(b.y));
+        } else {
+            const long r = idx / c4n;
+            const int c = (int)(idx - r * c4n) * 4;
+            const double *s = src + r * cols + c;
+            o.x = c + 0 < cols ? __double2float_rn(s[0]) : 0.f;
+            o.y = c + 1 < cols ? __double2float_rn(s[1]) : 0.f;
+            o.z = c + 2 < cols ? __double2float_rn(s[2]) : 0.f;
+            o.w = c + 3 < cols ? __double2float_rn(s[3]) : 0.f;
+        }
+        reinterpret_cast<float4 *>(dst)[idx] = o;
+    }
+}
+
+// dst[r*cols + c] = (double)src[r*ld + c]
+__global__ void cvt_f2d_kernel(const float *__restrict__ src, int ld, double *__restrict__ dst,
+                               long rows, int cols) {
+    const long total = rows * cols;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / cols;
+        const int c = (int)(idx - r * cols);
+        dst[idx] = (double)src[r * ld + c];
+    }
+}
+
+// corr = expf(lmax - gmax); lsum *= corr; contrib row *= corr.
+// A shard with no rows has lmax = -inf -> corr = 0 (attention-mpi.c:172,347).
+__global__ void merge_rescale_kernel(float *contrib, int ldo, float *lsum, const float *lmax,
+                                     const float *gmax, int m, int dv) {
+    const int c4n = ldo / 4;
+    const long total = (long)m * c4n;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(idx / c4n);
+        const int c4 = (int)(idx - (long)r * c4n);
+        const float corr = expf(lmax[r] - gmax[r]);
+        if (4 * c4 < dv) {
+            float4 *p = reinterpret_cast<float4 *>(contrib + (size_t)r * ldo) + c4;
+            float4 v = *p;
+            v.x *= corr; v.y *= corr; v.z *= corr; v.w *= corr;
+            *p = v;
+        }
+        if (c4 == 0) lsum[r] *= corr;
+    }
+}
+
+// inv = gsum == 0 ? 0 : 1/gsum; contrib row *= inv.
+__global__ void merge_normalise_kernel(float *contrib, int ldo, const float *gsum, int m, int dv) {
+    const int c4n = ldo / 4;
+    const long total = (long)m * c4n;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(idx / c4n);
+        const int c4 = (int)(idx - (long)r * c4n);
+        if (4 * c4 >= dv) continue;
+        const float g = gsum[r];
+        const float inv = (g == 0.f) ? 0.f : 1.0f / g;
+        float4 *p = reinterpret_cast<float4 *>(contrib + (size_t)r * ldo) + c4;
+        float4 v = *p;
+        v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
+        *p = v;
+    }
+}
+
+// result[r*dv + c] = (double)(contrib[r*ldo + c] * (lsum==0 ? 0 : 1/lsum))
+__global__ void finish_f64_kernel(const float *__restrict__ contrib, int ldo,
+                                  const float *__restrict__ lsum, double *__restrict__ result,
+                                  int m, int dv) {
+    const long total = (long)m * dv;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(idx / dv);
+        const int c = (int)(idx - (long)r * dv);
+        const float g = lsum[r];
+        const float inv = (g == 0.f) ? 0.f : 1.0f / g;
+        result[idx] = (double)(contrib[(size_t)r * ldo + c] * inv);
+    }
+}
+
+hipError_t launch_cvt_d2f(const double *src, float *dst, long rows, int cols, int ld, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    const long work = rows * (ld / 4);
+    hipLaunchKernelGGL(cvt_d2f_kernel, dim3(stream_grid(work)), dim3(256), 0, s, src, dst, rows, cols, ld);
+    return hipGetLastError();
+}
+
+hipError_t launch_cvt_f2d(const float *src, int ld, double *dst, long rows, int cols, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(cvt_f2d_kernel, dim3(stream_grid(rows * cols)), dim3(256), 0, s, src, ld, dst, rows, cols);
+    return hipGetLastError();
+}
+
+hipError_t launch_merge_rescale(float *contrib, int ldo, float *lsum, const float *lmax,
+                                const float *gmax, int m, int dv, hipStream_t s) {
+    if (m <= 0) return hipSuccess;
+    hipLaunchKernelGGL(merge_rescale_kernel, dim3(stream_grid((long)m * (ldo / 4))), dim3(256), 0, s,
+                       contrib, ldo, lsum, lmax, gmax, m, dv);
+    return hipGetLastError();
+}
+
+hipError_t launch_merge_normalise(float *contrib, int ldo, const float *gsum, int m, int dv,
+                                  hipStream_t s) {
+    if (m <= 0) return hipSuccess;
+    hipLaunchKernelGGL(merge_normalise_kernel, dim3(stream_grid((long)m * (ldo / 4))), dim3(256), 0, s,
+                       contrib, ldo, gsum, m, dv);
+    return hipGetLastError();
+}
+
+hipError_t launch_finish_f64(const float *contrib, int ldo, const float *lsum, double *result,
+                             int m, int dv, hipStream_t s) {
+    if (m <= 0) return hipSuccess;
+    hipLaunchKernelGGL(finish_f64_kernel, dim3(stream_grid((long)m * dv)), dim3(256), 0, s, contrib,
+                       ldo, lsum, result, m, dv);
+    return hipGetLastError();
+}
+
+}  // namespace sdpa

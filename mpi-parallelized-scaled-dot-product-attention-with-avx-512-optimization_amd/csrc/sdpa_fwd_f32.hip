@@ -1,0 +1,437 @@
+// sdpa_fwd_f32.hip -- the fused online-softmax attention kernel for gfx950 (CDNA4).
+//
+// Replaces the reference's per-row hot loop (paths relative to the reference tree):
+//   online_softmax_attention  attention-mpi.c:168-189
+//   dot_avx512                :103-121   -> QK^T on v_mfma_f32_32x32x2_f32
+//   axpy_avx512               :123-140   -> P.V  on v_mfma_f32_32x32x2_f32
+//   memset_zero_scale         :142-166   -> accumulator rescale, only when a tile
+//                                           moves the running max of some row
+// for ALL query rows of a batch against one K/V shard, producing the same
+// shard-local triple the reference produces per row: un-normalised contrib[dv],
+// lmax, lsum.
+//
+// Design (MI355X first; nothing here is a translation of the AVX-512 code):
+//   * workgroup = 4 waves, each wave owns 32 query rows; a workgroup walks its
+//     K/V range in 32-row tiles staged through LDS (double buffered, one barrier
+//     per tile, next tile's global loads in flight under the current tile's MFMAs).
+//   * swapped product S^T = K.Q^T: the MFMA D layout then gives every lane ONE
+//     query row (lane&31) and 16 of the tile's 32 key rows, so row max / row sum
+//     are lane-local apart from one exchange with lane^32.
+//   * P^T in the D layout is directly the B operand of O^T += V^T.P^T when the
+//     two k-slots of step r are key rows crow(r,0) / crow(r,1): no LDS round trip
+//     and no shuffle between the two contractions.
+//   * Q (32 x dk per wave) lives in registers for the whole K/V walk, O^T in
+//     4 x 16 accumulator registers.
+//   * f32-input MFMA is an exact fmaf chain (1/16 of the bf16 MFMA rate =
+//     157.3 TFLOP/s peak): "fp32 compute" as the reference, same rounding class.
+//   * in-GPU K/V splits (flash-decoding style) fill the 256 CUs when there are
+//     few query blocks; the split merge is the reference's own (max,sum,contrib)
+//     merge algebra (:340-362) applied inside one GPU.
+//
+#include "sdpa_internal.h"
+
+#include <math.h>
+
+namespace sdpa {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// key row (within a 32-row tile) held in accumulator register r of half-wave hi
+// for the 32x32 MFMA C/D layout: row = (r&3) + 8*(r>>2) + 4*hi.
+__device__ __forceinline__ constexpr int crow(int r, int hi) {
+    return (r & 3) + 8 * (r >> 2) + 4 * hi;
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// bijective "contiguous chunk per XCD" remap of a 1-D grid: hardware places
+// block b on XCD b%8; give each XCD a contiguous range of work items so blocks
+// that share a K/V split share an L2.
+__device__ __forceinline__ int xcd_remap(int bid, int total) {
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int q = total >> 3, r = total & 7;
+    const int first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return first + slot;
+}
+
+template <int DKP, int DVP>
+__global__ __launch_bounds__(256, 2) void fused_partial_kernel(PartialArgs a, int kv_per_split,
+                                                                int n_qblocks, float scale) {
+    constexpr int NU = DKP / 8;     // 16-byte K reads (4 MFMA k-steps each) per tile per lane
+    constexpr int NT = DVP / 32;    // 32-column O^T tiles; also floats per V read
+    constexpr int KLD = DKP + 4;    // padded K row (floats): ds_read_b128 column reads conflict-free
+    constexpr int KPT = DKP / 32;   // float4 staged per thread per K tile
+    constexpr int VPT = DVP / 32;
+    constexpr int KTILE = kKvTile * KLD;
+    constexpr int VTILE = kKvTile * DVP;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *const Ks = smem;                 // [2][KTILE]
+    float *const Vs = smem + 2 * KTILE;     // [2][VTILE]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 31;               // MFMA row/col index of this lane
+    const int hi = lane >> 5;               // which k-slot / accumulator half
+
+    const int work = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = work / n_qblocks;
+    const int qblock = work - split * n_qblocks;
+    const int qrow = qblock * kQRowsPerBlock + wave * 32 + li;   // this lane's query row
+
+    const int kv_begin = split * kv_per_split;
+    const int kv_end = min(a.n_local, kv_begin + kv_per_split);
+    const int ntiles = kv_end > kv_begin ? (kv_end - kv_begin + kKvTile - 1) / kKvTile : 0;
+
+    const float c = scale * 1.44269504088896340736f;   // scores -> log2 domain
+
+    // ---- Q fragment: B operand of S^T = K.Q^T.  k-slot mapping (shared with the K
+    //      reads below): MFMA step (u,e) of half-wave hi uses dk index 8u + 4hi + e.
+    float4 qf[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int col = 8 * u + 4 * hi;
+        qf[u] = (qrow < a.m && col < a.ldq)
+                    ? *reinterpret_cast<const float4 *>(a.Q + (size_t)qrow * a.ldq + col)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    f32x16 oacc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+    float m_run = -INFINITY;   // running max of raw dots (scale > 0 keeps the order)
+    float l_run = 0.f;         // this half-wave's share of the running sum
+
+    float4 kreg[KPT], vreg[VPT];
+    auto tile_gload = [&](int tile) {
+        const int base = kv_begin + tile * kKvTile;
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / (DKP / 4), c4 = idx % (DKP / 4);
+            const int g = base + row;
+            kreg[i] = (g < kv_end && 4 * c4 < a.ldk)
+                          ? *reinterpret_cast<const float4 *>(a.K + (size_t)g * a.ldk + 4 * c4)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / (DVP / 4), c4 = idx % (DVP / 4);
+            const int g = base + row;
+            vreg[i] = (g < kv_end && 4 * c4 < a.ldv)
+                          ? *reinterpret_cast<const float4 *>(a.V + (size_t)g * a.ldv + 4 * c4)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto tile_lstore = [&](int buf) {
+        float *kd = Ks + buf * KTILE;
+        float *vd = Vs + buf * VTILE;
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / (DKP / 4), c4 = idx % (DKP / 4);
+            *reinterpret_cast<float4 *>(kd + row * KLD + 4 * c4) = kreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / (DVP / 4), c4 = idx % (DVP / 4);
+            *reinterpret_cast<float4 *>(vd + row * DVP + 4 * c4) = vreg[i];
+        }
+    };
+
+    if (ntiles > 0) {
+        tile_gload(0);
+        tile_lstore(0);
+    }
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        const bool more = (t + 1 < ntiles);
+        if (more) tile_gload(t + 1);          // in flight under this tile's MFMAs
+
+        // ---- S^T tile = K_tile . Q^T   (A = K rows from LDS, B = Q from registers)
+        const float *kt = Ks + cur * KTILE + li * KLD + 4 * hi;
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const float4 kf = *reinterpret_cast<const float4 *>(kt + 8 * u);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[u].x, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[u].y, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[u].z, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[u].w, s, 0, 0, 0);
+        }
+
+        // ragged last tile: key rows past the shard end contribute exp(-inf) = 0
+        const int valid = kv_end - (kv_begin + t * kKvTile);
+        if (valid < kKvTile) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (crow(r, hi) >= valid) s[r] = -INFINITY;
+        }
+
+        // ---- online softmax, one query row per lane pair (lane, lane^32)
+        float tmax = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float m_new = fmaxf(m_run, tmax);
+        if (__any(m_new > m_run)) {           // wave-uniform: rare after the first tiles
+            const float alpha = fast_exp2((m_run - m_new) * c);
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[tt][r] *= alpha;
+            l_run *= alpha;
+            m_run = m_new;
+        }
+        const float mc = m_run * c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = fast_exp2(fmaf(s[r], c, -mc));
+            l_run += s[r];
+        }
+
+        // ---- O^T += V_tile^T . P^T   (A = V columns from LDS, B = P from registers)
+        const float *vt = Vs + cur * VTILE + NT * li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float *vp = vt + crow(r, hi) * DVP;
+            if constexpr (NT == 4) {
+                const float4 vf = *reinterpret_cast<const float4 *>(vp);
+                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.x, s[r], oacc[0], 0, 0, 0);
+                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.y, s[r], oacc[1], 0, 0, 0);
+                oacc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.z, s[r], oacc[2], 0, 0, 0);
+                oacc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.w, s[r], oacc[3], 0, 0, 0);
+            } else if constexpr (NT == 2) {
+                const float2 vf = *reinterpret_cast<const float2 *>(vp);
+                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.x, s[r], oacc[0], 0, 0, 0);
+                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.y, s[r], oacc[1], 0, 0, 0);
+            } else {
+                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[0], s[r], oacc[0], 0, 0, 0);
+            }
+        }
+
+        if (more) tile_lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: the shard-local triple of attention-mpi.c:188 for this row
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    float *out = a.contrib;
+    float *omax = a.lmax, *osum = a.lsum;
+    int ldo = a.ldo;
+    if (a.kv_splits > 1) {
+        ldo = a.ws_ld;
+        out = a.ws_contrib + (size_t)split * a.m * ldo;
+        omax = a.ws_lmax + (size_t)split * a.m;
+        osum = a.ws_lsum + (size_t)split * a.m;
+    }
+    if (qrow < a.m) {
+        float *orow = out + (size_t)qrow * ldo;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int col0 = NT * crow(r, hi);
+            if constexpr (NT == 4) {
+                if (col0 + 3 < a.dv) {
+                    *reinterpret_cast<float4 *>(orow + col0) =
+                        make_float4(oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]);
+                    continue;
+                }
+            }
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+                if (col0 + tt < a.dv) orow[col0 + tt] = oacc[tt][r];
+        }
+        if (hi == 0) {
+            omax[qrow] = m_run * scale;
+            osum[qrow] = l_tot;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// In-GPU split merge: the reference's shard merge (attention-mpi.c:340-362 minus
+// the final 1/gsum, which stays with the caller) applied to the kv_splits partial
+// triples of one GPU.  One thread per (row, 4 columns).
+// ---------------------------------------------------------------------------
+__global__ void split_merge_kernel(PartialArgs a) {
+    const int c4n = a.ws_ld / 4;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)a.m * c4n) return;
+    const int row = (int)(idx / c4n), c4 = (int)(idx % c4n);
+    float gm = -INFINITY;
+    for (int s = 0; s < a.kv_splits; ++s) gm = fmaxf(gm, a.ws_lmax[(size_t)s * a.m + row]);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float tot = 0.f;
+    for (int s = 0; s < a.kv_splits; ++s) {
+        const float lm = a.ws_lmax[(size_t)s * a.m + row];
+        const float w = (lm == -INFINITY) ? 0.f : expf(lm - gm);
+        tot += w * a.ws_lsum[(size_t)s * a.m + row];
+        {
+            const float4 o = *reinterpret_cast<const float4 *>(
+                a.ws_contrib + ((size_t)s * a.m + row) * a.ws_ld + 4 * c4);
+            acc.x += w * o.x; acc.y += w * o.y; acc.z += w * o.z; acc.w += w * o.w;
+        }
+    }
+    *reinterpret_cast<float4 *>(a.contrib + (size_t)row * a.ldo + 4 * c4) = acc;
+    if (c4 == 0) {
+        a.lmax[row] = gm;
+        a.lsum[row] = tot;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Any-shape kernel (dk or dv > 128): one wave per query row, lanes across key
+// rows for the dot products and across value columns for the accumulate.  A
+// correctness path for shapes the MFMA kernel does not cover in fp32; slow.
+// ---------------------------------------------------------------------------
+constexpr int kGenericMaxCols = 16;   // dv <= 64 * 16
+
+__global__ __launch_bounds__(256) void generic_partial_kernel(PartialArgs a, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    float *qs = smem + (size_t)wave * a.ldq;
+    if (row < a.m)
+        for (int t = lane; t < a.ldq; t += 64) qs[t] = a.Q[(size_t)row * a.ldq + t];
+    __syncthreads();
+    if (row >= a.m) return;
+
+    float acc[kGenericMaxCols];
+#pragma unroll
+    for (int cidx = 0; cidx < kGenericMaxCols; ++cidx) acc[cidx] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int dk4 = (a.dk + 3) / 4;   // pad columns are zero on both operands
+
+    for (int kv0 = 0; kv0 < a.n_local; kv0 += 64) {
+        const int j = kv0 + lane;
+        float s = -INFINITY;
+        if (j < a.n_local) {
+            const float4 *kp = reinterpret_cast<const float4 *>(a.K + (size_t)j * a.ldk);
+            const float4 *qp = reinterpret_cast<const float4 *>(qs);
+            float d = 0.f;
+            for (int t = 0; t < dk4; ++t) {
+                const float4 kk = kp[t], qq = qp[t];
+                d = fmaf(kk.x, qq.x, d); d = fmaf(kk.y, qq.y, d);
+                d = fmaf(kk.z, qq.z, d); d = fmaf(kk.w, qq.w, d);
+            }
+            s = d * scale;
+        }
+        float tmax = s;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = expf(m_run - m_new);
+        const float p = (j < a.n_local) ? expf(s - m_new) : 0.f;
+        float psum = p;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) psum += __shfl_xor(psum, o);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int cidx = 0; cidx < kGenericMaxCols; ++cidx) acc[cidx] *= alpha;
+        const int cnt = min(64, a.n_local - kv0);
+        for (int jj = 0; jj < cnt; ++jj) {
+            const float pj = __shfl(p, jj);
+            const float *vrow = a.V + (size_t)(kv0 + jj) * a.ldv;
+#pragma unroll
+            for (int cidx = 0; cidx < kGenericMaxCols; ++cidx) {
+                const int col = lane + 64 * cidx;
+                if (col < a.dv) acc[cidx] = fmaf(pj, vrow[col], acc[cidx]);
+            }
+        }
+    }
+#pragma unroll
+    for (int cidx = 0; cidx < kGenericMaxCols; ++cidx) {
+        const int col = lane + 64 * cidx;
+        if (col < a.dv) a.contrib[(size_t)row * a.ldo + col] = acc[cidx];
+    }
+    if (lane == 0) {
+        a.lmax[row] = m_run;
+        a.lsum[row] = l_run;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host-side launch logic
+// ---------------------------------------------------------------------------
+static inline int pad_dim(int d) { return d <= 32 ? 32 : (d <= 64 ? 64 : 128); }
+
+int pick_kv_splits(int m, int n_local, int dk, int dv) {
+    if (dk > kMaxFastDim || dv > kMaxFastDim) return 1;
+    if (m <= 0 || n_local <= 0) return 1;
+    const int nqb = (m + kQRowsPerBlock - 1) / kQRowsPerBlock;
+    const int ntiles = (n_local + kKvTile - 1) / kKvTile;
+    // aim for 2 resident workgroups on each of the 256 CUs, at least 4 tiles a split
+    int want = (512 + nqb - 1) / nqb;
+    int cap = ntiles / 4;
+    if (cap < 1) cap = 1;
+    if (want > cap) want = cap;
+    if (want > 64) want = 64;
+    return want < 1 ? 1 : want;
+}
+
+size_t workspace_bytes(int m, int n_local, int dk, int dv) {
+    const int s = pick_kv_splits(m, n_local, dk, dv);
+    if (s <= 1) return 0;
+    const size_t ws_ld = (size_t)((dv + 3) / 4) * 4;
+    return (size_t)s * (size_t)m * (ws_ld + 2) * sizeof(float);
+}
+
+template <int DKP, int DVP>
+static hipError_t launch_fast(const PartialArgs &a, hipStream_t s) {
+    const int nqb = (a.m + kQRowsPerBlock - 1) / kQRowsPerBlock;
+    const int ntiles = (a.n_local + kKvTile - 1) / kKvTile;
+    const int tiles_per_split = (ntiles + a.kv_splits - 1) / a.kv_splits;
+    const int kv_per_split = tiles_per_split > 0 ? tiles_per_split * kKvTile : kKvTile;
+    const size_t lds = (size_t)2 * kKvTile * ((DKP + 4) + DVP) * sizeof(float);
+    static bool attr_done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&fused_partial_kernel<DKP, DVP>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done[dev] = true;
+    }
+    const float scale = 1.0f / sqrtf((float)a.dk);   // attention-mpi.c:208
+    hipLaunchKernelGGL((fused_partial_kernel<DKP, DVP>), dim3(nqb * a.kv_splits), dim3(256), lds, s,
+                       a, kv_per_split, nqb, scale);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (a.kv_splits > 1) {
+        const long work = (long)a.m * (a.ws_ld / 4);
+        hipLaunchKernelGGL(split_merge_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, a);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
+hipError_t launch_shard_partial(const PartialArgs &a, hipStream_t s) {
+    if (a.dk > kMaxFastDim || a.dv > kMaxFastDim) {
+        if (a.dv > 64 * kGenericMaxCols) return hipErrorInvalidValue;
+        const size_t lds = (size_t)4 * a.ldq * sizeof(float);
+        if (lds > 64 * 1024) return hipErrorInvalidValue;
+        const float scale = 1.0f / sqrtf((float)a.dk);
+        hipLaunchKernelGGL(generic_partial_kernel, dim3((a.m + 3) / 4), dim3(256), lds, s, a, scale);
+        return hipGetLastError();
+    }
+    const int kp = pad_dim(a.dk), vp = pad_dim(a.dv);
+#define SDPA_CASE(KP, VP) if (kp == KP && vp == VP) return launch_fast<KP, VP>(a, s);
+    SDPA_CASE(128, 128) SDPA_CASE(128, 64) SDPA_CASE(128, 32)
+    SDPA_CASE(64, 128)  SDPA_CASE(64, 64)  SDPA_CASE(64, 32)
+    SDPA_CASE(32, 128)  SDPA_CASE(32, 64)  SDPA_CASE(32, 32)
+#undef SDPA_CASE
+    return hipErrorInvalidValue;
+}
+
+}  // namespace sdpa

@@ -1,0 +1,317 @@
+"""Python host mirror of the reference's operator interface for the attention hot path.
+
+Two entry points, same meaning as the reference's two `attention()` functions
+(paths relative to the reference tree):
+
+* `attention(Q, K, V)`            -- attention.c:20-21.  Host fp64 in, host fp64 out;
+  the whole call runs inside libsdpa_hip.so (`sdpa_attention_f64`), one process
+  driving the visible GPUs.
+* `attention_mpi(Q, K, V, m, n, dk, dv, rank, world)` -- attention-mpi.c:191-192.  One
+  process per GPU; only rank 0 holds the matrices (the others pass None, exactly like
+  the reference's non-root ranks, attention-mpi.c:508-517).  K/V rows are sharded with
+  owner_count/owner_disp (:19-27); per Q batch the shard-local triples are merged with
+  all-reduce(MAX), all-reduce(SUM) and reduce(SUM) (:340-380) through
+  `torch.distributed` (backend "nccl" = RCCL over xGMI).  Every compute stage is a HIP
+  kernel reached through the C ABI (`HipBackend`).
+
+PyTorch is used for device memory, streams and the process group only.  There is no
+CPU compute path in this package: `HipBackend` raises if the library or the GPU is
+missing.  (tests/ inject a checker-backed stand-in for the world_size-2 gloo run of
+the collective choreography; that stand-in lives in tests/, not here.)
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import SdpaError, SdpaTiming, check
+
+DEFAULT_Q_BATCH = 8192   # the reference uses B = 512 (attention-mpi.c:200); an internal constant
+
+
+def round4(x):
+    return (x + 3) // 4 * 4
+
+
+def owner_count(n, size, rank):
+    """attention-mpi.c:19-22."""
+    return _lib.load().sdpa_owner_count(n, size, rank)
+
+
+def owner_disp(n, size, rank):
+    """attention-mpi.c:24-27."""
+    return _lib.load().sdpa_owner_disp(n, size, rank)
+
+
+# --------------------------------------------------------------------------------------
+# host level (single process, C ABI does everything)
+# --------------------------------------------------------------------------------------
+def init(n_gpus=0):
+    check(_lib.load().sdpa_init(n_gpus), "sdpa_init")
+
+
+def shutdown():
+    _lib.load().sdpa_shutdown()
+
+
+def attention(Q, K, V, flags=0):
+    """result = softmax(Q K^T / sqrt(dk)) V; numpy fp64 [m,dk],[n,dk],[n,dv] -> [m,dv]."""
+    lib = _lib.load()
+    Q = np.ascontiguousarray(Q, dtype=np.float64)
+    K = np.ascontiguousarray(K, dtype=np.float64)
+    V = np.ascontiguousarray(V, dtype=np.float64)
+    if Q.ndim != 2 or K.ndim != 2 or V.ndim != 2 or Q.shape[1] != K.shape[1] or K.shape[0] != V.shape[0]:
+        raise ValueError("expected Q[m,dk], K[n,dk], V[n,dv]")
+    m, dk = Q.shape
+    n, dv = V.shape
+    out = np.empty((m, dv), dtype=np.float64)
+    check(lib.sdpa_attention_f64(Q.ctypes.data, K.ctypes.data, V.ctypes.data, out.ctypes.data,
+                                 m, n, dk, dv, flags), "sdpa_attention_f64")
+    return out
+
+
+def last_timing():
+    t = SdpaTiming()
+    check(_lib.load().sdpa_last_timing(ctypes.byref(t)), "sdpa_last_timing")
+    return {k: getattr(t, k) for k, _ in SdpaTiming._fields_}
+
+
+# --------------------------------------------------------------------------------------
+# device level (one process per GPU)
+# --------------------------------------------------------------------------------------
+class HipBackend:
+    """The stages of the hot path on torch CUDA tensors, each one a HIP kernel behind the
+    C ABI.  All work is enqueued on torch's current stream of `device`."""
+
+    name = "hip"
+
+    def __init__(self, device=None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise SdpaError(_lib.SDPA_ENODEV, "HipBackend")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._ws = None
+
+    @property
+    def comm_device(self):
+        return self.device
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def to_device(self, a, dtype=None):
+        t = torch.as_tensor(a)
+        return t.to(self.device, dtype=dtype, non_blocking=True)
+
+    def empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def cvt_d2f(self, x64):
+        """cvt_d2f_avx512 (attention-mpi.c:31-64): [rows, cols] f64 -> [rows, round4(cols)] f32."""
+        rows, cols = x64.shape
+        ld = round4(cols)
+        out = self.empty((rows, ld), torch.float32)
+        if rows:
+            assert x64.is_contiguous() and x64.dtype == torch.float64
+            with torch.cuda.device(self.device):
+                check(self.lib.sdpa_dev_cvt_d2f(x64.data_ptr(), out.data_ptr(), rows, cols, ld, self._stream()),
+                      "sdpa_dev_cvt_d2f")
+        return out
+
+    def cvt_f2d(self, x32, cols):
+        """cvt_f2d_avx512 (attention-mpi.c:68-101)."""
+        rows, ld = x32.shape
+        out = self.empty((rows, cols), torch.float64)
+        if rows:
+            with torch.cuda.device(self.device):
+                check(self.lib.sdpa_dev_cvt_f2d(x32.data_ptr(), ld, out.data_ptr(), rows, cols, self._stream()),
+                      "sdpa_dev_cvt_f2d")
+        return out
+
+    def shard_partial(self, Qf, Kf, Vf, dk, dv):
+        """online_softmax_attention (attention-mpi.c:168-189) for every row of Qf against one shard."""
+        m = Qf.shape[0]
+        n_local = Kf.shape[0]
+        ldo = round4(dv)
+        contrib = self.empty((m, ldo), torch.float32)
+        lmax = self.empty((m,), torch.float32)
+        lsum = self.empty((m,), torch.float32)
+        need = self.lib.sdpa_dev_workspace_bytes(m, n_local, dk, dv)
+        if need and (self._ws is None or self._ws.numel() < need):
+            self._ws = self.empty((need,), torch.uint8)
+        with torch.cuda.device(self.device):
+            check(self.lib.sdpa_dev_shard_partial_f32(
+                Qf.data_ptr(), Qf.shape[1], Kf.data_ptr() if n_local else None, Kf.shape[1],
+                Vf.data_ptr() if n_local else None, Vf.shape[1], contrib.data_ptr(), ldo,
+                lmax.data_ptr(), lsum.data_ptr(), m, n_local, dk, dv,
+                self._ws.data_ptr() if need else None, need, self._stream()), "sdpa_dev_shard_partial_f32")
+        return contrib, lmax, lsum
+
+    def merge_rescale(self, contrib, lsum, lmax, gmax, dv):
+        """attention-mpi.c:346-351 (in place)."""
+        with torch.cuda.device(self.device):
+            check(self.lib.sdpa_dev_merge_rescale(contrib.data_ptr(), contrib.shape[1], lsum.data_ptr(),
+                                                  lmax.data_ptr(), gmax.data_ptr(), contrib.shape[0], dv,
+                                                  self._stream()), "sdpa_dev_merge_rescale")
+
+    def merge_normalise(self, contrib, gsum, dv):
+        """attention-mpi.c:358-362 (in place)."""
+        with torch.cuda.device(self.device):
+            check(self.lib.sdpa_dev_merge_normalise(contrib.data_ptr(), contrib.shape[1], gsum.data_ptr(),
+                                                    contrib.shape[0], dv, self._stream()),
+                  "sdpa_dev_merge_normalise")
+
+    def finish_f64(self, contrib, lsum, dv):
+        """single shard: step 5 with gsum = lsum fused with the fp64 writeback (:358-362,:373)."""
+        out = self.empty((contrib.shape[0], dv), torch.float64)
+        with torch.cuda.device(self.device):
+            check(self.lib.sdpa_dev_finish_f64(contrib.data_ptr(), contrib.shape[1], lsum.data_ptr(),
+                                               out.data_ptr(), contrib.shape[0], dv, self._stream()),
+                  "sdpa_dev_finish_f64")
+        return out
+
+
+class ShardedAttention:
+    """One rank's state for the K/V-sharded path: the resident fp32 shard plus the per-batch
+    merge choreography of attention-mpi.c:307-399.  `dist` is torch.distributed (or None for a
+    single rank)."""
+
+    def __init__(self, backend, rank=0, world=1, dist=None, group=None, root=0):
+        self.be = backend
+        self.rank, self.world, self.root = rank, world, root
+        self.dist = dist if world > 1 else None
+        self.group = group
+        self.Kf = self.Vf = None
+        self.dk = self.dv = self.n = None
+
+    # ---- K/V distribution: attention-mpi.c:210-266 ------------------------------------
+    def load_kv_from_root(self, K64, V64, n, dk, dv):
+        """Root holds K,V (fp64, any of numpy / CPU tensor / device tensor); every rank ends up
+        with its own fp32 shard resident.  The root converts the whole of K and V to fp32 first
+        (:224-225,:248-249) and the shards travel as fp32 (Scatterv, :258-264)."""
+        be = self.be
+        self.n, self.dk, self.dv = n, dk, dv
+        cnt = owner_count(n, self.world, self.rank)
+        if self.world == 1:
+            self.Kf = be.cvt_d2f(be.to_device(K64, torch.float64).contiguous())
+            self.Vf = be.cvt_d2f(be.to_device(V64, torch.float64).contiguous())
+            return
+        cmax = owner_count(n, self.world, 0)             # rank 0 owns the largest shard
+        shard_k = be.empty((cmax, round4(dk)), torch.float32)
+        shard_v = be.empty((cmax, round4(dv)), torch.float32)
+        lists = (None, None)
+        if self.rank == self.root:
+            Kf = be.cvt_d2f(be.to_device(K64, torch.float64).contiguous())
+            Vf = be.cvt_d2f(be.to_device(V64, torch.float64).contiguous())
+            lk, lv = [], []
+            for r in range(self.world):
+                c, d = owner_count(n, self.world, r), owner_disp(n, self.world, r)
+                pk = be.empty((cmax, round4(dk)), torch.float32).zero_()
+                pv = be.empty((cmax, round4(dv)), torch.float32).zero_()
+                pk[:c] = Kf[d:d + c]
+                pv[:c] = Vf[d:d + c]
+                lk.append(pk)
+                lv.append(pv)
+            lists = (lk, lv)
+        self.dist.scatter(shard_k, lists[0], src=self.root, group=self.group)
+        self.dist.scatter(shard_v, lists[1], src=self.root, group=self.group)
+        self.Kf = shard_k[:cnt].contiguous()
+        self.Vf = shard_v[:cnt].contiguous()
+
+    def load_kv_shard(self, Kf_local, Vf_local, n, dk, dv):
+        """The shard is already on this rank's device as padded fp32 (bench: resident inputs)."""
+        self.Kf, self.Vf, self.n, self.dk, self.dv = Kf_local, Vf_local, n, dk, dv
+
+    # ---- one Q batch: attention-mpi.c:333-380 -----------------------------------------
+    def batch_partial(self, Qf):
+        return self.be.shard_partial(Qf, self.Kf, self.Vf, self.dk, self.dv)
+
+    def batch_merge(self, contrib, lmax, lsum, async_reduce=False):
+        """Steps 2-5 and 7 of the reference loop.  Returns (contrib, work): on the root `contrib`
+        holds the normalised, shard-summed fp32 rows once `work` (if any) has completed."""
+        be, dist = self.be, self.dist
+        if dist is None:
+            be.merge_normalise(contrib, lsum, self.dv)
+            return contrib, None
+        gmax = lmax.clone()
+        dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=self.group)     # :342
+        be.merge_rescale(contrib, lsum, lmax, gmax, self.dv)              # :346-351
+        gsum = lsum.clone()
+        dist.all_reduce(gsum, op=dist.ReduceOp.SUM, group=self.group)     # :354
+        be.merge_normalise(contrib, gsum, self.dv)                        # :358-362
+        work = dist.reduce(contrib, dst=self.root, op=dist.ReduceOp.SUM, group=self.group,
+                           async_op=async_reduce)                         # :380
+        return contrib, work
+
+    def forward_batches(self, q_batches):
+        """Run a sequence of fp32 Q batches (each already on every rank) through partial + merge,
+        with batch i's reduce overlapped with batch i+1's kernel (the Ireduce of :364-380).
+        Returns the list of per-batch normalised fp32 results (meaningful on the root)."""
+        outs, pending = [], None
+        for Qf in q_batches:
+            contrib, lmax, lsum = self.batch_partial(Qf)
+            if pending is not None:
+                pending.wait()
+            contrib, pending = self.batch_merge(contrib, lmax, lsum, async_reduce=True)
+            outs.append(contrib)
+        if pending is not None:
+            pending.wait()
+        return outs
+
+
+def attention_mpi(Q, K, V, m, n, dk, dv, rank, world, dist=None, group=None, backend=None,
+                  q_batch=DEFAULT_Q_BATCH):
+    """Mirror of the MPI `attention()` (attention-mpi.c:191-407): rank 0 passes the fp64 matrices,
+    every other rank passes None and may pass garbage dims; returns the fp64 [m,dv] result on
+    rank 0 (None elsewhere)."""
+    be = backend if backend is not None else HipBackend()
+    root = 0
+    if world > 1:
+        dims = torch.tensor([m, n, dk, dv] if rank == root else [0, 0, 0, 0], dtype=torch.int64,
+                            device=be.comm_device)
+        dist.broadcast(dims, src=root, group=group)                       # :196
+        m, n, dk, dv = (int(x) for x in dims.tolist())
+    sa = ShardedAttention(be, rank, world, dist, group, root)
+    sa.load_kv_from_root(K, V, n, dk, dv)
+
+    B = min(q_batch, m)
+    nb = (m + B - 1) // B
+    result = np.empty((m, dv), dtype=np.float64) if rank == root else None
+    Q64 = None
+    if rank == root:
+        Q64 = torch.as_tensor(np.ascontiguousarray(Q, dtype=np.float64) if isinstance(Q, np.ndarray) else Q)
+
+    def fetch(b):      # Q ping-pong prefetch: root converts, everyone receives (:303-305,:323-327)
+        i0 = b * B
+        bs = min(B, m - i0)
+        if rank == root:
+            qf = be.cvt_d2f(be.to_device(Q64[i0:i0 + bs], torch.float64).contiguous())
+        else:
+            qf = be.empty((bs, round4(dk)), torch.float32)
+        w = dist.broadcast(qf, src=root, group=group, async_op=True) if world > 1 else None
+        return qf, w
+
+    nxt = fetch(0)
+    pending = None          # (work, contrib, i0, bs) of the previous batch's reduce
+    for b in range(nb):
+        qf, w = nxt
+        if w is not None:
+            w.wait()                                                      # :316
+        if b + 1 < nb:
+            nxt = fetch(b + 1)
+        contrib, lmax, lsum = sa.batch_partial(qf)                        # :333-338
+        if pending is not None:                                           # :365-376
+            pw, pc, pi0, pbs = pending
+            if pw is not None:
+                pw.wait()
+            if rank == root:
+                result[pi0:pi0 + pbs] = be.cvt_f2d(pc, dv).cpu().numpy()
+        contrib, work = sa.batch_merge(contrib, lmax, lsum, async_reduce=world > 1)
+        pending = (work, contrib, b * B, min(B, m - b * B))
+    pw, pc, pi0, pbs = pending                                            # :387-399
+    if pw is not None:
+        pw.wait()
+    if rank == root:
+        result[pi0:pi0 + pbs] = be.cvt_f2d(pc, dv).cpu().numpy()
+    return result

@@ -1,0 +1,122 @@
+"""CPU: the C-ABI library loads, exports every symbol include/sdpa_hip.h declares, validates its
+arguments, and fails LOUDLY (no fallback) where there is no GPU."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, PKG
+
+HAS_GPU = torch.cuda.is_available()
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.load()
+    names = pkg.header_symbols()
+    assert len(names) >= 17 and "sdpa_attention_f64" in names and "sdpa_dev_shard_partial_f32" in names
+    for n in names:
+        assert hasattr(lib, n), "missing export " + n
+    # and nothing is bound in Python that the header does not declare
+    assert set(pkg._lib._PROTOS) == set(names)
+
+
+def test_version_and_strerror(pkg):
+    lib = pkg.load()
+    assert b"gfx950" in lib.sdpa_version()
+    assert lib.sdpa_strerror(0) == b"ok"
+    assert b"no CPU fallback" in lib.sdpa_strerror(pkg._lib.SDPA_ENODEV)
+
+
+@pytest.mark.parametrize("n,size", [(10, 3), (5, 8), (262144, 8), (100, 64)])
+def test_owner_partition_matches_oracle(n, size, pkg, orc):
+    for r in range(size):
+        assert pkg.owner_count(n, size, r) == orc.owner_count(n, size, r)
+        assert pkg.owner_disp(n, size, r) == orc.owner_disp(n, size, r)
+
+
+def test_argument_validation_precedes_device_use(pkg):
+    lib = pkg.load()
+    a = np.zeros((4, 4))
+    p = a.ctypes.data
+    E = pkg._lib.SDPA_EINVAL
+    assert lib.sdpa_attention_f64(None, p, p, p, 4, 4, 4, 4, 0) == E
+    assert lib.sdpa_attention_f64(p, p, p, p, 0, 4, 4, 4, 0) == E
+    assert lib.sdpa_attention_f64(p, p, p, p, 4, 4, -1, 4, 0) == E
+    assert lib.sdpa_init(-3) == E
+    assert lib.sdpa_dev_cvt_d2f(p, p, 4, 4, 6, None) == E        # ld not a multiple of 4
+    assert lib.sdpa_dev_cvt_d2f(p, p, 4, 8, 4, None) == E        # ld < cols
+    assert lib.sdpa_dev_shard_partial_f32(p, 4, p, 4, p, 4, p, 4, p, p, 0, 4, 4, 4, None, 0, None) == E
+    assert lib.sdpa_dev_shard_partial_f32(p, 4, p, 4, p, 4, p, 3, p, p, 4, 4, 4, 4, None, 0, None) == E
+    assert lib.sdpa_owner_count(5, 0, 0) == E
+    assert lib.sdpa_dev_kv_splits(8192, 8192, 128, 128) == 8
+    assert lib.sdpa_dev_kv_splits(32768, 65536, 128, 128) == 2
+    assert lib.sdpa_dev_kv_splits(512, 512, 64, 64) == 4
+    assert lib.sdpa_dev_kv_splits(8192, 8192, 512, 512) == 1
+    assert lib.sdpa_dev_workspace_bytes(32768, 65536, 128, 128) == 2 * 32768 * 130 * 4
+    assert lib.sdpa_dev_workspace_bytes(100000, 64, 128, 128) == 0
+
+
+@pytest.mark.skipif(HAS_GPU, reason="checks the no-GPU failure mode")
+def test_no_gpu_fails_loudly_never_falls_back(pkg):
+    lib = pkg.load()
+    assert lib.sdpa_device_count() <= 0
+    assert lib.sdpa_init(0) == pkg._lib.SDPA_ENODEV
+    Q = np.random.rand(4, 8); K = np.random.rand(6, 8); V = np.random.rand(6, 8)
+    with pytest.raises(pkg.SdpaError) as e:
+        pkg.attention(Q, K, V)
+    assert e.value.code == pkg._lib.SDPA_ENODEV
+    with pytest.raises(pkg.SdpaError):
+        pkg.HipBackend()
+    buf = np.zeros(64, dtype=np.float32).ctypes.data
+    assert lib.sdpa_dev_shard_partial_f32(buf, 4, buf, 4, buf, 4, buf, 4, buf, buf, 2, 2, 4, 4,
+                                          None, 0, None) == pkg._lib.SDPA_ENODEV
+
+
+def test_product_never_touches_the_oracle():
+    """the product tree must not import, link or execute anything under oracle/"""
+    pdir = os.path.join(ROOT, PKG)
+    for dirpath, _, files in os.walk(pdir):
+        if os.path.basename(dirpath) in ("build", "lib", "bin", "__pycache__"):
+            continue
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hip", ".cpp", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                for line in text.splitlines():
+                    s = line.strip()
+                    if s.startswith(("#include", "import ", "from ")) or "dlopen" in s or "CDLL" in s:
+                        assert "oracle" not in s, "%s: %s" % (f, s)
+    out = subprocess.run(["ldd", os.path.join(pdir, "lib", "libsdpa_hip.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out and "libamdhip64" in out
+
+
+# ---------------------------------------------------------------- CLI host (plain C) ----------
+CLI = os.path.join(ROOT, PKG, "bin", "attention-hip")
+
+
+def _run(args, **kw):
+    return subprocess.run([CLI] + args, capture_output=True, text=True, **kw)
+
+
+def test_cli_usage_and_io_errors(tmp_path):
+    """attention.c:165-168 / :86-89 / :103-114 messages and exit codes"""
+    r = _run([])
+    assert r.returncode == 1 and r.stdout == "" and r.stderr == "Usage: %s <testing data>\n" % CLI
+    r = _run(["/no/such/file"])
+    assert r.returncode == 1 and r.stderr == "Cannot open file: /no/such/file\n" and r.stdout == ""
+    short = tmp_path / "short.bin"
+    short.write_bytes(open(os.path.join(ROOT, "tests", "golden", "tiny_D1.bin"), "rb").read()[:200])
+    r = _run([str(short)])
+    assert r.returncode == 1 and r.stderr == "Invalid testing data.\n" and r.stdout == ""
+    hdr = tmp_path / "hdr.bin"
+    hdr.write_bytes(b"\x01\x00\x00")
+    r = _run([str(hdr)])
+    assert r.returncode == 1 and r.stderr == "Invalid testing data.\n"
+
+
+@pytest.mark.skipif(HAS_GPU, reason="checks the no-GPU failure mode")
+def test_cli_without_gpu_exits_nonzero_and_prints_nothing_on_stdout():
+    r = _run([os.path.join(ROOT, "tests", "golden", "tiny_D1.bin")])
+    assert r.returncode == 1 and r.stdout == "" and "no usable HIP device" in r.stderr

@@ -1,0 +1,244 @@
+"""GPU (-m gpu): parity of the HIP hot path with the oracle, through the C ABI.
+
+Tolerance (BASELINE.md section 4, fp32 compute / fp64 output): the whole result array,
+max|got - fp64 oracle| <= 5e-5 * max(1, max|V|), any NaN/Inf fails."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import PKG, ROOT, fp32_tol
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(ROOT, "tests", "golden")
+CLI = os.path.join(ROOT, PKG, "bin", "attention-hip")
+
+
+def golden_cases():
+    return json.load(open(os.path.join(GOLD, "INDEX.json")))
+
+
+@pytest.fixture(scope="module")
+def be(pkg):
+    assert torch.cuda.is_available(), "the -m gpu tests need a real MI355X"
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+    torch.cuda.set_device(0)
+    return pkg.HipBackend("cuda:0")
+
+
+def dev_attention(pkg, be, Q, K, V):
+    """device-level path: cvt_d2f -> fused kernel (+ split merge) -> finish_f64"""
+    m, dk = Q.shape
+    n, dv = V.shape
+    sa = pkg.ShardedAttention(be)
+    sa.load_kv_from_root(K, V, n, dk, dv)
+    qf = be.cvt_d2f(torch.from_numpy(np.ascontiguousarray(Q)).cuda())
+    contrib, lmax, lsum = sa.batch_partial(qf)
+    return be.finish_f64(contrib, lsum, dv).cpu().numpy()
+
+
+def check(got, want, V, what=""):
+    assert got.shape == want.shape
+    assert np.isfinite(got).all(), what + ": non-finite values"
+    err = np.abs(got - want).max()
+    assert err <= fp32_tol(V), "%s: max|err| %.3e > %.3e" % (what, err, fp32_tol(V))
+    return err
+
+
+# ---------------------------------------------------------------- golden vectors -------------
+@pytest.mark.parametrize("case", golden_cases(), ids=lambda c: c["name"])
+def test_golden_host_level(case, pkg, O):
+    Q, K, V, ans = O.read_case(os.path.join(GOLD, case["file"]))
+    check(pkg.attention(Q, K, V), ans, V, "host level")
+
+
+@pytest.mark.parametrize("case", golden_cases(), ids=lambda c: c["name"])
+def test_golden_device_level(case, pkg, be, O):
+    Q, K, V, ans = O.read_case(os.path.join(GOLD, case["file"]))
+    check(dev_attention(pkg, be, Q, K, V), ans, V, "device level")
+
+
+@pytest.mark.parametrize("case", golden_cases(), ids=lambda c: c["name"])
+def test_golden_cli_prints_correct(case):
+    """the plain-C host: same stdout contract as attention.c:184-189"""
+    r = subprocess.run([CLI, os.path.join(GOLD, case["file"])], capture_output=True, text=True,
+                       env=dict(os.environ, SDPA_VERBOSE="1"))
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.split("\n")
+    assert lines[0] == "Correct!" and lines[1].startswith("Elapsed time: ") and lines[1].endswith(" us")
+    assert lines[2] == "" and len(lines) == 3
+    assert "non-finite" not in r.stderr
+
+
+def test_cli_reports_wrong_on_a_corrupted_answer(tmp_path, O):
+    Q, K, V, ans = O.read_case(os.path.join(GOLD, "tiny_D1.bin"))
+    bad = ans.copy()
+    bad[3, 2] += 0.5
+    p = str(tmp_path / "bad.bin")
+    O.write_case(p, Q, K, V, bad)
+    r = subprocess.run([CLI, p], capture_output=True, text=True)
+    assert r.returncode == 0
+    assert r.stdout.startswith("Expect result[3][2] to be ") and r.stdout.endswith("Wrong!\n")
+
+
+# ---------------------------------------------------------------- shape / edge matrix --------
+SHAPES = [
+    # m,    n,   dk,  dv, dist
+    (1,     1,    1,   1, "D2"),      # smallest possible
+    (1,   100,    4,   4, "D2"),
+    (5,     3,    2,   7, "D1"),      # odd everything, n < tile
+    (32,   32,   32,  32, "D2"),      # exactly one wave / one tile
+    (33,   33,   33,  33, "D2"),      # one past every tile edge
+    (127, 255,   64,  64, "D1"),
+    (129, 257,   65,  31, "D3"),      # pads dk to 128, dv to 32
+    (512, 512,   64,  64, "D1"),      # BASELINE config 1
+    (300, 1000,  72,  40, "D2"),      # dims not multiples of 16/32
+    (64,    5,   16,  16, "D2"),
+    (257, 2048, 128, 128, "D3"),      # peaky softmax
+    (256, 4096, 128, 128, "D4"),      # late spike key: running max jumps in the last tiles
+    (130,  700,  96, 128, "D2"),
+    (200,  333, 128,  64, "D1"),
+    (40,   300, 100, 200, "D2"),      # dv > 128 -> any-shape kernel
+    (24,   200, 256, 256, "D1"),      # dk, dv > 128
+    (16,   130, 512, 512, "D1"),      # BASELINE config 5 dims (fp32 any-shape path)
+]
+
+
+@pytest.mark.parametrize("m,n,dk,dv,dist", SHAPES)
+def test_shapes_device_level(m, n, dk, dv, dist, pkg, be, orc, O):
+    Q, K, V = O.make_inputs(m, n, dk, dv, dist, seed=m + n)
+    check(dev_attention(pkg, be, Q, K, V), orc.attention_f64(Q, K, V), V, "device level")
+
+
+@pytest.mark.parametrize("m,n,dk,dv,dist", SHAPES[3:14:2])
+def test_shapes_host_level(m, n, dk, dv, dist, pkg, orc, O):
+    Q, K, V = O.make_inputs(m, n, dk, dv, dist, seed=m + n)
+    check(pkg.attention(Q, K, V), orc.attention_f64(Q, K, V), V, "host level")
+
+
+def test_host_level_q_pipeline_batches(pkg, orc, O, monkeypatch):
+    """several ping-ponged Q batches with a ragged last one (attention-mpi.c:307-330)"""
+    Q, K, V = O.make_inputs(1000, 600, 64, 64, "D2", seed=5)
+    want = orc.attention_f64(Q, K, V)
+    monkeypatch.setenv("SDPA_QBATCH", "192")
+    got = pkg.attention(Q, K, V)
+    assert pkg.last_timing()["q_batches"] == 6
+    check(got, want, V, "6 batches")
+    monkeypatch.delenv("SDPA_QBATCH")
+    got1 = pkg.attention(Q, K, V, flags=1)      # SDPA_F_NO_PIPELINE
+    assert pkg.last_timing()["q_batches"] == 1
+    check(got1, want, V, "1 batch")
+
+
+# ---------------------------------------------------------------- the shard-local triple -----
+@pytest.mark.parametrize("m,n_local,dk,dv", [(100, 333, 64, 64), (70, 64, 128, 128), (513, 2000, 128, 128)])
+def test_partial_triple_matches_oracle(m, n_local, dk, dv, pkg, be, orc, O):
+    """contrib (un-normalised), lmax, lsum of attention-mpi.c:168-189, incl. in-GPU K/V splits"""
+    Q, K, V = O.make_inputs(m, n_local, dk, dv, "D2", seed=3)
+    Qf, Kf, Vf = (x.astype(np.float32) for x in (Q, K, V))
+    c_ref, mx_ref, s_ref = orc.shard_partial_f32(Qf, Kf, Vf)
+    sa = pkg.ShardedAttention(be)
+    sa.load_kv_from_root(K, V, n_local, dk, dv)
+    contrib, lmax, lsum = sa.batch_partial(be.cvt_d2f(torch.from_numpy(Q).cuda()))
+    contrib, lmax, lsum = contrib.cpu().numpy()[:, :dv], lmax.cpu().numpy(), lsum.cpu().numpy()
+    assert np.abs(lmax - mx_ref).max() <= 2e-6 * max(1.0, np.abs(mx_ref).max())
+    assert np.abs(lsum / s_ref - 1).max() <= 2e-5
+    assert np.abs(contrib - c_ref).max() <= 2e-5 * max(1.0, np.abs(c_ref).max())
+
+
+def test_empty_shard_triple(pkg, be):
+    """n_local = 0: contrib = 0, lmax = -inf, lsum = 0 (attention-mpi.c:172-173)"""
+    qf = torch.randn(40, 64, device="cuda")
+    kf = torch.empty(0, 64, device="cuda")
+    vf = torch.empty(0, 64, device="cuda")
+    contrib, lmax, lsum = be.shard_partial(qf, kf, vf, 64, 64)
+    assert torch.all(contrib == 0) and torch.all(lsum == 0) and torch.all(torch.isneginf(lmax))
+
+
+def test_kv_splits_are_used_and_agree(pkg, be, orc, O):
+    """few query blocks + long K/V: the fused kernel splits K/V inside the GPU and merges"""
+    m, n, dk, dv = 256, 8192, 128, 128
+    assert pkg.load().sdpa_dev_kv_splits(m, n, dk, dv) > 1
+    Q, K, V = O.make_inputs(m, n, dk, dv, "D3", seed=8)
+    check(dev_attention(pkg, be, Q, K, V), O.numpy_attention_f64(Q, K, V), V, "kv splits")
+
+
+# ---------------------------------------------------------------- shard merge (multi-GPU algebra)
+@pytest.mark.parametrize("parts", [2, 3, 8])
+def test_shard_merge_equals_single_shard(parts, pkg, be, orc, O):
+    """P shards computed one after the other on one GPU and merged with the merge kernels
+    (all-reduce MAX / SUM and reduce SUM done with torch ops) == the unsharded result.
+    parts=8 with n=5 leaves three shards empty."""
+    for (m, n, dk, dv, dist) in [(96, 1000, 64, 64, "D4"), (64, 5, 16, 16, "D2")]:
+        Q, K, V = O.make_inputs(m, n, dk, dv, dist, seed=parts)
+        want = orc.attention_f64(Q, K, V)
+        qf = be.cvt_d2f(torch.from_numpy(Q).cuda())
+        triples = []
+        for r in range(parts):
+            c, d = pkg.owner_count(n, parts, r), pkg.owner_disp(n, parts, r)
+            sa = pkg.ShardedAttention(be)
+            sa.load_kv_from_root(K[d:d + c], V[d:d + c], c, dk, dv)
+            triples.append(sa.batch_partial(qf))
+        gmax = torch.stack([t[1] for t in triples]).max(dim=0).values
+        for contrib, lmax, lsum in triples:
+            be.merge_rescale(contrib, lsum, lmax, gmax, dv)
+        gsum = torch.stack([t[2] for t in triples]).sum(dim=0)
+        for contrib, _, _ in triples:
+            be.merge_normalise(contrib, gsum, dv)
+        total = torch.stack([t[0] for t in triples]).sum(dim=0)
+        got = be.cvt_f2d(total, dv).cpu().numpy()
+        check(got, want, V, "P=%d" % parts)
+
+
+# ---------------------------------------------------------------- converts -------------------
+def test_cvt_d2f_is_round_to_nearest_even_and_pads_zero(be):
+    x = torch.randn(37, 70, dtype=torch.float64, device="cuda") * 1e3
+    x[0, 0] = 1.0 + 2.0 ** -24            # exactly halfway between two floats -> even
+    x[0, 1] = 1.0 + 2.0 ** -24 + 2.0 ** -40
+    y = be.cvt_d2f(x)
+    assert y.shape == (37, 72)
+    assert torch.equal(y[:, :70], x.to(torch.float32)) and torch.all(y[:, 70:] == 0)
+    assert y[0, 0].item() == 1.0 and y[0, 1].item() > 1.0
+    z = be.cvt_f2d(y, 70)
+    assert torch.equal(z, y[:, :70].to(torch.float64))
+    big = torch.randn(1000, 128, dtype=torch.float64, device="cuda")
+    assert torch.equal(be.cvt_d2f(big), big.to(torch.float32))
+
+
+# ---------------------------------------------------------------- full-size properties -------
+def test_config2_rows_and_properties(pkg, be, O):
+    """BASELINE config 2 (m=n=8192, d=128): a row subset against the fp64 oracle, plus
+    size-independent properties: linearity in V, invariance under a permutation of the K/V rows,
+    rows of softmax weights summing to one (V = ones -> result = ones)."""
+    m = n = 8192
+    d = 128
+    Q, K, V = O.make_inputs(m, n, d, d, "D2", seed=42)
+    got = dev_attention(pkg, be, Q, K, V)
+    rows = np.random.default_rng(0).choice(m, 192, replace=False)
+    check(got[rows], O.numpy_attention_f64(Q, K, V, rows), V, "row subset")
+    V2 = np.random.default_rng(1).standard_normal(V.shape)
+    lin = dev_attention(pkg, be, Q, K, 2.0 * V - 0.5 * V2)
+    got2 = dev_attention(pkg, be, Q, K, V2)
+    assert np.abs(lin - (2.0 * got - 0.5 * got2)).max() <= 4 * fp32_tol(V)
+    perm = np.random.default_rng(2).permutation(n)
+    assert np.abs(dev_attention(pkg, be, Q, K[perm], V[perm]) - got).max() <= 2 * fp32_tol(V)
+    ones = dev_attention(pkg, be, Q, K, np.ones_like(V))
+    assert np.abs(ones - 1.0).max() <= 1e-5
+
+
+def test_headline_shape_row_subset(pkg, O):
+    """the metric shape m=32768 n=65536 d=128 through the host-level boundary; 128 random rows
+    against the fp64 oracle and the idempotence of a second call"""
+    m, n, d = 32768, 65536, 128
+    Q, K, V = O.make_inputs(m, n, d, d, "D1", seed=7)
+    got = pkg.attention(Q, K, V)
+    assert np.isfinite(got).all()
+    rows = np.random.default_rng(3).choice(m, 128, replace=False)
+    check(got[rows], O.numpy_attention_f64(Q, K, V, rows), V, "headline rows")
+    t = pkg.last_timing()
+    assert t["n_gpus"] >= 1 and t["q_batches"] == 4
+    again = pkg.attention(Q, K, V)
+    assert np.array_equal(again, got), "same inputs must give bit-identical results run to run"

@@ -1,0 +1,91 @@
+"""CPU: the oracle is pinned against reference-produced golden vectors and, where the reference
+build exists (build container), against the reference's own attention() directly."""
+import glob
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, fp32_tol
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def golden_cases():
+    return json.load(open(os.path.join(GOLD, "INDEX.json")))
+
+
+@pytest.mark.parametrize("case", golden_cases(), ids=lambda c: c["name"])
+def test_oracle_bit_exact_on_golden(case, orc, O):
+    Q, K, V, ans = O.read_case(os.path.join(GOLD, case["file"]))
+    assert Q.shape == (case["m"], case["dk"]) and V.shape == (case["n"], case["dv"])
+    got = orc.attention_f64(Q, K, V)
+    assert np.array_equal(got, ans), "restatement differs from reference attention.c output"
+
+
+@pytest.mark.parametrize("case", golden_cases(), ids=lambda c: c["name"])
+def test_golden_inputs_regenerate(case, O):
+    """the committed fixtures are exactly make_inputs(seed) -- the generating script is reproducible"""
+    Q, K, V, _ = O.read_case(os.path.join(GOLD, case["file"]))
+    q2, k2, v2 = O.make_inputs(case["m"], case["n"], case["dk"], case["dv"], case["dist"], case["seed"])
+    assert np.array_equal(Q, q2) and np.array_equal(K, k2) and np.array_equal(V, v2)
+
+
+def test_oracle_vs_reference_build_live(orc, O):
+    if not O.RefSerial.available():
+        pytest.skip("oracle/_ref not built here (no /root/reference)")
+    ref = O.RefSerial()
+    for seed, (m, n, dk, dv, dist) in enumerate([(7, 9, 3, 5, "D2"), (31, 257, 72, 40, "D3"), (64, 64, 64, 64, "D1")]):
+        Q, K, V = O.make_inputs(m, n, dk, dv, dist, 100 + seed)
+        assert np.array_equal(orc.attention_f64(Q, K, V), ref.attention(Q, K, V))
+
+
+@pytest.mark.parametrize("parts", [1, 2, 3, 8])
+@pytest.mark.parametrize("case", golden_cases(), ids=lambda c: c["name"])
+def test_sharded_f32_restatement_within_tolerance(case, parts, orc, O):
+    """the fp32 K/V-sharded pipeline (attention-mpi.c:191-407) restated; parts > n gives empty shards"""
+    Q, K, V, ans = O.read_case(os.path.join(GOLD, case["file"]))
+    got = orc.attention_sharded_f32(Q, K, V, parts)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ans).max() <= fp32_tol(V)
+
+
+def test_numpy_fp64_agrees(orc, O):
+    Q, K, V = O.make_inputs(50, 400, 128, 128, "D3", 9)
+    assert np.abs(O.numpy_attention_f64(Q, K, V) - orc.attention_f64(Q, K, V)).max() < 1e-12
+    rows = np.array([3, 17, 49])
+    assert np.abs(O.numpy_attention_f64(Q, K, V, rows) - orc.attention_f64(Q, K, V)[rows]).max() < 1e-12
+
+
+@pytest.mark.parametrize("n,size", [(10, 3), (5, 8), (262144, 8), (65536, 8), (1, 1), (7, 7), (100, 64)])
+def test_owner_partition(n, size, orc):
+    """attention-mpi.c:19-27: contiguous, balanced (sizes differ by <= 1), covers [0,n)"""
+    cnt = [orc.owner_count(n, size, r) for r in range(size)]
+    dsp = [orc.owner_disp(n, size, r) for r in range(size)]
+    assert sum(cnt) == n and dsp[0] == 0
+    assert all(dsp[r + 1] == dsp[r] + cnt[r] for r in range(size - 1))
+    assert max(cnt) - min(cnt) <= 1 and cnt == sorted(cnt, reverse=True)
+
+
+def test_file_format_roundtrip(tmp_path, orc, O):
+    Q, K, V = O.make_inputs(9, 11, 6, 4, "D2", 3)
+    ans = orc.attention_f64(Q, K, V)
+    p = str(tmp_path / "c.bin")
+    O.write_case(p, Q, K, V, ans)
+    assert os.path.getsize(p) == 16 + 8 * (9 * 6 + 11 * 6 + 11 * 4 + 9 * 4)
+    q2, k2, v2, a2 = O.read_case(p)
+    assert all(np.array_equal(a, b) for a, b in ((Q, q2), (K, k2), (V, v2), (ans, a2)))
+
+
+def test_reference_cli_accepts_generated_files(tmp_path, orc, O):
+    """our generator writes what the reference's own programs read (attention.c:92-121,:139-140)"""
+    exe = os.path.join(ROOT, "oracle", "_ref", "attention")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref not built here")
+    Q, K, V = O.make_inputs(20, 33, 16, 8, "D1", 5)
+    p = str(tmp_path / "c.bin")
+    O.write_case(p, Q, K, V, orc.attention_f64(Q, K, V))
+    out = subprocess.run([exe, p], capture_output=True, text=True).stdout
+    assert out.startswith("Correct!\nElapsed time: ")
