@@ -44,7 +44,7 @@ WORKLOADS = {
 F32_MFMA_PEAK_TFLOPS = 157.3                       # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 
 
-def cpu_baseline(m, n, d, budget_rows=2048):
+def cpu_baseline(m, n, d, budget_rows=8192):
     """Time the CPU path on this host on a bounded sample: `rows` query rows against the full
     K/V.  Prefers the reference's own binary (kind "reference"); falls back to the oracle port."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -66,7 +66,7 @@ def cpu_baseline(m, n, d, budget_rows=2048):
     except Exception:
         phys = 0
     avail = len(os.sched_getaffinity(0))
-    cores = max(1, min(avail, phys if phys > 0 else avail, 64))
+    cores = max(1, min(avail, phys if phys > 0 else avail, 256))
     if os.path.exists(exe) and os.path.exists(mpiexec) and "avx512f" in cpuinfo:
         try:
             ans = np.concatenate([O.numpy_attention_f64(Q[i:i + 256], K, V) for i in range(0, rows, 256)])
