@@ -119,9 +119,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # SDPA_BENCH_FORCE_DIST=1 runs the RCCL choreography even at world size 1 (a one-rank
+    # communicator), to exercise the collective call path on a single-GPU box.
+    force_dist = os.environ.get("SDPA_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     pkg = importlib.import_module(PKG)
@@ -141,7 +145,7 @@ def main():
     B = args.q_batch if args.q_batch > 0 else (m if world == 1 else max(1, m // 4))
     B = min(B, m)
     nb = (m + B - 1) // B
-    sa = pkg.ShardedAttention(be, rank, world, dist)
+    sa = pkg.ShardedAttention(be, rank, world, dist, force_collectives=force_dist)
     kernel_events = []
 
     def step(record):
@@ -158,7 +162,7 @@ def main():
                 kernel_events.append((e0, e1, qf.shape[0]))
             if pending is not None:
                 pending.wait()
-            contrib, pending = sa.batch_merge(contrib, lmax, lsum, async_reduce=world > 1)
+            contrib, pending = sa.batch_merge(contrib, lmax, lsum, async_reduce=dist is not None)
             outs.append(contrib)
         if pending is not None:
             pending.wait()

@@ -31,10 +31,14 @@
 #include "sdpa_internal.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace sdpa {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x1 __attribute__((ext_vector_type(1)));
 
 // key row (within a 32-row tile) held in accumulator register r of half-wave hi
 // for the 32x32 MFMA C/D layout: row = (r&3) + 8*(r>>2) + 4*hi.
@@ -53,6 +57,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int total) {
     const int first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return first + slot;
 }
+
+// NT consecutive floats of one V row (one per 32-column O^T tile) as a native vector.
+template <int NT> struct VFrag;
+template <> struct VFrag<4> {
+    f32x4 v;
+    static __device__ __forceinline__ VFrag load(const float *p) { return {*reinterpret_cast<const f32x4 *>(p)}; }
+};
+template <> struct VFrag<2> {
+    f32x2 v;
+    static __device__ __forceinline__ VFrag load(const float *p) { return {*reinterpret_cast<const f32x2 *>(p)}; }
+};
+template <> struct VFrag<1> {
+    f32x1 v;
+    static __device__ __forceinline__ VFrag load(const float *p) { VFrag f; f.v[0] = *p; return f; }
+};
 
 template <int DKP, int DVP>
 __global__ __launch_bounds__(256, 2) void fused_partial_kernel(PartialArgs a, int kv_per_split,
@@ -105,42 +124,66 @@ __global__ __launch_bounds__(256, 2) void fused_partial_kernel(PartialArgs a, in
     float m_run = -INFINITY;   // running max of raw dots (scale > 0 keeps the order)
     float l_run = 0.f;         // this half-wave's share of the running sum
 
-    float4 kreg[KPT], vreg[VPT];
-    auto tile_gload = [&](int tile) {
-        const int base = kv_begin + tile * kKvTile;
+    // Staging loads are UNCONDITIONAL (no exec-masked branches, so the loads stay in flight
+    // under the MFMAs): rows past the shard end are clamped to its last row (their scores are
+    // masked to -inf below, and 0 * finite = 0 in P.V), columns past the leading dimension are
+    // clamped to the last in-row float4 (the matching Q columns are zero; V columns past dv
+    // are never stored).
+    f32x4 kreg[KPT], vreg[VPT];   // native vectors: plain SSA values after unrolling
+    const int ldk_last = a.ldk - 4, ldv_last = a.ldv - 4;
+    unsigned koff[KPT], voff[VPT];           // loop-invariant per-lane byte offsets (full tiles)
 #pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-            const int idx = tid + 256 * i;
-            const int row = idx / (DKP / 4), c4 = idx % (DKP / 4);
-            const int g = base + row;
-            kreg[i] = (g < kv_end && 4 * c4 < a.ldk)
-                          ? *reinterpret_cast<const float4 *>(a.K + (size_t)g * a.ldk + 4 * c4)
-                          : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+    for (int i = 0; i < KPT; ++i) {
+        const int idx = tid + 256 * i;
+        koff[i] = (unsigned)((idx / (DKP / 4)) * a.ldk + min(4 * (idx % (DKP / 4)), ldk_last)) * 4u;
+    }
 #pragma unroll
-        for (int i = 0; i < VPT; ++i) {
-            const int idx = tid + 256 * i;
-            const int row = idx / (DVP / 4), c4 = idx % (DVP / 4);
-            const int g = base + row;
-            vreg[i] = (g < kv_end && 4 * c4 < a.ldv)
-                          ? *reinterpret_cast<const float4 *>(a.V + (size_t)g * a.ldv + 4 * c4)
-                          : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < VPT; ++i) {
+        const int idx = tid + 256 * i;
+        voff[i] = (unsigned)((idx / (DVP / 4)) * a.ldv + min(4 * (idx % (DVP / 4)), ldv_last)) * 4u;
+    }
+    auto tile_gload = [&](int tile) __attribute__((always_inline)) {
+        const int base = kv_begin + tile * kKvTile;          // wave-uniform
+        const int last = kv_end - 1 - base;                  // last valid row of this tile
+        // scalar 64-bit base + unsigned 32-bit per-lane byte offset (saddr + voffset form)
+        const char *kb = reinterpret_cast<const char *>(a.K + (size_t)base * a.ldk);
+        const char *vb = reinterpret_cast<const char *>(a.V + (size_t)base * a.ldv);
+        if (last >= kKvTile - 1) {                           // full tile: nothing to clamp
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) kreg[i] = *reinterpret_cast<const f32x4 *>(kb + koff[i]);
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) vreg[i] = *reinterpret_cast<const f32x4 *>(vb + voff[i]);
+        } else {                                             // ragged last tile: clamp the rows
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                const int idx = tid + 256 * i;
+                const int row = min(idx / (DKP / 4), last);
+                const int col = min(4 * (idx % (DKP / 4)), ldk_last);
+                kreg[i] = *reinterpret_cast<const f32x4 *>(kb + (unsigned)(row * a.ldk + col) * 4u);
+            }
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) {
+                const int idx = tid + 256 * i;
+                const int row = min(idx / (DVP / 4), last);
+                const int col = min(4 * (idx % (DVP / 4)), ldv_last);
+                vreg[i] = *reinterpret_cast<const f32x4 *>(vb + (unsigned)(row * a.ldv + col) * 4u);
+            }
         }
     };
-    auto tile_lstore = [&](int buf) {
+    auto tile_lstore = [&](int buf) __attribute__((always_inline)) {
         float *kd = Ks + buf * KTILE;
         float *vd = Vs + buf * VTILE;
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             const int idx = tid + 256 * i;
             const int row = idx / (DKP / 4), c4 = idx % (DKP / 4);
-            *reinterpret_cast<float4 *>(kd + row * KLD + 4 * c4) = kreg[i];
+            *reinterpret_cast<f32x4 *>(kd + row * KLD + 4 * c4) = kreg[i];
         }
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int idx = tid + 256 * i;
             const int row = idx / (DVP / 4), c4 = idx % (DVP / 4);
-            *reinterpret_cast<float4 *>(vd + row * DVP + 4 * c4) = vreg[i];
+            *reinterpret_cast<f32x4 *>(vd + row * DVP + 4 * c4) = vreg[i];
         }
     };
 
@@ -150,23 +193,42 @@ __global__ __launch_bounds__(256, 2) void fused_partial_kernel(PartialArgs a, in
     }
     __syncthreads();
 
+    const int base_prio = (a.tune & 1) ? ((blockIdx.x >> 8) & 1) : 0;
+    if (base_prio) __builtin_amdgcn_s_setprio(1);
+
     for (int t = 0; t < ntiles; ++t) {
         const int cur = t & 1;
-        const bool more = (t + 1 < ntiles);
-        if (more) tile_gload(t + 1);          // in flight under this tile's MFMAs
+        // next tile's global loads, in flight under this tile's MFMAs.  Unconditional (the
+        // last iteration re-fetches its own tile into the idle buffer) so that the staged
+        // registers stay plain SSA values -- no control flow, no scratch.
+        tile_gload(min(t + 1, ntiles - 1));
 
         // ---- S^T tile = K_tile . Q^T   (A = K rows from LDS, B = Q from registers)
         const float *kt = Ks + cur * KTILE + li * KLD + 4 * hi;
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        // K fragments are read two 16-byte pieces (8 MFMAs = 512 cycles) ahead of their use
+        float4 kf0 = *reinterpret_cast<const float4 *>(kt);
+        float4 kf1 = *reinterpret_cast<const float4 *>(kt + 8);
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const float4 kf = *reinterpret_cast<const float4 *>(kt + 8 * u);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[u].x, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[u].y, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[u].z, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[u].w, s, 0, 0, 0);
+        for (int u = 0; u < NU; u += 2) {
+            float4 kn0 = kf0, kn1 = kf1;
+            if (u + 2 < NU) {
+                kn0 = *reinterpret_cast<const float4 *>(kt + 8 * (u + 2));
+                kn1 = *reinterpret_cast<const float4 *>(kt + 8 * (u + 3));
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the reads AHEAD of this step's MFMAs
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf0.x, qf[u].x, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf0.y, qf[u].y, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf0.z, qf[u].z, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf0.w, qf[u].w, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf1.x, qf[u + 1].x, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf1.y, qf[u + 1].y, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf1.z, qf[u + 1].z, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf1.w, qf[u + 1].w, s, 0, 0, 0);
+            kf0 = kn0;
+            kf1 = kn1;
         }
 
         // ragged last tile: key rows past the shard end contribute exp(-inf) = 0
@@ -178,6 +240,7 @@ __global__ __launch_bounds__(256, 2) void fused_partial_kernel(PartialArgs a, in
         }
 
         // ---- online softmax, one query row per lane pair (lane, lane^32)
+        if (a.tune & 2) __builtin_amdgcn_s_setprio(2);
         float tmax = s[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
@@ -199,27 +262,31 @@ __global__ __launch_bounds__(256, 2) void fused_partial_kernel(PartialArgs a, in
             l_run += s[r];
         }
 
+        if (a.tune & 2) { if (base_prio) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         // ---- O^T += V_tile^T . P^T   (A = V columns from LDS, B = P from registers)
-        const float *vt = Vs + cur * VTILE + NT * li;
+        // V fragments are read two steps (8 MFMAs) ahead; the next tile's staged registers go
+        // to the other LDS buffer half-way through, under the MFMAs.
+        const float *vt = Vs + cur * VTILE + NT * li + 4 * hi * DVP;   // crow(r,hi) = crow(r,0) + 4hi
+        VFrag<NT> vf0 = VFrag<NT>::load(vt + crow(0, 0) * DVP);
+        VFrag<NT> vf1 = VFrag<NT>::load(vt + crow(1, 0) * DVP);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float *vp = vt + crow(r, hi) * DVP;
-            if constexpr (NT == 4) {
-                const float4 vf = *reinterpret_cast<const float4 *>(vp);
-                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.x, s[r], oacc[0], 0, 0, 0);
-                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.y, s[r], oacc[1], 0, 0, 0);
-                oacc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.z, s[r], oacc[2], 0, 0, 0);
-                oacc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.w, s[r], oacc[3], 0, 0, 0);
-            } else if constexpr (NT == 2) {
-                const float2 vf = *reinterpret_cast<const float2 *>(vp);
-                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.x, s[r], oacc[0], 0, 0, 0);
-                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.y, s[r], oacc[1], 0, 0, 0);
-            } else {
-                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[0], s[r], oacc[0], 0, 0, 0);
+        for (int r = 0; r < 16; r += 2) {
+            VFrag<NT> vn0 = vf0, vn1 = vf1;
+            if (r + 2 < 16) {
+                vn0 = VFrag<NT>::load(vt + crow(r + 2, 0) * DVP);
+                vn1 = VFrag<NT>::load(vt + crow(r + 3, 0) * DVP);
             }
+            if (r == 8) tile_lstore(cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+                oacc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf0.v[tt], s[r], oacc[tt], 0, 0, 0);
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+                oacc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf1.v[tt], s[r + 1], oacc[tt], 0, 0, 0);
+            vf0 = vn0;
+            vf1 = vn1;
         }
-
-        if (more) tile_lstore(cur ^ 1);
         __syncthreads();
     }
 
@@ -416,7 +483,10 @@ static hipError_t launch_fast(const PartialArgs &a, hipStream_t s) {
     return e;
 }
 
-hipError_t launch_shard_partial(const PartialArgs &a, hipStream_t s) {
+hipError_t launch_shard_partial(const PartialArgs &a_in, hipStream_t s) {
+    PartialArgs a = a_in;
+    static const int tune_env = getenv("SDPA_TUNE") ? atoi(getenv("SDPA_TUNE")) : 0;
+    a.tune = tune_env;
     if (a.dk > kMaxFastDim || a.dv > kMaxFastDim) {
         if (a.dv > 64 * kGenericMaxCols) return hipErrorInvalidValue;
         const size_t lds = (size_t)4 * a.ldq * sizeof(float);

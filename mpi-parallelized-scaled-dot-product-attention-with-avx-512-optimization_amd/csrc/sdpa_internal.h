@@ -23,6 +23,7 @@ struct PartialArgs {
     int ws_ld;                     // row stride of ws_contrib = dv rounded up to 4
     float *ws_lmax;                // [kv_splits x m]
     float *ws_lsum;                // [kv_splits x m]
+    int tune;                      // experiment switches ($SDPA_TUNE), 0 = shipped default
 };
 
 int  pick_kv_splits(int m, int n_local, int dk, int dv);

@@ -177,10 +177,10 @@ class ShardedAttention:
     merge choreography of attention-mpi.c:307-399.  `dist` is torch.distributed (or None for a
     single rank)."""
 
-    def __init__(self, backend, rank=0, world=1, dist=None, group=None, root=0):
+    def __init__(self, backend, rank=0, world=1, dist=None, group=None, root=0, force_collectives=False):
         self.be = backend
         self.rank, self.world, self.root = rank, world, root
-        self.dist = dist if world > 1 else None
+        self.dist = dist if (world > 1 or force_collectives) else None
         self.group = group
         self.Kf = self.Vf = None
         self.dk = self.dv = self.n = None

@@ -1,6 +1,8 @@
+#!/bin/bash
+# GPU-box check: parity tests, then the bench line.  Usage: bash tools/gpu_check.sh [tag] [pytest-args]
+TAG=${1:-run}
 mkdir -p gpurun_out
-{ rocminfo | grep -E "Marketing|gfx|Compute Unit" | head -8; python -c "import torch;print(torch.cuda.device_count())"; nproc; grep -m1 "model name" /proc/cpuinfo; ls /root/reference 2>&1 | head -2; ls /opt/conda/bin/mpiexec; } > gpurun_out/env.log 2>&1
-timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest1.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest1.log
-tail -30 gpurun_out/pytest1.log
-timeout 600 python bench.py --steps 5 --warmup 2 > gpurun_out/bench1.log 2>&1; echo "bench rc=$?" >> gpurun_out/bench1.log
-tail -5 gpurun_out/bench1.log
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_$TAG.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_$TAG.log
+tail -4 gpurun_out/pytest_$TAG.log
+timeout 600 python bench.py --steps 10 --warmup 3 ${BENCH_ARGS} > gpurun_out/bench_$TAG.log 2>&1; echo "bench rc=$?" >> gpurun_out/bench_$TAG.log
+tail -3 gpurun_out/bench_$TAG.log | cut -c1-1500
