@@ -33,6 +33,9 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <stdint.h>
+#include <type_traits>
+
 namespace sdpa {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -47,6 +50,20 @@ __device__ __forceinline__ constexpr int crow(int r, int hi) {
 }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// exp2 / max as volatile asm: ordered against sched_barrier() and each other, so they stay in
+// the MFMA shadow they were written in (the compiler otherwise gathers pure VALU ops after the
+// MFMA block).  s_nop 0: a TRANS result needs one wait state before a non-TRANS VALU reads it.
+__device__ __forceinline__ float pinned_exp2(float x) {
+    float y;
+    asm volatile("v_exp_f32 %0, %1\n\ts_nop 0" : "=v"(y) : "v"(x));
+    return y;
+}
+__device__ __forceinline__ float pinned_max(float a, float b) {
+    float y;
+    asm volatile("v_max_f32 %0, %1, %2" : "=v"(y) : "v"(a), "v"(b));
+    return y;
+}
 
 // bijective "contiguous chunk per XCD" remap of a 1-D grid: hardware places
 // block b on XCD b%8; give each XCD a contiguous range of work items so blocks
@@ -325,6 +342,324 @@ __global__ __launch_bounds__(256, 2) void fused_partial_kernel(PartialArgs a, in
 }
 
 // ---------------------------------------------------------------------------
+// Software-pipelined variant for dense dk, dv in {64, 128} (leading dimensions equal to
+// the dims, i.e. no padding columns).  Same maths and same outputs as
+// fused_partial_kernel; what changes is the schedule inside a wave:
+//   * K/V tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave
+//     instruction, no staging registers).  The DMA destination is lane-linear, so the
+//     conflict-free K image is an XOR swizzle of the 16-byte chunks (chunk c of row r sits
+//     at position c ^ (r & 15)) applied on the per-lane SOURCE address and undone by the
+//     reads; V rows are read whole and need none.
+//   * two score tiles are live: while the matrix pipe runs S^T(t+1) = K(t+1).Q^T, the VALU
+//     turns S^T(t) into P(t) (fma + exp2 + row-sum), 2 values per 8 MFMAs; while it runs
+//     O^T += V(t)^T.P(t)^T, the VALU reduces the row max of S^T(t+1).  The only serial
+//     pieces left per tile are the (rare) accumulator rescale and the barrier.
+//   * K is staged two tiles ahead, V one tile ahead, in two buffers each.
+// ---------------------------------------------------------------------------
+// ABL: timing-only ablation switches (results are wrong when non-zero; $SDPA_TUNE selects them):
+//   1 = no DMA / no barrier in the steady state, 2 = no LDS fragment reads, 4 = no softmax VALU
+template <int DK, int DV, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, int kv_per_split,
+                                                                  int n_qblocks, float scale) {
+    constexpr int NU = DK / 8;                // 16-byte K reads per tile per lane
+    constexpr int PPU = 16 / NU;              // P values finished per 4-MFMA QK^T step
+    constexpr int NT = DV / 32;               // O^T tiles
+    constexpr int KTILE = kKvTile * DK;       // floats
+    constexpr int VTILE = kKvTile * DV;
+    constexpr int KCH = DK / 4;               // 16-byte chunks per K row
+    constexpr int VCH = DV / 4;
+    constexpr int KPW = (kKvTile * KCH / 64) / 4;   // 1-KiB DMA pieces per wave per K tile
+    constexpr int VPW = (kKvTile * VCH / 64) / 4;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *const Ks = smem;                   // [2][KTILE], swizzled chunks
+    float *const Vs = smem + 2 * KTILE;       // [2][VTILE]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31;
+    const int hi = lane >> 5;
+
+    const int work = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = work / n_qblocks;
+    const int qblock = work - split * n_qblocks;
+    const int qrow = qblock * kQRowsPerBlock + wave * 32 + li;
+
+    const int kv_begin = split * kv_per_split;
+    const int kv_end = min(a.n_local, kv_begin + kv_per_split);
+    const int T = kv_end > kv_begin ? (kv_end - kv_begin + kKvTile - 1) / kKvTile : 0;
+    const float c = scale * 1.44269504088896340736f;
+
+    float4 qf[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+        qf[u] = qrow < a.m ? *reinterpret_cast<const float4 *>(a.Q + (size_t)qrow * DK + 8 * u + 4 * hi)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    f32x16 oacc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // ---- LDS-DMA staging: per-lane source byte offsets inside a tile (loop invariant)
+    unsigned koff[KPW], voff[VPW];
+#pragma unroll
+    for (int j = 0; j < KPW; ++j) {
+        const int row = (wave * KPW + j) * (64 / KCH) + lane / KCH;
+        const int cpos = lane % KCH;
+        koff[j] = (unsigned)(row * DK * 4 + ((cpos ^ (row & 15)) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < VPW; ++j) {
+        const int row = (wave * VPW + j) * (64 / VCH) + lane / VCH;
+        voff[j] = (unsigned)(row * DV * 4 + ((lane % VCH) << 4));
+    }
+    // The DMA is issued from inline asm on purpose: hipcc treats the builtin as a pending LDS
+    // write and drains vmcnt(0) before the next ds_read, which would serialise the stream.
+    // Hidden in asm, the loads stay in flight under the MFMAs; they are drained by the explicit
+    // s_waitcnt vmcnt(0) in front of the end-of-step barrier (stage_fence).
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane(
+        (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)smem);
+    auto dma_piece = [&](const char *gbase, unsigned lane_off, unsigned lds_byte) __attribute__((always_inline)) {
+        if constexpr (ABL & 1) return;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %2\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %3\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(lane_off), "s"(lds_byte), "s"(gbase)
+                     : "memory");
+    };
+    auto stage_fence = [&]() __attribute__((always_inline)) {
+        if constexpr (ABL & 1) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    auto dma_k = [&](int tile, int buf) __attribute__((always_inline)) {
+        const int base = kv_begin + tile * kKvTile;
+        const int last = kv_end - 1 - base;
+        const char *kb = reinterpret_cast<const char *>(a.K + (size_t)base * DK);
+#pragma unroll
+        for (int j = 0; j < KPW; ++j) {
+            unsigned off = koff[j];
+            if (last < kKvTile - 1) {         // ragged tile: clamp the source row, keep the chunk
+                const unsigned row = min((int)(off / (DK * 4)), last);
+                off = row * (DK * 4) + (off % (DK * 4));
+            }
+            dma_piece(kb, off, lds_base + (unsigned)(buf * KTILE + (wave * KPW + j) * 256) * 4u);
+        }
+    };
+    auto dma_v = [&](int tile, int buf) __attribute__((always_inline)) {
+        const int base = kv_begin + tile * kKvTile;
+        const int last = kv_end - 1 - base;
+        const char *vb = reinterpret_cast<const char *>(a.V + (size_t)base * DV);
+#pragma unroll
+        for (int j = 0; j < VPW; ++j) {
+            unsigned off = voff[j];
+            if (last < kKvTile - 1) {
+                const unsigned row = min((int)(off / (DV * 4)), last);
+                off = row * (DV * 4) + (off % (DV * 4));
+            }
+            dma_piece(vb, off, lds_base + (unsigned)((2 * KTILE + buf * VTILE) + (wave * VPW + j) * 256) * 4u);
+        }
+    };
+
+    // K fragment byte addresses inside a K buffer: chunk (2u+hi) of row li, un-swizzled
+    // (the XOR only touches the low 4 chunk bits: chunks 16..31 of a 128-wide row are the
+    //  same 8 addresses + 256 bytes)
+    unsigned kaddr[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) kaddr[u] = (unsigned)(li * DK * 4 + (((2 * u + hi) ^ (li & 15)) << 4));
+
+    auto kfrag = [&](int buf, int u) __attribute__((always_inline)) -> float4 {
+        if constexpr (ABL & 2) return qf[(u + 1) % NU];
+        return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Ks + buf * KTILE) +
+                                                 kaddr[u & 7] + (u >> 3) * 256);
+    };
+
+    // P(t) from S(t): 16 values, called in slices from inside the QK^T groups
+    auto softmax_slice = [&](f32x16 &su, int first, int count, float mc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = first; r < first + count; ++r) {
+            su[r] = fast_exp2(fmaf(su[r], c, -mc));
+            l_run += su[r];
+        }
+    };
+    auto mask_ragged = [&](f32x16 &sx, int tile) __attribute__((always_inline)) {
+        const int valid = kv_end - (kv_begin + tile * kKvTile);
+        if (valid < kKvTile) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (crow(r, hi) >= valid) sx[r] = -INFINITY;
+        }
+    };
+    // fold the row max of a finished score tile into the running max; rescale O, l if it moved
+    auto absorb_max = [&](float tmax) __attribute__((always_inline)) {
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float m_new = fmaxf(m_run, tmax);
+        if (__any(m_new > m_run)) {
+            const float alpha = fast_exp2((m_run - m_new) * c);   // first tile: exp2(-inf) = 0
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[tt][r] *= alpha;
+            l_run *= alpha;
+            m_run = m_new;
+        }
+    };
+
+    // one pipelined tile step: consumes S(t) in `su`, produces S(t+1) in `sm`
+    auto step = [&](auto has_next, f32x16 &su, f32x16 &sm, int t) __attribute__((always_inline)) {
+        constexpr bool HAS_NEXT = decltype(has_next)::value;
+        const int vbuf = t & 1, kbuf = (t + 1) & 1;
+        if (t + 2 < T) dma_k(t + 2, t & 1);
+        if (t + 1 < T) dma_v(t + 1, (t + 1) & 1);
+        const float mc = m_run * c;
+
+        if constexpr (HAS_NEXT) {
+            // [A] S^T(t+1) on the matrix pipe  ||  P(t) on the VALU.  Per 4 MFMAs: the K
+            // fragment for the step after next is read, and PPU score(s) become P values.  The
+            // exp2 is a volatile asm so that it stays inside its sched_barrier-fenced slot.
+            float4 kf = kfrag(kbuf, 0);
+            float4 kn = kfrag(kbuf, 1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sm[r] = 0.f;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                float4 kn2 = kn;
+                if (u + 2 < NU) kn2 = kfrag(kbuf, u + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                sm = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[u].x, sm, 0, 0, 0);
+                sm = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[u].y, sm, 0, 0, 0);
+                sm = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[u].z, sm, 0, 0, 0);
+                sm = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[u].w, sm, 0, 0, 0);
+#pragma unroll
+                for (int r = u * PPU; r < (u + 1) * PPU; ++r) {
+                    if constexpr (ABL & 4) {
+                        asm volatile("" : "+v"(su[r]));
+                    } else {
+                        su[r] = pinned_exp2(fmaf(su[r], c, -mc));
+                        l_run += su[r];
+                    }
+                }
+                kf = kn;
+                kn = kn2;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            softmax_slice(su, 0, 16, mc);
+        }
+
+        // [B] O^T += V(t)^T.P(t)^T on the matrix pipe  ||  row max of S^T(t+1) on the VALU
+        if constexpr (HAS_NEXT) mask_ragged(sm, t + 1);
+        const float *vt = Vs + vbuf * VTILE + NT * li + 4 * hi * DV;
+        float tmax = -INFINITY;
+        auto vload = [&](int r) __attribute__((always_inline)) -> VFrag<NT> {
+            if constexpr (ABL & 2) {
+                VFrag<NT> f;
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) f.v[tt] = qf[r % NU].x;
+                return f;
+            } else {
+                return VFrag<NT>::load(vt + crow(r, 0) * DV);
+            }
+        };
+        VFrag<NT> vf = vload(0);
+        VFrag<NT> vn = vload(1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            VFrag<NT> vn2 = vn;
+            if (r + 2 < 16) vn2 = vload(r + 2);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+                oacc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.v[tt], su[r], oacc[tt], 0, 0, 0);
+            // row max of S(t+1): starts one step late so that the QK^T chain has drained
+            if constexpr (HAS_NEXT && !(ABL & 4)) {
+                if (r >= 1) tmax = pinned_max(tmax, sm[r - 1]);
+                if (r == 15) tmax = pinned_max(tmax, sm[15]);
+            }
+            vf = vn;
+            vn = vn2;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (HAS_NEXT && !(ABL & 4)) absorb_max(tmax);
+        stage_fence();                        // drain this wave's DMAs, then barrier
+    };
+
+    f32x16 sA, sB;
+    if (T > 0) {
+        dma_k(0, 0);
+        dma_v(0, 0);
+        if (T > 1) dma_k(1, 1);
+        stage_fence();
+        // prologue: S^T(0), its mask and max
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sA[r] = 0.f;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const float4 kf = kfrag(0, u);
+            sA = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[u].x, sA, 0, 0, 0);
+            sA = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[u].y, sA, 0, 0, 0);
+            sA = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[u].z, sA, 0, 0, 0);
+            sA = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[u].w, sA, 0, 0, 0);
+        }
+        mask_ragged(sA, 0);
+        float tmax = sA[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sA[r]);
+        absorb_max(tmax);
+        __syncthreads();                      // everyone is done with K(0) before K(2) lands on it
+
+        int t = 0;
+        for (; t + 2 < T; t += 2) {
+            step(std::true_type(), sA, sB, t);
+            step(std::true_type(), sB, sA, t + 1);
+        }
+        if (T - t == 2) {
+            step(std::true_type(), sA, sB, t);
+            step(std::false_type(), sB, sA, t + 1);
+        } else {
+            step(std::false_type(), sA, sB, t);
+        }
+    }
+
+    // ---- epilogue (identical to fused_partial_kernel)
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    float *out = a.contrib;
+    float *omax = a.lmax, *osum = a.lsum;
+    int ldo = a.ldo;
+    if (a.kv_splits > 1) {
+        ldo = a.ws_ld;
+        out = a.ws_contrib + (size_t)split * a.m * ldo;
+        omax = a.ws_lmax + (size_t)split * a.m;
+        osum = a.ws_lsum + (size_t)split * a.m;
+    }
+    if (qrow < a.m) {
+        float *orow = out + (size_t)qrow * ldo;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int col0 = NT * crow(r, hi);
+            if constexpr (NT == 4) {
+                *reinterpret_cast<float4 *>(orow + col0) =
+                    make_float4(oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]);
+            } else {
+                *reinterpret_cast<float2 *>(orow + col0) = make_float2(oacc[0][r], oacc[1][r]);
+            }
+        }
+        if (hi == 0) {
+            omax[qrow] = m_run * scale;
+            osum[qrow] = l_tot;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // In-GPU split merge: the reference's shard merge (attention-mpi.c:340-362 minus
 // the final 1/gsum, which stays with the caller) applied to the kv_splits partial
 // triples of one GPU.  One thread per (row, 4 columns).
@@ -483,6 +818,36 @@ static hipError_t launch_fast(const PartialArgs &a, hipStream_t s) {
     return e;
 }
 
+template <int DK, int DV, int ABL = 0>
+static hipError_t launch_pipelined(const PartialArgs &a, hipStream_t s) {
+    const int nqb = (a.m + kQRowsPerBlock - 1) / kQRowsPerBlock;
+    const int ntiles = (a.n_local + kKvTile - 1) / kKvTile;
+    const int tiles_per_split = (ntiles + a.kv_splits - 1) / a.kv_splits;
+    const int kv_per_split = tiles_per_split > 0 ? tiles_per_split * kKvTile : kKvTile;
+    const size_t lds = (size_t)2 * kKvTile * (DK + DV) * sizeof(float);
+    static bool attr_done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&fused_pipelined_kernel<DK, DV, ABL>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done[dev] = true;
+    }
+    const float scale = 1.0f / sqrtf((float)a.dk);   // attention-mpi.c:208
+    hipLaunchKernelGGL((fused_pipelined_kernel<DK, DV, ABL>), dim3(nqb * a.kv_splits), dim3(256), lds, s,
+                       a, kv_per_split, nqb, scale);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (a.kv_splits > 1) {
+        const long work = (long)a.m * (a.ws_ld / 4);
+        hipLaunchKernelGGL(split_merge_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, a);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
 hipError_t launch_shard_partial(const PartialArgs &a_in, hipStream_t s) {
     PartialArgs a = a_in;
     static const int tune_env = getenv("SDPA_TUNE") ? atoi(getenv("SDPA_TUNE")) : 0;
@@ -494,6 +859,25 @@ hipError_t launch_shard_partial(const PartialArgs &a_in, hipStream_t s) {
         const float scale = 1.0f / sqrtf((float)a.dk);
         hipLaunchKernelGGL(generic_partial_kernel, dim3((a.m + 3) / 4), dim3(256), lds, s, a, scale);
         return hipGetLastError();
+    }
+    // dense 64/128-wide operands take the software-pipelined LDS-DMA kernel ($SDPA_TUNE&4: off)
+    const bool dense = a.ldq == a.dk && a.ldk == a.dk && a.ldv == a.dv && a.ldo % 4 == 0 &&
+                       (reinterpret_cast<uintptr_t>(a.K) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.V) & 15) == 0;
+    if (dense && !(a.tune & 4)) {
+        if (a.dk == 128 && a.dv == 128) {
+            switch ((a.tune >> 4) & 7) {     // timing-only ablations, see fused_pipelined_kernel
+                case 1: return launch_pipelined<128, 128, 1>(a, s);
+                case 2: return launch_pipelined<128, 128, 2>(a, s);
+                case 3: return launch_pipelined<128, 128, 3>(a, s);
+                case 4: return launch_pipelined<128, 128, 4>(a, s);
+                case 7: return launch_pipelined<128, 128, 7>(a, s);
+                default: break;
+            }
+            return launch_pipelined<128, 128>(a, s);
+        }
+        if (a.dk == 64 && a.dv == 64) return launch_pipelined<64, 64>(a, s);
+        if (a.dk == 128 && a.dv == 64) return launch_pipelined<128, 64>(a, s);
+        if (a.dk == 64 && a.dv == 128) return launch_pipelined<64, 128>(a, s);
     }
     const int kp = pad_dim(a.dk), vp = pad_dim(a.dv);
 #define SDPA_CASE(KP, VP) if (kp == KP && vp == VP) return launch_fast<KP, VP>(a, s);
