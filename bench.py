@@ -207,7 +207,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath) and world == 1 and args.workload == "headline":
             try:
-                traffic = json.load(open(tpath))
+                traffic = json.load(open(tpath))["per_launch_bytes"]
             except Exception:  # noqa: BLE001
                 traffic = None
         line = {
@@ -231,7 +231,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
                          "traffic": traffic,
-                         "kernel": "sdpa::fused_partial_kernel<128,128>" if d == 128 else "sdpa::fused_partial_kernel",
+                         "kernel": "sdpa::fused_pipelined_kernel<%d,%d,0>" % (d, d) if d in (64, 128) else "sdpa::fused_partial_kernel",
                          "kernel_ms_avg": avg_ms, "launches": len(k_ms),
                          "flop_per_launch": flop_per_launch},
         }

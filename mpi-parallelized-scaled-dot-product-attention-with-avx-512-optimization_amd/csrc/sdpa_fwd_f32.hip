@@ -59,6 +59,11 @@ __device__ __forceinline__ float pinned_exp2(float x) {
     asm volatile("v_exp_f32 %0, %1\n\ts_nop 0" : "=v"(y) : "v"(x));
     return y;
 }
+__device__ __forceinline__ float pinned_max3(float a, float b, float c) {
+    float y;
+    asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(y) : "v"(a), "v"(b), "v"(c));
+    return y;
+}
 __device__ __forceinline__ float pinned_max(float a, float b) {
     float y;
     asm volatile("v_max_f32 %0, %1, %2" : "=v"(y) : "v"(a), "v"(b));
@@ -391,18 +396,30 @@ __global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, 
     const int T = kv_end > kv_begin ? (kv_end - kv_begin + kKvTile - 1) / kKvTile : 0;
     const float c = scale * 1.44269504088896340736f;
 
+    // Q is pre-multiplied by scale*log2(e): the MFMA chain then yields scores directly in the
+    // exp2 domain, and with the accumulator initialised to -m_ref it yields (score - m_ref), so a
+    // P value costs ONE VALU instruction (v_exp_f32).  VALU cycles are MFMA cycles lost here: the
+    // f32-input MFMA runs at the f32 vector rate and does not overlap VALU issue.
     float4 qf[NU];
 #pragma unroll
-    for (int u = 0; u < NU; ++u)
+    for (int u = 0; u < NU; ++u) {
         qf[u] = qrow < a.m ? *reinterpret_cast<const float4 *>(a.Q + (size_t)qrow * DK + 8 * u + 4 * hi)
                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        qf[u].x *= c; qf[u].y *= c; qf[u].z *= c; qf[u].w *= c;
+    }
 
     f32x16 oacc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    // Softmax state of this lane's query row, all in the exp2 domain:
+    //   m_ref   reference exponent the accumulators are relative to (the row max when it was
+    //           last moved; NOT moved for rises below kDeferLog2 -- fp32 has the headroom)
+    //   max_rel running (true row max - m_ref) >= 0, folded back in at the epilogue
+    //   l_run   this half-wave's share of sum exp2(score - m_ref)
+    constexpr float kDeferLog2 = 24.0f;
+    float m_ref = 0.f, max_rel = 0.f, l_run = 0.f;
 
     // ---- LDS-DMA staging: per-lane source byte offsets inside a tile (loop invariant)
     unsigned koff[KPW], voff[VPW];
@@ -482,14 +499,6 @@ __global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, 
                                                  kaddr[u & 7] + (u >> 3) * 256);
     };
 
-    // P(t) from S(t): 16 values, called in slices from inside the QK^T groups
-    auto softmax_slice = [&](f32x16 &su, int first, int count, float mc) __attribute__((always_inline)) {
-#pragma unroll
-        for (int r = first; r < first + count; ++r) {
-            su[r] = fast_exp2(fmaf(su[r], c, -mc));
-            l_run += su[r];
-        }
-    };
     auto mask_ragged = [&](f32x16 &sx, int tile) __attribute__((always_inline)) {
         const int valid = kv_end - (kv_begin + tile * kKvTile);
         if (valid < kKvTile) {
@@ -498,19 +507,27 @@ __global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, 
                 if (crow(r, hi) >= valid) sx[r] = -INFINITY;
         }
     };
-    // fold the row max of a finished score tile into the running max; rescale O, l if it moved
-    auto absorb_max = [&](float tmax) __attribute__((always_inline)) {
+    // Row max of a finished score tile (relative to m_ref).  Only a rise of more than
+    // 2^kDeferLog2 moves m_ref: O, l and the pending scores `sx` are then all brought to the
+    // new reference exactly once.  (Rare: after the first tile it needs a key whose score beats
+    // everything seen so far by > 16.6 in natural-log units.)
+    auto absorb_rel = [&](float tmax, f32x16 &sx) __attribute__((always_inline)) {
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float m_new = fmaxf(m_run, tmax);
-        if (__any(m_new > m_run)) {
-            const float alpha = fast_exp2((m_run - m_new) * c);   // first tile: exp2(-inf) = 0
+        if (__any(tmax > kDeferLog2)) {
+            const float jump = fmaxf(tmax, 0.f);
+            const float alpha = fast_exp2(-jump);
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oacc[tt][r] *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sx[r] -= jump;
             l_run *= alpha;
-            m_run = m_new;
+            m_ref += jump;
+            max_rel -= jump;
+            tmax -= jump;
         }
+        max_rel = fmaxf(max_rel, tmax);
     };
 
     // one pipelined tile step: consumes S(t) in `su`, produces S(t+1) in `sm`
@@ -519,8 +536,6 @@ __global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, 
         const int vbuf = t & 1, kbuf = (t + 1) & 1;
         if (t + 2 < T) dma_k(t + 2, t & 1);
         if (t + 1 < T) dma_v(t + 1, (t + 1) & 1);
-        const float mc = m_run * c;
-
         if constexpr (HAS_NEXT) {
             // [A] S^T(t+1) on the matrix pipe  ||  P(t) on the VALU.  Per 4 MFMAs: the K
             // fragment for the step after next is read, and PPU score(s) become P values.  The
@@ -528,7 +543,7 @@ __global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, 
             float4 kf = kfrag(kbuf, 0);
             float4 kn = kfrag(kbuf, 1);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sm[r] = 0.f;
+            for (int r = 0; r < 16; ++r) sm[r] = -m_ref;
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 float4 kn2 = kn;
@@ -543,7 +558,7 @@ __global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, 
                     if constexpr (ABL & 4) {
                         asm volatile("" : "+v"(su[r]));
                     } else {
-                        su[r] = pinned_exp2(fmaf(su[r], c, -mc));
+                        su[r] = pinned_exp2(su[r]);
                         l_run += su[r];
                     }
                 }
@@ -552,7 +567,11 @@ __global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, 
             }
             __builtin_amdgcn_sched_barrier(0);
         } else {
-            softmax_slice(su, 0, 16, mc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                su[r] = fast_exp2(su[r]);
+                l_run += su[r];
+            }
         }
 
         // [B] O^T += V(t)^T.P(t)^T on the matrix pipe  ||  row max of S^T(t+1) on the VALU
@@ -581,14 +600,15 @@ __global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, 
                 oacc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.v[tt], su[r], oacc[tt], 0, 0, 0);
             // row max of S(t+1): starts one step late so that the QK^T chain has drained
             if constexpr (HAS_NEXT && !(ABL & 4)) {
-                if (r >= 1) tmax = pinned_max(tmax, sm[r - 1]);
-                if (r == 15) tmax = pinned_max(tmax, sm[15]);
+                if (r == 2) tmax = pinned_max(sm[0], sm[1]);
+                if (r >= 4 && (r & 1) == 0) tmax = pinned_max3(tmax, sm[r - 2], sm[r - 1]);
+                if (r == 15) tmax = pinned_max3(tmax, sm[14], sm[15]);
             }
             vf = vn;
             vn = vn2;
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (HAS_NEXT && !(ABL & 4)) absorb_max(tmax);
+        if constexpr (HAS_NEXT && !(ABL & 4)) absorb_rel(tmax, sm);
         stage_fence();                        // drain this wave's DMAs, then barrier
     };
 
@@ -613,7 +633,9 @@ __global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, 
         float tmax = sA[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sA[r]);
-        absorb_max(tmax);
+        m_ref = fmaxf(tmax, __shfl_xor(tmax, 32));      // finite: every tile has a valid key row
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sA[r] -= m_ref;
         __syncthreads();                      // everyone is done with K(0) before K(2) lands on it
 
         int t = 0;
@@ -629,8 +651,14 @@ __global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, 
         }
     }
 
-    // ---- epilogue (identical to fused_partial_kernel)
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    // ---- epilogue: express the triple relative to the TRUE row max (m_ref + max_rel), in the
+    //      reference's units (lmax is a natural-log score: exp2-domain value * ln 2)
+    const float fold = fast_exp2(-max_rel);
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[tt][r] *= fold;
+    const float l_tot = (l_run + __shfl_xor(l_run, 32)) * fold;
     float *out = a.contrib;
     float *omax = a.lmax, *osum = a.lsum;
     int ldo = a.ldo;
@@ -653,7 +681,7 @@ __global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, 
             }
         }
         if (hi == 0) {
-            omax[qrow] = m_run * scale;
+            omax[qrow] = T > 0 ? (m_ref + max_rel) * 0.69314718055994530942f : -INFINITY;
             osum[qrow] = l_tot;
         }
     }

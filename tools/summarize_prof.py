@@ -32,3 +32,29 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
     for name, cs in acc.items():
         for c, v in cs.items():
             print("   %-70s %-28s n=%d mean=%.6g" % (name, c, len(v), sum(v) / len(v)))
+
+# ---- HBM-side traffic of the fused kernel per launch, for bench.py's roofline.traffic.
+# Collected as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes,
+# units are KiB, and on gfx950 FETCH_SIZE reports half the bytes of wide (16 B/lane) streaming
+# reads, so it is doubled; WRITE_SIZE is taken as is (uncalibrated).
+import json
+
+
+def fused_mean(d, counter):
+    vals = []
+    for p in glob.glob(os.path.join(out, d, "**", "*counter_collection.csv"), recursive=True):
+        for r in rows(p):
+            if "fused_" in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
+                vals.append(float(r["Counter_Value"]))
+    return sum(vals) / len(vals) if vals else None
+
+
+f, w = fused_mean("pmc_fetch", "FETCH_SIZE"), fused_mean("pmc_write", "WRITE_SIZE")
+if f is not None and w is not None:
+    t = {"per_launch_bytes": f * 1024 * 2 + w * 1024, "fetch_size_kib": f, "write_size_kib": w,
+         "correction": "FETCH_SIZE KiB x1024 x2 (gfx950 wide-read under-count) + WRITE_SIZE KiB x1024",
+         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python bench.py --steps 2 --warmup 1"}
+    json.dump(t, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+    print()
+    print("== fused kernel HBM-side traffic per launch ==")
+    print(json.dumps(t))
