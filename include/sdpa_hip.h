@@ -49,6 +49,8 @@ extern "C" {
 /* flags for sdpa_attention_f64 */
 #define SDPA_F_DEFAULT     0
 #define SDPA_F_NO_PIPELINE 1   /* one Q batch, no copy/compute overlap (debug)     */
+#define SDPA_F_BF16        2   /* bf16-input MFMA path (fp32 accumulate/softmax);  */
+                               /* also selected by $SDPA_PRECISION=bf16            */
 
 /* Per-call wall-clock breakdown of the last sdpa_attention_f64(), microseconds. */
 struct sdpa_timing {
@@ -138,6 +140,31 @@ SDPA_API int sdpa_dev_merge_normalise(float *contrib, int ldo, const float *gsum
  * writeback of :373,:396.  result[m x dv] dense fp64.                         */
 SDPA_API int sdpa_dev_finish_f64(const float *contrib, int ldo, const float *lsum,
                                  double *result, int m, int dv, void *stream);
+
+/* ---- device level, bf16-input MFMA variant (BASELINE.json config 5) ---------- */
+/* Same stage as sdpa_dev_shard_partial_f32 with operands rounded to bf16 (RNE) and
+ * fp32 accumulation; tolerance 1e-2*max(1,max|V|).  Operand images:
+ *   Qb[m x ld], Kb[n_local x ld]   bf16 row-major, ld = sdpa_dev_bf16_ld(dk) (dk padded to
+ *                                  64/128/256/512), pad columns zero;
+ *   Vt[dvp x ldvt]                 bf16, V TRANSPOSED: Vt[c*ldvt + j] = V[j][c];
+ *                                  dvp = sdpa_dev_bf16_dvp(dv), ldvt = sdpa_dev_bf16_ldn(n_local)
+ *                                  (n_local padded to 32), pads zero.
+ * sdpa_dev_cvt_d2bf / sdpa_dev_cvt_d2bf_t write these images from dense fp64.
+ * dk <= 512, dv <= 1024.                                                          */
+SDPA_API int  sdpa_dev_bf16_ld(int dk);
+SDPA_API int  sdpa_dev_bf16_dvp(int dv);
+SDPA_API long sdpa_dev_bf16_ldn(long n_local);
+SDPA_API int  sdpa_dev_cvt_d2bf(const double *src, void *dst, long rows, int cols, int ld,
+                                void *stream);
+SDPA_API int  sdpa_dev_cvt_d2bf_t(const double *src, void *dst, long rows, int cols, int cols_pad,
+                                  long ldt, void *stream);
+SDPA_API int    sdpa_dev_kv_splits_bf16(int m, int n_local, int dk, int dv);
+SDPA_API size_t sdpa_dev_workspace_bytes_bf16(int m, int n_local, int dk, int dv);
+SDPA_API int  sdpa_dev_shard_partial_bf16(const void *Qb, int ldq, const void *Kb, int ldk,
+                                          const void *Vt, long ldvt, float *contrib, int ldo,
+                                          float *lmax, float *lsum, int m, int n_local, int dk,
+                                          int dv, void *workspace, size_t workspace_bytes,
+                                          void *stream);
 
 #ifdef __cplusplus
 }

@@ -14,6 +14,7 @@ REPO_DIR = os.path.dirname(PKG_DIR)
 LIB_PATH = os.path.join(PKG_DIR, "lib", "libsdpa_hip.so")
 HEADER_PATH = os.path.join(REPO_DIR, "include", "sdpa_hip.h")
 
+SDPA_F_NO_PIPELINE, SDPA_F_BF16 = 1, 2
 SDPA_OK, SDPA_EINVAL, SDPA_ENODEV, SDPA_EHIP, SDPA_ERCCL, SDPA_ENOMEM, SDPA_EUNSUP = 0, -1, -2, -3, -4, -5, -6
 
 _c_int, _c_long, _c_size_t, _c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_size_t, ctypes.c_void_p
@@ -53,6 +54,17 @@ _PROTOS = {
                                         _c_int, _c_int, _c_void_p]),
     "sdpa_dev_merge_normalise": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p]),
     "sdpa_dev_finish_f64": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p]),
+    "sdpa_dev_bf16_ld": (_c_int, [_c_int]),
+    "sdpa_dev_bf16_dvp": (_c_int, [_c_int]),
+    "sdpa_dev_bf16_ldn": (_c_long, [_c_long]),
+    "sdpa_dev_cvt_d2bf": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p]),
+    "sdpa_dev_cvt_d2bf_t": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_long, _c_void_p]),
+    "sdpa_dev_kv_splits_bf16": (_c_int, [_c_int] * 4),
+    "sdpa_dev_workspace_bytes_bf16": (_c_size_t, [_c_int] * 4),
+    "sdpa_dev_shard_partial_bf16": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_long,
+                                             _c_void_p, _c_int, _c_void_p, _c_void_p,
+                                             _c_int, _c_int, _c_int, _c_int,
+                                             _c_void_p, _c_size_t, _c_void_p]),
 }
 
 _lib = None

@@ -34,7 +34,7 @@ using sdpa::PartialArgs;
 // ---- minimal RCCL surface (NCCL API), resolved at run time ------------------
 typedef struct ncclComm *ncclComm_t;
 enum { kNcclSuccess = 0 };
-enum { kNcclFloat = 7 };                 // ncclFloat32
+enum { kNcclUint8 = 1, kNcclFloat = 7 };  // ncclUint8, ncclFloat32
 enum { kNcclSum = 0, kNcclMax = 2 };     // ncclRedOp_t
 struct Rccl {
     void *handle = nullptr;
@@ -283,22 +283,36 @@ int sdpa_last_timing(struct sdpa_timing *out) {
 // =============================================================================
 // host level
 // =============================================================================
-static int stage_kv_shard(Gpu &g, const double *K, const double *V, int n, int dk, int dv, int P) {
+static int stage_kv_shard(Gpu &g, const double *K, const double *V, int n, int dk, int dv, int P,
+                          bool bf16) {
     const int cnt = sdpa_owner_count(n, P, g.dev);
     const int off = sdpa_owner_disp(n, P, g.dev);
     const int ldk = round4(dk), ldv = round4(dv);
     HIP_TRY(hipSetDevice(g.dev));
     SDPA_TRY(ensure(g.k64, (size_t)cnt * dk * sizeof(double)));
     SDPA_TRY(ensure(g.v64, (size_t)cnt * dv * sizeof(double)));
-    SDPA_TRY(ensure(g.kf, (size_t)cnt * ldk * sizeof(float)));
-    SDPA_TRY(ensure(g.vf, (size_t)cnt * ldv * sizeof(float)));
+    const int ldb = sdpa::bf16_pad_dk(dk), dvp = sdpa::bf16_pad_dv(dv);
+    const long ldn = sdpa::bf16_pad_n(cnt);
+    if (bf16) {
+        SDPA_TRY(ensure(g.kf, (size_t)cnt * ldb * sizeof(unsigned short)));
+        SDPA_TRY(ensure(g.vf, (size_t)dvp * ldn * sizeof(unsigned short)));
+    } else {
+        SDPA_TRY(ensure(g.kf, (size_t)cnt * ldk * sizeof(float)));
+        SDPA_TRY(ensure(g.vf, (size_t)cnt * ldv * sizeof(float)));
+    }
     if (cnt > 0) {
         HIP_TRY(hipMemcpyAsync(g.k64.p, K + (size_t)off * dk, (size_t)cnt * dk * sizeof(double),
                                hipMemcpyHostToDevice, g.s_in));
-        HIP_TRY(sdpa::launch_cvt_d2f((const double *)g.k64.p, (float *)g.kf.p, cnt, dk, ldk, g.s_in));
+        if (bf16)
+            HIP_TRY(sdpa::launch_cvt_d2bf((const double *)g.k64.p, (unsigned short *)g.kf.p, cnt, dk, ldb, g.s_in));
+        else
+            HIP_TRY(sdpa::launch_cvt_d2f((const double *)g.k64.p, (float *)g.kf.p, cnt, dk, ldk, g.s_in));
         HIP_TRY(hipMemcpyAsync(g.v64.p, V + (size_t)off * dv, (size_t)cnt * dv * sizeof(double),
                                hipMemcpyHostToDevice, g.s_in));
-        HIP_TRY(sdpa::launch_cvt_d2f((const double *)g.v64.p, (float *)g.vf.p, cnt, dv, ldv, g.s_in));
+        if (bf16)
+            HIP_TRY(sdpa::launch_cvt_d2bf_t((const double *)g.v64.p, (unsigned short *)g.vf.p, cnt, dv, dvp, ldn, g.s_in));
+        else
+            HIP_TRY(sdpa::launch_cvt_d2f((const double *)g.v64.p, (float *)g.vf.p, cnt, dv, ldv, g.s_in));
     }
     HIP_TRY(hipStreamSynchronize(g.s_in));
     return SDPA_OK;
@@ -308,24 +322,29 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
                        int n, int dk, int dv, int flags) {
     if (!Q || !K || !V || !result || m <= 0 || n <= 0 || dk <= 0 || dv <= 0) return SDPA_EINVAL;
     if (dv > 1024) return SDPA_EUNSUP;
+    bool bf16 = (flags & SDPA_F_BF16) != 0;
+    if (const char *prec = getenv("SDPA_PRECISION")) bf16 = bf16 || strcmp(prec, "bf16") == 0;
+    if (bf16 && dk > 512) return SDPA_EUNSUP;
     const double t_enter = now_us();
     if (!E.up) {
         const char *env = getenv("SDPA_GPUS");
         SDPA_TRY(sdpa_init(env ? atoi(env) : 0));
     }
     const int P = E.n;
-    const int ldq = round4(dk), ldo = round4(dv);
+    const int ldo = round4(dv);
+    const int ldq = bf16 ? sdpa::bf16_pad_dk(dk) : round4(dk);      // elements per staged Q row
+    const size_t q_elem = bf16 ? sizeof(unsigned short) : sizeof(float);
 
     // ---- K/V shards: rows [owner_disp, +owner_count) of K and V to GPU g ---------------
     // One host thread per GPU so the PCIe links work in parallel even from pageable memory.
     {
         std::vector<int> rc(P, SDPA_OK);
         if (P == 1) {
-            rc[0] = stage_kv_shard(E.g[0], K, V, n, dk, dv, P);
+            rc[0] = stage_kv_shard(E.g[0], K, V, n, dk, dv, P, bf16);
         } else {
             std::vector<std::thread> th;
             for (int i = 0; i < P; ++i)
-                th.emplace_back([&, i] { rc[i] = stage_kv_shard(E.g[i], K, V, n, dk, dv, P); });
+                th.emplace_back([&, i] { rc[i] = stage_kv_shard(E.g[i], K, V, n, dk, dv, P, bf16); });
             for (auto &t : th) t.join();
         }
         for (int i = 0; i < P; ++i) SDPA_TRY(rc[i]);
@@ -344,11 +363,13 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
         Gpu &g = E.g[i];
         HIP_TRY(hipSetDevice(g.dev));
         const int cnt = sdpa_owner_count(n, P, i);
-        const size_t ws_full = sdpa::workspace_bytes(B, cnt, dk, dv);
-        const size_t ws_tail = sdpa::workspace_bytes(m - (nb - 1) * B, cnt, dk, dv);
+        const int tail_rows = m - (nb - 1) * B;
+        const size_t ws_full = bf16 ? sdpa_dev_workspace_bytes_bf16(B, cnt, dk, dv) : sdpa::workspace_bytes(B, cnt, dk, dv);
+        const size_t ws_tail = bf16 ? sdpa_dev_workspace_bytes_bf16(tail_rows, cnt, dk, dv)
+                                    : sdpa::workspace_bytes(tail_rows, cnt, dk, dv);
         SDPA_TRY(ensure(g.ws, ws_full > ws_tail ? ws_full : ws_tail));
         for (int s = 0; s < 2; ++s) {
-            SDPA_TRY(ensure(g.qf[s], (size_t)B * ldq * sizeof(float)));
+            SDPA_TRY(ensure(g.qf[s], (size_t)B * ldq * q_elem));
             SDPA_TRY(ensure(g.contrib[s], (size_t)B * ldo * sizeof(float)));
             SDPA_TRY(ensure(g.lmax[s], (size_t)B * sizeof(float)));
             SDPA_TRY(ensure(g.lsum[s], (size_t)B * sizeof(float)));
@@ -390,8 +411,12 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
         if (b >= 2) HIP_TRY(hipStreamWaitEvent(root.s_in, root.ev_run[s], 0));
         HIP_TRY(hipMemcpyAsync(root.q64[s].p, Q + (size_t)i0 * dk, (size_t)bs * dk * sizeof(double),
                                hipMemcpyHostToDevice, root.s_in));
-        HIP_TRY(sdpa::launch_cvt_d2f((const double *)root.q64[s].p, (float *)root.qf[s].p, bs, dk,
-                                     ldq, root.s_in));
+        if (bf16)
+            HIP_TRY(sdpa::launch_cvt_d2bf((const double *)root.q64[s].p, (unsigned short *)root.qf[s].p, bs,
+                                          dk, ldq, root.s_in));
+        else
+            HIP_TRY(sdpa::launch_cvt_d2f((const double *)root.q64[s].p, (float *)root.qf[s].p, bs, dk,
+                                         ldq, root.s_in));
         HIP_TRY(hipEventRecord(root.ev_q[s], root.s_in));
         HIP_TRY(hipStreamWaitEvent(root.s_run, root.ev_q[s], 0));
         // out64[s] is still being copied out for batch b-2
@@ -400,7 +425,7 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
         if (P > 1) {   // MPI_Ibcast of the Q batch (attention-mpi.c:305,:327)
             RCCL_TRY(E.rccl.GroupStart());
             for (int i = 0; i < P; ++i)
-                RCCL_TRY(E.rccl.Broadcast(root.qf[s].p, E.g[i].qf[s].p, (size_t)bs * ldq, kNcclFloat,
+                RCCL_TRY(E.rccl.Broadcast(root.qf[s].p, E.g[i].qf[s].p, (size_t)bs * ldq * q_elem, kNcclUint8,
                                           0, E.g[i].comm, E.g[i].s_run));
             RCCL_TRY(E.rccl.GroupEnd());
         }
@@ -409,26 +434,53 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
         for (int i = 0; i < P; ++i) {
             Gpu &g = E.g[i];
             HIP_TRY(hipSetDevice(g.dev));
-            PartialArgs a = {};
-            a.Q = (const float *)g.qf[s].p;  a.ldq = ldq;
-            a.K = (const float *)g.kf.p;     a.ldk = round4(dk);
-            a.V = (const float *)g.vf.p;     a.ldv = round4(dv);
-            a.contrib = (float *)g.contrib[s].p;  a.ldo = ldo;
-            a.lmax = (float *)g.lmax[s].p;
-            a.lsum = (float *)g.lsum[s].p;
-            a.m = bs;  a.n_local = sdpa_owner_count(n, P, i);  a.dk = dk;  a.dv = dv;
-            a.kv_splits = sdpa::pick_kv_splits(bs, a.n_local, dk, dv);
-            if (a.kv_splits > 1) {
-                a.ws_ld = ldo;
-                a.ws_contrib = (float *)g.ws.p;
-                a.ws_lmax = a.ws_contrib + (size_t)a.kv_splits * bs * a.ws_ld;
-                a.ws_lsum = a.ws_lmax + (size_t)a.kv_splits * bs;
+            const int n_loc = sdpa_owner_count(n, P, i);
+            int splits_here = 1;
+            if (i == 0) HIP_TRY(hipEventRecord(g.ev_k[2 * b], g.s_run));
+            if (bf16) {
+                sdpa::Bf16Args a = {};
+                a.Q = (const unsigned short *)g.qf[s].p;  a.ldq = ldq;
+                a.K = (const unsigned short *)g.kf.p;     a.ldk = ldq;
+                a.Vt = (const unsigned short *)g.vf.p;    a.ldvt = sdpa::bf16_pad_n(n_loc);
+                a.contrib = (float *)g.contrib[s].p;  a.ldo = ldo;
+                a.lmax = (float *)g.lmax[s].p;
+                a.lsum = (float *)g.lsum[s].p;
+                a.m = bs;  a.n_local = n_loc;  a.dk = dk;  a.dv = dv;
+                a.kv_splits = splits_here = sdpa::pick_kv_splits_bf16(bs, n_loc, dk, dv);
+                if (a.kv_splits > 1) {
+                    a.ws_ld = ldo;
+                    a.ws_contrib = (float *)g.ws.p;
+                    a.ws_lmax = a.ws_contrib + (size_t)a.kv_splits * bs * a.ws_ld;
+                    a.ws_lsum = a.ws_lmax + (size_t)a.kv_splits * bs;
+                }
+                if (n_loc > 0) {
+                    HIP_TRY(sdpa::launch_shard_partial_bf16(a, g.s_run));
+                } else {   // empty shard: the fp32 launcher's T = 0 path writes (0, -inf, 0)
+                    PartialArgs e = {};
+                    e.Q = (const float *)g.qf[s].p;  e.ldq = 4;  e.ldk = 4;  e.ldv = 4;
+                    e.contrib = a.contrib;  e.ldo = ldo;  e.lmax = a.lmax;  e.lsum = a.lsum;
+                    e.m = bs;  e.n_local = 0;  e.dk = 4;  e.dv = dv;  e.kv_splits = 1;
+                    HIP_TRY(sdpa::launch_shard_partial(e, g.s_run));
+                }
+            } else {
+                PartialArgs a = {};
+                a.Q = (const float *)g.qf[s].p;  a.ldq = ldq;
+                a.K = (const float *)g.kf.p;     a.ldk = round4(dk);
+                a.V = (const float *)g.vf.p;     a.ldv = round4(dv);
+                a.contrib = (float *)g.contrib[s].p;  a.ldo = ldo;
+                a.lmax = (float *)g.lmax[s].p;
+                a.lsum = (float *)g.lsum[s].p;
+                a.m = bs;  a.n_local = n_loc;  a.dk = dk;  a.dv = dv;
+                a.kv_splits = splits_here = sdpa::pick_kv_splits(bs, a.n_local, dk, dv);
+                if (a.kv_splits > 1) {
+                    a.ws_ld = ldo;
+                    a.ws_contrib = (float *)g.ws.p;
+                    a.ws_lmax = a.ws_contrib + (size_t)a.kv_splits * bs * a.ws_ld;
+                    a.ws_lsum = a.ws_lmax + (size_t)a.kv_splits * bs;
+                }
+                HIP_TRY(sdpa::launch_shard_partial(a, g.s_run));
             }
-            if (i == 0) {
-                splits_used = a.kv_splits;
-                HIP_TRY(hipEventRecord(g.ev_k[2 * b], g.s_run));
-            }
-            HIP_TRY(sdpa::launch_shard_partial(a, g.s_run));
+            if (i == 0) splits_used = splits_here;
             if (i == 0) HIP_TRY(hipEventRecord(g.ev_k[2 * b + 1], g.s_run));
         }
 
@@ -580,6 +632,68 @@ int sdpa_dev_finish_f64(const float *contrib, int ldo, const float *lsum, double
     if (!contrib || !lsum || !result || m <= 0 || dv <= 0 || check_ld(ldo, dv)) return SDPA_EINVAL;
     SDPA_TRY(require_device());
     HIP_TRY(sdpa::launch_finish_f64(contrib, ldo, lsum, result, m, dv, (hipStream_t)stream));
+    return SDPA_OK;
+}
+
+int sdpa_dev_bf16_ld(int dk) { return (dk <= 0 || dk > 512) ? SDPA_EUNSUP : sdpa::bf16_pad_dk(dk); }
+int sdpa_dev_bf16_dvp(int dv) { return (dv <= 0 || dv > 1024) ? SDPA_EUNSUP : sdpa::bf16_pad_dv(dv); }
+long sdpa_dev_bf16_ldn(long n_local) { return n_local < 0 ? SDPA_EINVAL : sdpa::bf16_pad_n(n_local); }
+
+int sdpa_dev_cvt_d2bf(const double *src, void *dst, long rows, int cols, int ld, void *stream) {
+    if (rows < 0 || cols <= 0 || ld < cols) return SDPA_EINVAL;
+    if (rows == 0) return SDPA_OK;
+    if (!src || !dst) return SDPA_EINVAL;
+    SDPA_TRY(require_device());
+    HIP_TRY(sdpa::launch_cvt_d2bf(src, (unsigned short *)dst, rows, cols, ld, (hipStream_t)stream));
+    return SDPA_OK;
+}
+
+int sdpa_dev_cvt_d2bf_t(const double *src, void *dst, long rows, int cols, int cols_pad, long ldt,
+                        void *stream) {
+    if (rows < 0 || cols <= 0 || cols_pad < cols || ldt < rows) return SDPA_EINVAL;
+    if (!dst || (rows > 0 && !src)) return SDPA_EINVAL;
+    SDPA_TRY(require_device());
+    HIP_TRY(sdpa::launch_cvt_d2bf_t(src, (unsigned short *)dst, rows, cols, cols_pad, ldt,
+                                    (hipStream_t)stream));
+    return SDPA_OK;
+}
+
+int sdpa_dev_kv_splits_bf16(int m, int n_local, int dk, int dv) {
+    if (m <= 0 || n_local < 0 || dk <= 0 || dv <= 0) return SDPA_EINVAL;
+    return sdpa::pick_kv_splits_bf16(m, n_local, dk, dv);
+}
+
+size_t sdpa_dev_workspace_bytes_bf16(int m, int n_local, int dk, int dv) {
+    if (m <= 0 || n_local < 0 || dk <= 0 || dv <= 0) return 0;
+    const int s = sdpa::pick_kv_splits_bf16(m, n_local, dk, dv);
+    return s <= 1 ? 0 : (size_t)s * m * ((size_t)round4(dv) + 2) * sizeof(float);
+}
+
+int sdpa_dev_shard_partial_bf16(const void *Qb, int ldq, const void *Kb, int ldk, const void *Vt,
+                                long ldvt, float *contrib, int ldo, float *lmax, float *lsum, int m,
+                                int n_local, int dk, int dv, void *workspace, size_t workspace_bytes,
+                                void *stream) {
+    if (m <= 0 || n_local <= 0 || dk <= 0 || dv <= 0) return SDPA_EINVAL;
+    if (!Qb || !Kb || !Vt || !contrib || !lmax || !lsum) return SDPA_EINVAL;
+    if (dk > 512 || dv > 1024) return SDPA_EUNSUP;
+    if (ldq != sdpa::bf16_pad_dk(dk) || ldk != ldq || ldvt < n_local || ldvt % 32 != 0 || check_ld(ldo, dv))
+        return SDPA_EINVAL;
+    if ((double)sdpa::bf16_pad_dv(dv) * (double)ldvt * 2.0 >= 4294967296.0) return SDPA_EUNSUP;
+    SDPA_TRY(require_device());
+    sdpa::Bf16Args a = {};
+    a.Q = (const unsigned short *)Qb; a.ldq = ldq; a.K = (const unsigned short *)Kb; a.ldk = ldk;
+    a.Vt = (const unsigned short *)Vt; a.ldvt = ldvt;
+    a.contrib = contrib; a.ldo = ldo; a.lmax = lmax; a.lsum = lsum;
+    a.m = m; a.n_local = n_local; a.dk = dk; a.dv = dv;
+    a.kv_splits = sdpa::pick_kv_splits_bf16(m, n_local, dk, dv);
+    if (a.kv_splits > 1) {
+        if (!workspace || workspace_bytes < sdpa_dev_workspace_bytes_bf16(m, n_local, dk, dv)) return SDPA_EINVAL;
+        a.ws_ld = round4(dv);
+        a.ws_contrib = (float *)workspace;
+        a.ws_lmax = a.ws_contrib + (size_t)a.kv_splits * m * a.ws_ld;
+        a.ws_lsum = a.ws_lmax + (size_t)a.kv_splits * m;
+    }
+    HIP_TRY(sdpa::launch_shard_partial_bf16(a, (hipStream_t)stream));
     return SDPA_OK;
 }
 

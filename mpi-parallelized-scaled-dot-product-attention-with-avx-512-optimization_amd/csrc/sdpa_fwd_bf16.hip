@@ -1,0 +1,387 @@
+// sdpa_fwd_bf16.hip -- bf16-input MFMA variant of the fused online-softmax kernel
+// (BASELINE.json config 5: d_k = d_v up to 512, fp32 accumulate and softmax).
+//
+// Same hot path as sdpa_fwd_f32.hip (online_softmax_attention, attention-mpi.c:168-189,
+// for all rows of a Q batch against one K/V shard; same (contrib, lmax, lsum) outputs), with
+// the operands rounded to bf16 instead of fp32 (the reference's mixed-precision step,
+// attention-mpi.c:31-64, taken one notch further) and the two contractions on
+// v_mfma_f32_32x32x16_bf16 (dense peak ~2.5 PFLOP/s).  Tolerance of this path:
+// max|delta| <= 1e-2 * max(1, max|V|).
+//
+// Layout decisions specific to this variant:
+//   * V is handed over TRANSPOSED: Vt[dv][n] bf16 (the convert kernel writes it that way).  The
+//     P.V MFMA needs, per lane, kv-consecutive elements of one V column; with Vt that is an
+//     8-byte LDS read, no transpose instruction and no shuffle.
+//   * k-slot mapping of the second MFMA is chosen to match the C/D layout of the first: step s
+//     of half-wave hi uses key rows 16s + {4hi..4hi+3, 8+4hi..8+4hi+3}, which are exactly the
+//     rows accumulator registers 8s..8s+7 of that lane hold -- P goes from the softmax
+//     registers into the B operand with a bf16 pack only.
+//   * d = 512 does not fit one wave's registers as a 32x512 fp32 O tile next to a 32x512 Q
+//     fragment twice over, so dv is processed in chunks of <= 256 columns by separate
+//     workgroups (blockIdx carries the chunk); the score tile is recomputed per chunk.
+//   * workgroup = 4 waves x 32 query rows, 32-row K/V tiles, register-staged double buffer,
+//     one barrier per tile (the structure of fused_partial_kernel).
+#include "sdpa_internal.h"
+
+#include <math.h>
+
+namespace sdpa {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ constexpr int crow16(int r, int hi) {
+    return (r & 3) + 8 * (r >> 2) + 4 * hi;
+}
+
+__device__ __forceinline__ unsigned f32_to_bf16_rne(float x) {
+    unsigned u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);          // round to nearest even (finite inputs)
+    return u >> 16;
+}
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    return f32_to_bf16_rne(lo) | (f32_to_bf16_rne(hi) << 16);
+}
+
+__device__ __forceinline__ int xcd_remap_b(int bid, int total) {
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int q = total >> 3, r = total & 7;
+    const int first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return first + slot;
+}
+
+template <int DK, int DVC>
+__global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_kernel(
+    Bf16Args a, int kv_per_split, int n_qblocks, int n_chunks, float scale) {
+    constexpr int NKS = DK / 16;              // QK^T k-steps (one 16-byte fragment each)
+    constexpr int NT = DVC / 32;              // O^T tiles of this dv chunk
+    constexpr int KLD = DK + 8;               // bf16 elements per padded K row (+16 B)
+    constexpr int VLD = 36;                   // bf16 elements per padded Vt row (72 B, ds_read_b64 conflict-free)
+    constexpr int KTILE = kKvTile * KLD;      // bf16 elements
+    constexpr int VTILE = DVC * VLD;
+    constexpr int KPT = DK / 64;              // 16-byte K pieces staged per thread
+    constexpr int VPT = DVC / 64;             // 16-byte Vt pieces staged per thread
+
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+    unsigned short *const Ks = smem16;                    // [2][KTILE]
+    unsigned short *const Vs = smem16 + 2 * KTILE;        // [2][VTILE]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 31;
+    const int hi = lane >> 5;
+
+    int work = xcd_remap_b(blockIdx.x, gridDim.x);
+    const int qblock = work % n_qblocks;
+    work /= n_qblocks;
+    const int chunk = work % n_chunks;
+    const int split = work / n_chunks;
+    const int qrow = qblock * kQRowsPerBlock + wave * 32 + li;
+    const int dv0 = chunk * DVC;
+
+    const int kv_begin = split * kv_per_split;
+    const int kv_end = min(a.n_local, kv_begin + kv_per_split);
+    const int ntiles = kv_end > kv_begin ? (kv_end - kv_begin + kKvTile - 1) / kKvTile : 0;
+    const float c = scale * 1.44269504088896340736f;
+
+    // Q fragment (B operand of S^T = K.Q^T): k-slot (ks, hi, j) <-> dk index 16ks + 8hi + j
+    u32x4 qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        if (qrow < a.m)
+            qf[ks] = *reinterpret_cast<const u32x4 *>(a.Q + (size_t)qrow * a.ldq + 16 * ks + 8 * hi);
+        else
+            qf[ks] = u32x4{0u, 0u, 0u, 0u};
+    }
+
+    f32x16 oacc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // ---- register staging of the next tile
+    u32x4 kreg[KPT], vreg[VPT];
+    unsigned koff[KPT], voff[VPT];
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        const int idx = tid + 256 * i;
+        koff[i] = (unsigned)((idx / (DK / 8)) * a.ldk + 8 * (idx % (DK / 8))) * 2u;
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int idx = tid + 256 * i;                   // 4 pieces (32 keys) per Vt row
+        voff[i] = (unsigned)(((size_t)(dv0 + idx / 4) * a.ldvt + 8 * (idx % 4)) * 2u);
+    }
+    auto tile_gload = [&](int tile) __attribute__((always_inline)) {
+        const int base = kv_begin + tile * kKvTile;
+        const int last = kv_end - 1 - base;
+        const char *kb = reinterpret_cast<const char *>(a.K + (size_t)base * a.ldk);
+        const char *vb = reinterpret_cast<const char *>(a.Vt + base);   // Vt[*][base + ...]
+        if (last >= kKvTile - 1) {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) kreg[i] = *reinterpret_cast<const u32x4 *>(kb + koff[i]);
+        } else {                                          // ragged tile: clamp the K rows
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                const int idx = tid + 256 * i;
+                const int row = min(idx / (DK / 8), last);
+                kreg[i] = *reinterpret_cast<const u32x4 *>(
+                    kb + (unsigned)(row * a.ldk + 8 * (idx % (DK / 8))) * 2u);
+            }
+        }
+        // Vt rows are zero-padded to a multiple of 32 keys by the convert kernel: no clamp needed
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) vreg[i] = *reinterpret_cast<const u32x4 *>(vb + voff[i]);
+    };
+    auto tile_lstore = [&](int buf) __attribute__((always_inline)) {
+        unsigned short *kd = Ks + buf * KTILE;
+        unsigned short *vd = Vs + buf * VTILE;
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int idx = tid + 256 * i;
+            *reinterpret_cast<u32x4 *>(kd + (idx / (DK / 8)) * KLD + 8 * (idx % (DK / 8))) = kreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int idx = tid + 256 * i;
+            unsigned short *dst = vd + (idx / 4) * VLD + 8 * (idx % 4);   // 8-byte aligned
+            *reinterpret_cast<u32x2 *>(dst) = u32x2{vreg[i].x, vreg[i].y};
+            *reinterpret_cast<u32x2 *>(dst + 4) = u32x2{vreg[i].z, vreg[i].w};
+        }
+    };
+
+    if (ntiles > 0) {
+        tile_gload(0);
+        tile_lstore(0);
+    }
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        tile_gload(min(t + 1, ntiles - 1));
+
+        // ---- S^T = K_tile . Q^T
+        const unsigned short *kt = Ks + cur * KTILE + li * KLD + 8 * hi;
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const u32x4 kf = *reinterpret_cast<const u32x4 *>(kt + 16 * ks);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
+                                                        __builtin_bit_cast(bf16x8, qf[ks]), s, 0, 0, 0);
+        }
+
+        const int valid = kv_end - (kv_begin + t * kKvTile);
+        if (valid < kKvTile) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (crow16(r, hi) >= valid) s[r] = -INFINITY;
+        }
+
+        // ---- online softmax (fp32), one query row per lane pair
+        float tmax = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float m_new = fmaxf(m_run, tmax);
+        if (__any(m_new > m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[tt][r] *= alpha;
+            l_run *= alpha;
+            m_run = m_new;
+        }
+        const float mc = m_run * c;
+        // l sums the ROUNDED p values: numerator and denominator see the same bf16 P
+        u32x4 pb[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            unsigned w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float p0 = __builtin_amdgcn_exp2f(fmaf(s[8 * h + 2 * j], c, -mc));
+                const float p1 = __builtin_amdgcn_exp2f(fmaf(s[8 * h + 2 * j + 1], c, -mc));
+                w[j] = pack_bf16(p0, p1);
+                l_run += __uint_as_float(w[j] << 16) + __uint_as_float(w[j] & 0xffff0000u);
+            }
+            pb[h] = u32x4{w[0], w[1], w[2], w[3]};
+        }
+
+        // ---- O^T += Vt_tile . P^T
+        const unsigned short *vt = Vs + cur * VTILE + li * VLD + 4 * hi;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                const unsigned short *vp = vt + (32 * tt) * VLD + 16 * h;
+                const u32x2 lo = *reinterpret_cast<const u32x2 *>(vp);        // keys 16h+4hi .. +3
+                const u32x2 up = *reinterpret_cast<const u32x2 *>(vp + 8);    // keys 16h+8+4hi .. +3
+                const u32x4 vf = u32x4{lo.x, lo.y, up.x, up.y};
+                oacc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
+                                                                   __builtin_bit_cast(bf16x8, pb[h]),
+                                                                   oacc[tt], 0, 0, 0);
+            }
+        }
+
+        tile_lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: this chunk's columns of the shard-local triple
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    float *out = a.contrib;
+    float *omax = a.lmax, *osum = a.lsum;
+    int ldo = a.ldo;
+    if (a.kv_splits > 1) {
+        ldo = a.ws_ld;
+        out = a.ws_contrib + (size_t)split * a.m * ldo;
+        omax = a.ws_lmax + (size_t)split * a.m;
+        osum = a.ws_lsum + (size_t)split * a.m;
+    }
+    if (qrow < a.m) {
+        float *orow = out + (size_t)qrow * ldo + dv0;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int col = 32 * tt + crow16(r, hi);
+                if (dv0 + col < a.dv) orow[col] = oacc[tt][r];
+            }
+        if (hi == 0 && chunk == 0) {
+            omax[qrow] = m_run * scale;
+            osum[qrow] = l_tot;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// converts: fp64 -> bf16 (RNE), row-major with zero-padded columns, and the transposed V image
+// ---------------------------------------------------------------------------
+__global__ void cvt_d2bf_kernel(const double *__restrict__ src, unsigned short *__restrict__ dst,
+                                long rows, int cols, int ld) {
+    const long total = rows * ld;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / ld;
+        const int cidx = (int)(idx - r * ld);
+        dst[idx] = cidx < cols ? (unsigned short)f32_to_bf16_rne(__double2float_rn(src[r * cols + cidx])) : 0;
+    }
+}
+
+// dst[cidx * ldt + r] = bf16(src[r * cols + cidx]) for r < rows, 0 for rows <= r < ldt; rows of
+// dst beyond `cols` (up to cols_pad) are zero.  32x32 tiles through LDS so both sides coalesce.
+__global__ void cvt_d2bf_t_kernel(const double *__restrict__ src, unsigned short *__restrict__ dst,
+                                  long rows, int cols, int cols_pad, long ldt) {
+    __shared__ unsigned short tile[32][33];
+    const long r0 = (long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 256 threads: ty in 0..7
+    for (int k = ty; k < 32; k += 8) {
+        const long r = r0 + k;
+        const int cc = c0 + tx;
+        tile[k][tx] = (r < rows && cc < cols)
+                          ? (unsigned short)f32_to_bf16_rne(__double2float_rn(src[r * cols + cc])) : 0;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int cc = c0 + k;
+        const long r = r0 + tx;
+        if (cc < cols_pad && r < ldt) dst[(size_t)cc * ldt + r] = tile[tx][k];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host-side launch logic
+// ---------------------------------------------------------------------------
+int bf16_pad_dk(int dk) { return dk <= 64 ? 64 : dk <= 128 ? 128 : dk <= 256 ? 256 : 512; }
+int bf16_chunk_dv(int dv) { return dv <= 64 ? 64 : dv <= 128 ? 128 : 256; }
+int bf16_pad_dv(int dv) { const int ch = bf16_chunk_dv(dv); return (dv + ch - 1) / ch * ch; }
+long bf16_pad_n(long n) { return (n + 31) / 32 * 32; }
+
+int pick_kv_splits_bf16(int m, int n_local, int dk, int dv) {
+    if (m <= 0 || n_local <= 0) return 1;
+    const int nqb = (m + kQRowsPerBlock - 1) / kQRowsPerBlock;
+    const int chunks = bf16_pad_dv(dv) / bf16_chunk_dv(dv);
+    const int ntiles = (n_local + kKvTile - 1) / kKvTile;
+    const int per_cu = (bf16_pad_dk(dk) + 2 * bf16_chunk_dv(dv) > 512) ? 1 : 2;
+    int want = (256 * per_cu + nqb * chunks - 1) / (nqb * chunks);
+    int cap = ntiles / 8;
+    if (cap < 1) cap = 1;
+    if (want > cap) want = cap;
+    if (want > 64) want = 64;
+    return want < 1 ? 1 : want;
+}
+
+template <int DK, int DVC>
+static hipError_t launch_bf16(const Bf16Args &a, hipStream_t s) {
+    const int nqb = (a.m + kQRowsPerBlock - 1) / kQRowsPerBlock;
+    const int chunks = bf16_pad_dv(a.dv) / DVC;
+    const int ntiles = (a.n_local + kKvTile - 1) / kKvTile;
+    const int tiles_per_split = (ntiles + a.kv_splits - 1) / a.kv_splits;
+    const int kv_per_split = tiles_per_split > 0 ? tiles_per_split * kKvTile : kKvTile;
+    const size_t lds = (size_t)2 * (kKvTile * (DK + 8) + DVC * 36) * sizeof(unsigned short);
+    static bool attr_done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_bf16_kernel<DK, DVC>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done[dev] = true;
+    }
+    const float scale = 1.0f / sqrtf((float)a.dk);   // attention-mpi.c:208
+    hipLaunchKernelGGL((fused_bf16_kernel<DK, DVC>), dim3(nqb * chunks * a.kv_splits), dim3(256), lds, s,
+                       a, kv_per_split, nqb, chunks, scale);
+    return hipGetLastError();
+}
+
+hipError_t launch_shard_partial_bf16(const Bf16Args &a, hipStream_t s) {
+    const int kp = bf16_pad_dk(a.dk), vc = bf16_chunk_dv(a.dv);
+    if (a.dk > 512 || a.ldq != kp || a.ldk != kp) return hipErrorInvalidValue;
+    hipError_t e = hipErrorInvalidValue;
+#define SDPA_BCASE(KP, VC) if (kp == KP && vc == VC) e = launch_bf16<KP, VC>(a, s);
+    SDPA_BCASE(64, 64)  SDPA_BCASE(64, 128)  SDPA_BCASE(64, 256)
+    SDPA_BCASE(128, 64) SDPA_BCASE(128, 128) SDPA_BCASE(128, 256)
+    SDPA_BCASE(256, 64) SDPA_BCASE(256, 128) SDPA_BCASE(256, 256)
+    SDPA_BCASE(512, 64) SDPA_BCASE(512, 128) SDPA_BCASE(512, 256)
+#undef SDPA_BCASE
+    if (e != hipSuccess) return e;
+    if (a.kv_splits > 1) {
+        PartialArgs p = {};
+        p.contrib = a.contrib; p.ldo = a.ldo; p.lmax = a.lmax; p.lsum = a.lsum;
+        p.m = a.m; p.dv = a.dv; p.kv_splits = a.kv_splits;
+        p.ws_contrib = a.ws_contrib; p.ws_ld = a.ws_ld; p.ws_lmax = a.ws_lmax; p.ws_lsum = a.ws_lsum;
+        e = launch_split_merge(p, s);
+    }
+    return e;
+}
+
+hipError_t launch_cvt_d2bf(const double *src, unsigned short *dst, long rows, int cols, int ld,
+                           hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    long g = (rows * ld + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(cvt_d2bf_kernel, dim3((unsigned)g), dim3(256), 0, s, src, dst, rows, cols, ld);
+    return hipGetLastError();
+}
+
+hipError_t launch_cvt_d2bf_t(const double *src, unsigned short *dst, long rows, int cols,
+                             int cols_pad, long ldt, hipStream_t s) {
+    if (ldt <= 0 || cols_pad <= 0) return hipSuccess;
+    const unsigned gx = (unsigned)((ldt + 31) / 32), gy = (unsigned)((cols_pad + 31) / 32);
+    hipLaunchKernelGGL(cvt_d2bf_t_kernel, dim3(gx, gy), dim3(256), 0, s, src, dst, rows, cols,
+                       cols_pad, ldt);
+    return hipGetLastError();
+}
+
+}  // namespace sdpa

@@ -816,6 +816,12 @@ size_t workspace_bytes(int m, int n_local, int dk, int dv) {
     return (size_t)s * (size_t)m * (ws_ld + 2) * sizeof(float);
 }
 
+hipError_t launch_split_merge(const PartialArgs &a, hipStream_t s) {
+    const long work = (long)a.m * (a.ws_ld / 4);
+    hipLaunchKernelGGL(split_merge_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 template <int DKP, int DVP>
 static hipError_t launch_fast(const PartialArgs &a, hipStream_t s) {
     const int nqb = (a.m + kQRowsPerBlock - 1) / kQRowsPerBlock;

@@ -26,6 +26,33 @@ struct PartialArgs {
     int tune;                      // experiment switches ($SDPA_TUNE), 0 = shipped default
 };
 
+// bf16 variant: Q,K row-major bf16 (ld = dk padded to 64/128/256/512, pad columns zero),
+// Vt = V transposed, bf16 [dv_pad x ldvt] (ldvt = n_local padded to 32, pads zero).
+struct Bf16Args {
+    const unsigned short *Q;  int ldq;
+    const unsigned short *K;  int ldk;
+    const unsigned short *Vt; long ldvt;
+    float *contrib;  int ldo;
+    float *lmax;
+    float *lsum;
+    int m, n_local, dk, dv;
+    int kv_splits;
+    float *ws_contrib;  int ws_ld;
+    float *ws_lmax;
+    float *ws_lsum;
+};
+
+int  bf16_pad_dk(int dk);
+int  bf16_chunk_dv(int dv);
+int  bf16_pad_dv(int dv);
+long bf16_pad_n(long n);
+int  pick_kv_splits_bf16(int m, int n_local, int dk, int dv);
+hipError_t launch_shard_partial_bf16(const Bf16Args &a, hipStream_t s);
+hipError_t launch_cvt_d2bf(const double *src, unsigned short *dst, long rows, int cols, int ld, hipStream_t s);
+hipError_t launch_cvt_d2bf_t(const double *src, unsigned short *dst, long rows, int cols, int cols_pad,
+                             long ldt, hipStream_t s);
+hipError_t launch_split_merge(const PartialArgs &a, hipStream_t s);
+
 int  pick_kv_splits(int m, int n_local, int dk, int dv);
 size_t workspace_bytes(int m, int n_local, int dk, int dv);
 

@@ -55,9 +55,12 @@ def shutdown():
     _lib.load().sdpa_shutdown()
 
 
-def attention(Q, K, V, flags=0):
-    """result = softmax(Q K^T / sqrt(dk)) V; numpy fp64 [m,dk],[n,dk],[n,dv] -> [m,dv]."""
+def attention(Q, K, V, flags=0, precision=None):
+    """result = softmax(Q K^T / sqrt(dk)) V; numpy fp64 [m,dk],[n,dk],[n,dv] -> [m,dv].
+    precision="bf16" selects the bf16-input MFMA path (flag SDPA_F_BF16)."""
     lib = _lib.load()
+    if precision == "bf16":
+        flags |= _lib.SDPA_F_BF16
     Q = np.ascontiguousarray(Q, dtype=np.float64)
     K = np.ascontiguousarray(K, dtype=np.float64)
     V = np.ascontiguousarray(V, dtype=np.float64)
@@ -148,6 +151,53 @@ class HipBackend:
                 self._ws.data_ptr() if need else None, need, self._stream()), "sdpa_dev_shard_partial_f32")
         return contrib, lmax, lsum
 
+    # ---- bf16-input MFMA variant (BASELINE config 5) -------------------------------------
+    def cvt_d2bf(self, x64, ld=None):
+        """fp64 [rows, cols] -> bf16 [rows, ld] (RNE, pad columns zero); ld defaults to the padded dk."""
+        rows, cols = x64.shape
+        ld = self.lib.sdpa_dev_bf16_ld(cols) if ld is None else ld
+        check(min(ld, 0), "sdpa_dev_bf16_ld")
+        out = self.empty((rows, ld), torch.bfloat16)
+        if rows:
+            assert x64.is_contiguous() and x64.dtype == torch.float64
+            with torch.cuda.device(self.device):
+                check(self.lib.sdpa_dev_cvt_d2bf(x64.data_ptr(), out.data_ptr(), rows, cols, ld, self._stream()),
+                      "sdpa_dev_cvt_d2bf")
+        return out
+
+    def cvt_d2bf_t(self, v64):
+        """fp64 V[n, dv] -> the transposed bf16 image Vt[dv_pad, n_pad] the bf16 kernel reads."""
+        n, dv = v64.shape
+        dvp, ldn = self.lib.sdpa_dev_bf16_dvp(dv), self.lib.sdpa_dev_bf16_ldn(n)
+        check(min(dvp, 0), "sdpa_dev_bf16_dvp")
+        out = self.empty((dvp, max(ldn, 32)), torch.bfloat16)
+        assert v64.is_contiguous() and v64.dtype == torch.float64
+        with torch.cuda.device(self.device):
+            check(self.lib.sdpa_dev_cvt_d2bf_t(v64.data_ptr() if n else None, out.data_ptr(), n, dv, dvp,
+                                               out.shape[1], self._stream()), "sdpa_dev_cvt_d2bf_t")
+        return out
+
+    def shard_partial_bf16(self, Qb, Kb, Vt, n_local, dk, dv):
+        """online_softmax_attention (attention-mpi.c:168-189) on the bf16 MFMA kernel."""
+        m = Qb.shape[0]
+        if n_local == 0:    # empty shard: (0, -inf, 0) as attention-mpi.c:172-173
+            zk = self.empty((0, 4), torch.float32)
+            zv = self.empty((0, round4(dv)), torch.float32)
+            return self.shard_partial(self.empty((m, 4), torch.float32).zero_(), zk, zv, 4, dv)
+        ldo = round4(dv)
+        contrib = self.empty((m, ldo), torch.float32)
+        lmax = self.empty((m,), torch.float32)
+        lsum = self.empty((m,), torch.float32)
+        need = self.lib.sdpa_dev_workspace_bytes_bf16(m, n_local, dk, dv)
+        if need and (self._ws is None or self._ws.numel() < need):
+            self._ws = self.empty((need,), torch.uint8)
+        with torch.cuda.device(self.device):
+            check(self.lib.sdpa_dev_shard_partial_bf16(
+                Qb.data_ptr(), Qb.shape[1], Kb.data_ptr(), Kb.shape[1], Vt.data_ptr(), Vt.shape[1],
+                contrib.data_ptr(), ldo, lmax.data_ptr(), lsum.data_ptr(), m, n_local, dk, dv,
+                self._ws.data_ptr() if need else None, need, self._stream()), "sdpa_dev_shard_partial_bf16")
+        return contrib, lmax, lsum
+
     def merge_rescale(self, contrib, lsum, lmax, gmax, dv):
         """attention-mpi.c:346-351 (in place)."""
         with torch.cuda.device(self.device):
@@ -177,7 +227,10 @@ class ShardedAttention:
     merge choreography of attention-mpi.c:307-399.  `dist` is torch.distributed (or None for a
     single rank)."""
 
-    def __init__(self, backend, rank=0, world=1, dist=None, group=None, root=0, force_collectives=False):
+    def __init__(self, backend, rank=0, world=1, dist=None, group=None, root=0, force_collectives=False,
+                 precision="f32"):
+        assert precision in ("f32", "bf16")
+        self.precision = precision
         self.be = backend
         self.rank, self.world, self.root = rank, world, root
         self.dist = dist if (world > 1 or force_collectives) else None
@@ -194,9 +247,11 @@ class ShardedAttention:
         self.n, self.dk, self.dv = n, dk, dv
         cnt = owner_count(n, self.world, self.rank)
         if self.world == 1:
-            self.Kf = be.cvt_d2f(be.to_device(K64, torch.float64).contiguous())
-            self.Vf = be.cvt_d2f(be.to_device(V64, torch.float64).contiguous())
+            self.load_kv_shard_f64(be.to_device(K64, torch.float64).contiguous(),
+                                   be.to_device(V64, torch.float64).contiguous(), n, dk, dv)
             return
+        assert self.precision == "f32", "the root-scatter path distributes fp32 shards"
+
         cmax = owner_count(n, self.world, 0)             # rank 0 owns the largest shard
         shard_k = be.empty((cmax, round4(dk)), torch.float32)
         shard_v = be.empty((cmax, round4(dv)), torch.float32)
@@ -219,12 +274,30 @@ class ShardedAttention:
         self.Kf = shard_k[:cnt].contiguous()
         self.Vf = shard_v[:cnt].contiguous()
 
+    def load_kv_shard_f64(self, K64_local, V64_local, n, dk, dv):
+        """This rank's rows of K and V are on its device in fp64 (bench: resident inputs): convert
+        them to the operand image of the selected precision (attention-mpi.c:224-225)."""
+        self.n, self.dk, self.dv = n, dk, dv
+        self.n_local = K64_local.shape[0]
+        if self.precision == "bf16":
+            self.Kf = self.be.cvt_d2bf(K64_local)
+            self.Vf = self.be.cvt_d2bf_t(V64_local)
+        else:
+            self.Kf = self.be.cvt_d2f(K64_local)
+            self.Vf = self.be.cvt_d2f(V64_local)
+
+    def convert_q(self, Q64):
+        """Q batch fp64 -> operand image (attention-mpi.c:303,:325)."""
+        return self.be.cvt_d2bf(Q64) if self.precision == "bf16" else self.be.cvt_d2f(Q64)
+
     def load_kv_shard(self, Kf_local, Vf_local, n, dk, dv):
         """The shard is already on this rank's device as padded fp32 (bench: resident inputs)."""
         self.Kf, self.Vf, self.n, self.dk, self.dv = Kf_local, Vf_local, n, dk, dv
 
     # ---- one Q batch: attention-mpi.c:333-380 -----------------------------------------
     def batch_partial(self, Qf):
+        if self.precision == "bf16":
+            return self.be.shard_partial_bf16(Qf, self.Kf, self.Vf, self.n_local, self.dk, self.dv)
         return self.be.shard_partial(Qf, self.Kf, self.Vf, self.dk, self.dv)
 
     def batch_merge(self, contrib, lmax, lsum, async_reduce=False):

@@ -1,0 +1,139 @@
+"""GPU (-m gpu): the bf16-input MFMA path (BASELINE config 5) against the oracle.
+
+Tolerance: max|got - fp64 oracle| <= 1e-2 * max(1, max|V|).  A tighter
+check isolates the kernel from the input rounding: against the fp64 oracle evaluated on the
+SAME bf16-rounded Q, K, V the budget is 4e-3 * max(1, max|V|) (P is rounded to bf16 once)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import fp32_tol
+
+pytestmark = pytest.mark.gpu
+
+
+def bf16_tol(V):
+    return 1e-2 * max(1.0, float(np.abs(V).max()))
+
+
+def to_bf16_f64(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(torch.bfloat16).to(torch.float64).numpy()
+
+
+@pytest.fixture(scope="module")
+def be(pkg):
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    return pkg.HipBackend("cuda:0")
+
+
+def dev_attention_bf16(pkg, be, Q, K, V):
+    m, dk = Q.shape
+    n, dv = V.shape
+    sa = pkg.ShardedAttention(be, precision="bf16")
+    sa.load_kv_from_root(K, V, n, dk, dv)
+    qb = sa.convert_q(torch.from_numpy(np.ascontiguousarray(Q)).cuda())
+    contrib, lmax, lsum = sa.batch_partial(qb)
+    return be.finish_f64(contrib, lsum, dv).cpu().numpy()
+
+
+def test_bf16_converts(be, pkg):
+    x = torch.randn(70, 72, dtype=torch.float64, device="cuda") * 3
+    y = be.cvt_d2bf(x)
+    assert y.shape == (70, 128) and y.dtype == torch.bfloat16
+    assert torch.equal(y[:, :72], x.to(torch.float32).to(torch.bfloat16)) and torch.all(y[:, 72:] == 0)
+    v = torch.randn(100, 40, dtype=torch.float64, device="cuda")
+    vt = be.cvt_d2bf_t(v)
+    assert vt.shape == (64, 128)
+    assert torch.equal(vt[:40, :100], v.to(torch.float32).to(torch.bfloat16).t())
+    assert torch.all(vt[40:] == 0) and torch.all(vt[:, 100:] == 0)
+    big = torch.randn(4096, 512, dtype=torch.float64, device="cuda")
+    assert torch.equal(be.cvt_d2bf_t(big), big.to(torch.float32).to(torch.bfloat16).t().contiguous())
+
+
+SHAPES = [
+    # m,    n,   dk,  dv, dist
+    (64,   64,   64,  64, "D1"),
+    (1,     1,    1,   1, "D2"),
+    (33,   33,   33,  33, "D2"),
+    (200,   5,   16,  16, "D2"),      # n < tile
+    (130, 333,  128, 128, "D2"),
+    (100, 257,   72,  40, "D2"),      # dims padded to 128 / 64
+    (96,  1000,  64,  64, "D4"),      # late spike key
+    (257, 2048, 128, 128, "D3"),      # peaky
+    (64,  300,  256, 256, "D1"),
+    (48,  300,  512, 512, "D1"),      # BASELINE config 5 dims: two dv chunks of 256
+    (40,  200,  100, 200, "D2"),      # dv padded to 256, dk to 128
+    (32,   96,  512,  64, "D1"),
+    (129, 700,  300, 700, "D1"),      # dk -> 512, dv -> 3 chunks
+]
+
+
+@pytest.mark.parametrize("m,n,dk,dv,dist", SHAPES)
+def test_bf16_shapes(m, n, dk, dv, dist, pkg, be, orc, O):
+    Q, K, V = O.make_inputs(m, n, dk, dv, dist, seed=m + n + 1)
+    got = dev_attention_bf16(pkg, be, Q, K, V)
+    assert got.shape == (m, dv) and np.isfinite(got).all()
+    want = orc.attention_f64(Q, K, V)
+    assert np.abs(got - want).max() <= bf16_tol(V)
+    same_inputs = orc.attention_f64(to_bf16_f64(Q), to_bf16_f64(K), to_bf16_f64(V))
+    assert np.abs(got - same_inputs).max() <= 4e-3 * max(1.0, np.abs(V).max())
+
+
+def test_bf16_kv_splits_and_triple(pkg, be, O):
+    """long K/V with few query blocks: in-GPU splits; the triple's lmax is the fp32-exact row max of
+    the bf16-rounded scores"""
+    m, n, d = 256, 8192, 128
+    assert pkg.load().sdpa_dev_kv_splits_bf16(m, n, d, d) > 1
+    Q, K, V = O.make_inputs(m, n, d, d, "D2", seed=4)
+    got = dev_attention_bf16(pkg, be, Q, K, V)
+    assert np.abs(got - O.numpy_attention_f64(Q, K, V)).max() <= bf16_tol(V)
+    sa = pkg.ShardedAttention(be, precision="bf16")
+    sa.load_kv_from_root(K, V, n, d, d)
+    _, lmax, _ = sa.batch_partial(sa.convert_q(torch.from_numpy(Q).cuda()))
+    s = (to_bf16_f64(Q) @ to_bf16_f64(K).T) / np.sqrt(np.float32(d))
+    assert np.abs(lmax.cpu().numpy() - s.max(axis=1)).max() <= 1e-4 * max(1.0, np.abs(s).max())
+
+
+def test_bf16_host_level_flag_and_shard_merge(pkg, be, orc, O):
+    Q, K, V = O.make_inputs(300, 900, 128, 128, "D2", seed=2)
+    want = orc.attention_f64(Q, K, V)
+    got = pkg.attention(Q, K, V, precision="bf16")
+    assert np.isfinite(got).all() and np.abs(got - want).max() <= bf16_tol(V)
+    # it really took the bf16 path: the fp32 path is ~100x closer
+    f32 = pkg.attention(Q, K, V)
+    assert np.abs(f32 - want).max() <= fp32_tol(V) < np.abs(got - want).max()
+    # 3 shards (one after the other on this GPU) merged with the merge kernels == unsharded
+    qb = be.cvt_d2bf(torch.from_numpy(Q).cuda())
+    triples = []
+    for r in range(3):
+        c, d0 = pkg.owner_count(900, 3, r), pkg.owner_disp(900, 3, r)
+        sa = pkg.ShardedAttention(be, precision="bf16")
+        sa.load_kv_from_root(K[d0:d0 + c], V[d0:d0 + c], c, 128, 128)
+        triples.append(sa.batch_partial(qb))
+    gmax = torch.stack([t[1] for t in triples]).max(dim=0).values
+    for contrib, lmax, lsum in triples:
+        be.merge_rescale(contrib, lsum, lmax, gmax, 128)
+    gsum = torch.stack([t[2] for t in triples]).sum(dim=0)
+    for contrib, _, _ in triples:
+        be.merge_normalise(contrib, gsum, 128)
+    merged = be.cvt_f2d(torch.stack([t[0] for t in triples]).sum(dim=0), 128).cpu().numpy()
+    assert np.abs(merged - want).max() <= bf16_tol(V)
+
+
+def test_bf16_empty_shard(pkg, be):
+    qb = torch.zeros(40, 64, dtype=torch.bfloat16, device="cuda")
+    contrib, lmax, lsum = be.shard_partial_bf16(qb, None, None, 0, 64, 64)
+    assert torch.all(contrib[:, :64] == 0) and torch.all(lsum == 0) and torch.all(torch.isneginf(lmax))
+
+
+def test_bf16_config5_rows(pkg, O):
+    """BASELINE config 5 at a quarter of m (m=8192, n=65536, dk=dv=512) through the host-level
+    boundary: a row subset against the fp64 oracle"""
+    m, n, d = 8192, 65536, 512
+    rng = np.random.default_rng(5)
+    Q, K, V = (rng.uniform(-1, 1, s) for s in ((m, d), (n, d), (n, d)))
+    got = pkg.attention(Q, K, V, precision="bf16")
+    assert np.isfinite(got).all()
+    rows = rng.choice(m, 48, replace=False)
+    assert np.abs(got[rows] - O.numpy_attention_f64(Q, K, V, rows)).max() <= bf16_tol(V)
