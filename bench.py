@@ -40,8 +40,11 @@ WORKLOADS = {
     "config2": dict(m=8192, n=8192, d=128),        # configs[1]
     "config3": dict(m=32768, n=262144, d=128),     # configs[2], K/V-sharded strong scaling
     "config1": dict(m=512, n=512, d=64),           # configs[0]
+    "config4": dict(m=131072, n=65536, d=128),     # configs[3], many Q batches
+    "config5": dict(m=32768, n=65536, d=512),      # configs[4], bf16 MFMA path (use --precision bf16)
 }
 F32_MFMA_PEAK_TFLOPS = 157.3                       # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+BF16_MFMA_PEAK_TFLOPS = 2500.0                     # dense bf16 MFMA peak (no 2:1 sparsity)
 
 
 def cpu_baseline(m, n, d, budget_rows=8192):
@@ -105,6 +108,8 @@ def main():
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
     ap.add_argument("--q-batch", type=int, default=0, help="Q rows per batch (0 = m at N=1, m/4 at N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
+                    help="operand precision of the fused kernel (the headline metric is f32)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -142,17 +147,17 @@ def main():
     K64 = torch.rand((cnt, d), generator=g, device=dev, dtype=torch.float64) * 2 - 1
     V64 = torch.rand((cnt, d), generator=g, device=dev, dtype=torch.float64) * 2 - 1
 
-    B = args.q_batch if args.q_batch > 0 else (m if world == 1 else max(1, m // 4))
+    B = args.q_batch if args.q_batch > 0 else (m if world == 1 else max(1, m // 2))
     B = min(B, m)
     nb = (m + B - 1) // B
-    sa = pkg.ShardedAttention(be, rank, world, dist, force_collectives=force_dist)
+    sa = pkg.ShardedAttention(be, rank, world, dist, force_collectives=force_dist, precision=args.precision)
     kernel_events = []
 
     def step(record):
-        sa.load_kv_shard(be.cvt_d2f(K64), be.cvt_d2f(V64), n, d, d)      # attention-mpi.c:224-225
+        sa.load_kv_shard_f64(K64, V64, n, d, d)                          # attention-mpi.c:224-225
         pending, outs = None, []
         for b in range(nb):
-            qf = be.cvt_d2f(Q64[b * B:min(m, (b + 1) * B)])             # :303,:325
+            qf = sa.convert_q(Q64[b * B:min(m, (b + 1) * B)])           # :303,:325
             if record:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -202,10 +207,17 @@ def main():
         if not os.environ.get("SDPA_TUNE"):   # ablation switches give wrong results by design
             assert np.isfinite(chk).all() and np.abs(chk).max() <= 1.0 + 1e-6
         ms_per_step = elapsed / args.steps * 1e3
+        peak = BF16_MFMA_PEAK_TFLOPS if args.precision == "bf16" else F32_MFMA_PEAK_TFLOPS
+        if args.precision == "bf16":
+            kernel_name = "sdpa::fused_bf16_kernel"
+        elif d in (64, 128):
+            kernel_name = "sdpa::fused_pipelined_kernel<%d,%d,0>" % (d, d)
+        else:
+            kernel_name = "sdpa::fused_partial_kernel / generic_partial_kernel"
         total_flop = 4.0 * m * n * d
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath) and world == 1 and args.workload == "headline":
+        if os.path.exists(tpath) and world == 1 and args.workload == "headline" and args.precision == "f32":
             try:
                 traffic = json.load(open(tpath))["per_launch_bytes"]
             except Exception:  # noqa: BLE001
@@ -219,19 +231,20 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.precision,
             "data": "synthetic U(-1,1) fp64 Q/K/V resident in HBM (Q replicated, K/V row-sharded)",
-            "config": {"workload": "%s: m=%d n=%d dk=dv=%d, fp32 compute / fp64 in-out" % (args.workload, m, n, d),
+            "config": {"workload": "%s: m=%d n=%d dk=dv=%d, %s compute / fp64 in-out" % (args.workload, m, n, d, args.precision),
                        "q_batch": B, "q_batches": nb,
                        "kv_rows_per_gpu": cnt,
-                       "kv_splits_in_gpu": pkg.load().sdpa_dev_kv_splits(min(B, m), cnt, d, d),
+                       "kv_splits_in_gpu": (pkg.load().sdpa_dev_kv_splits_bf16 if args.precision == "bf16"
+                                            else pkg.load().sdpa_dev_kv_splits)(min(B, m), cnt, d, d),
                        "parallelism": "kv-shard x%d (all-reduce MAX, all-reduce SUM, reduce SUM over RCCL)" % world
                                       if world > 1 else "single GPU"},
             "tflops": total_flop / (elapsed / args.steps) / 1e12,
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak,
+                         "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic,
-                         "kernel": "sdpa::fused_pipelined_kernel<%d,%d,0>" % (d, d) if d in (64, 128) else "sdpa::fused_partial_kernel",
+                         "kernel": kernel_name,
                          "kernel_ms_avg": avg_ms, "launches": len(k_ms),
                          "flop_per_launch": flop_per_launch},
         }

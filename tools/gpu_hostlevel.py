@@ -4,7 +4,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("mpi-parallelized-scaled-dot-product-attention-with-avx-512-optimization_amd")
-shapes = {"headline": (32768, 65536, 128), "config2": (8192, 8192, 128), "config1": (512, 512, 64)}
+shapes = {"headline": (32768, 65536, 128), "config2": (8192, 8192, 128), "config1": (512, 512, 64),
+          "config4": (131072, 65536, 128)}
 pkg.init(0)
 for name in sys.argv[1:] or ["headline", "config2", "config1"]:
     m, n, d = shapes[name]
