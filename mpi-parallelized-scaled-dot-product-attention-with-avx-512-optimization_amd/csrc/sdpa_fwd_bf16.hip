@@ -24,6 +24,7 @@
 #include "sdpa_internal.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace sdpa {
 
@@ -58,7 +59,9 @@ __device__ __forceinline__ int xcd_remap_b(int bid, int total) {
     return first + slot;
 }
 
-template <int DK, int DVC>
+// ABL: timing-only ablations (wrong results): 1 = no staging/barrier, 2 = no LDS fragment reads,
+// 4 = no softmax VALU
+template <int DK, int DVC, int ABL = 0>
 __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_kernel(
     Bf16Args a, int kv_per_split, int n_qblocks, int n_chunks, float scale) {
     constexpr int NKS = DK / 16;              // QK^T k-steps (one 16-byte fragment each)
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
 
     for (int t = 0; t < ntiles; ++t) {
         const int cur = t & 1;
-        tile_gload(min(t + 1, ntiles - 1));
+        if constexpr (!(ABL & 1)) tile_gload(min(t + 1, ntiles - 1));
 
         // ---- S^T = K_tile . Q^T
         const unsigned short *kt = Ks + cur * KTILE + li * KLD + 8 * hi;
@@ -178,7 +181,9 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            const u32x4 kf = *reinterpret_cast<const u32x4 *>(kt + 16 * ks);
+            u32x4 kf;
+            if constexpr (ABL & 2) kf = qf[(ks + 1) % NKS];
+            else kf = *reinterpret_cast<const u32x4 *>(kt + 16 * ks);
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
                                                         __builtin_bit_cast(bf16x8, qf[ks]), s, 0, 0, 0);
         }
@@ -191,6 +196,13 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
         }
 
         // ---- online softmax (fp32), one query row per lane pair
+        u32x4 pb[2];
+        if constexpr (ABL & 4) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                pb[h] = u32x4{__float_as_uint(s[8 * h]), __float_as_uint(s[8 * h + 1]),
+                              __float_as_uint(s[8 * h + 2]), __float_as_uint(s[8 * h + 3])};
+        } else {
         float tmax = s[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
@@ -208,7 +220,6 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
         const float mc = m_run * c;
         // (l sums the unrounded p: the bf16 rounding of P is unbiased, the row sum of 2^-9-relative
         //  errors is far inside this path's 1e-2 tolerance)
-        u32x4 pb[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             unsigned w[4];
@@ -221,6 +232,7 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
             }
             pb[h] = u32x4{w[0], w[1], w[2], w[3]};
         }
+        }
 
         // ---- O^T += Vt_tile . P^T
         const unsigned short *vt = Vs + cur * VTILE + li * VLD + 4 * hi;
@@ -229,17 +241,24 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
                 const unsigned short *vp = vt + (32 * tt) * VLD + 16 * h;
-                const u32x2 lo = *reinterpret_cast<const u32x2 *>(vp);        // keys 16h+4hi .. +3
-                const u32x2 up = *reinterpret_cast<const u32x2 *>(vp + 8);    // keys 16h+8+4hi .. +3
-                const u32x4 vf = u32x4{lo.x, lo.y, up.x, up.y};
+                u32x4 vf;
+                if constexpr (ABL & 2) {
+                    vf = qf[(tt + h) % NKS];
+                } else {
+                    const u32x2 lo = *reinterpret_cast<const u32x2 *>(vp);        // keys 16h+4hi .. +3
+                    const u32x2 up = *reinterpret_cast<const u32x2 *>(vp + 8);    // keys 16h+8+4hi .. +3
+                    vf = u32x4{lo.x, lo.y, up.x, up.y};
+                }
                 oacc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
                                                                    __builtin_bit_cast(bf16x8, pb[h]),
                                                                    oacc[tt], 0, 0, 0);
             }
         }
 
-        tile_lstore(cur ^ 1);
-        __syncthreads();
+        if constexpr (!(ABL & 1)) {
+            tile_lstore(cur ^ 1);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: this chunk's columns of the shard-local triple
@@ -327,7 +346,7 @@ int pick_kv_splits_bf16(int m, int n_local, int dk, int dv) {
     return want < 1 ? 1 : want;
 }
 
-template <int DK, int DVC>
+template <int DK, int DVC, int ABL = 0>
 static hipError_t launch_bf16(const Bf16Args &a, hipStream_t s) {
     const int nqb = (a.m + kQRowsPerBlock - 1) / kQRowsPerBlock;
     const int chunks = bf16_pad_dv(a.dv) / DVC;
@@ -339,13 +358,13 @@ static hipError_t launch_bf16(const Bf16Args &a, hipStream_t s) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_bf16_kernel<DK, DVC>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_bf16_kernel<DK, DVC, ABL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done[dev] = true;
     }
     const float scale = 1.0f / sqrtf((float)a.dk);   // attention-mpi.c:208
-    hipLaunchKernelGGL((fused_bf16_kernel<DK, DVC>), dim3(nqb * chunks * a.kv_splits), dim3(256), lds, s,
+    hipLaunchKernelGGL((fused_bf16_kernel<DK, DVC, ABL>), dim3(nqb * chunks * a.kv_splits), dim3(256), lds, s,
                        a, kv_per_split, nqb, chunks, scale);
     return hipGetLastError();
 }
@@ -354,6 +373,16 @@ hipError_t launch_shard_partial_bf16(const Bf16Args &a, hipStream_t s) {
     const int kp = bf16_pad_dk(a.dk), vc = bf16_chunk_dv(a.dv);
     if (a.dk > 512 || a.ldq != kp || a.ldk != kp) return hipErrorInvalidValue;
     hipError_t e = hipErrorInvalidValue;
+    static const int tune = getenv("SDPA_TUNE") ? atoi(getenv("SDPA_TUNE")) : 0;
+    if (kp == 512 && vc == 256 && ((tune >> 4) & 7)) {   // timing-only ablations
+        switch ((tune >> 4) & 7) {
+            case 1: return launch_bf16<512, 256, 1>(a, s);
+            case 2: return launch_bf16<512, 256, 2>(a, s);
+            case 4: return launch_bf16<512, 256, 4>(a, s);
+            case 6: return launch_bf16<512, 256, 6>(a, s);
+            default: return launch_bf16<512, 256, 7>(a, s);
+        }
+    }
 #define SDPA_BCASE(KP, VC) if (kp == KP && vc == VC) e = launch_bf16<KP, VC>(a, s);
     SDPA_BCASE(64, 64)  SDPA_BCASE(64, 128)  SDPA_BCASE(64, 256)
     SDPA_BCASE(128, 64) SDPA_BCASE(128, 128) SDPA_BCASE(128, 256)
