@@ -457,32 +457,40 @@ __global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
+    // Full tiles (all but possibly the last of a split) take the branch-free path: no per-lane
+    // address arithmetic at all in the steady state (VALU cycles are MFMA cycles lost here).
     auto dma_k = [&](int tile, int buf) __attribute__((always_inline)) {
         const int base = kv_begin + tile * kKvTile;
         const int last = kv_end - 1 - base;
         const char *kb = reinterpret_cast<const char *>(a.K + (size_t)base * DK);
+        if (last >= kKvTile - 1) {
 #pragma unroll
-        for (int j = 0; j < KPW; ++j) {
-            unsigned off = koff[j];
-            if (last < kKvTile - 1) {         // ragged tile: clamp the source row, keep the chunk
-                const unsigned row = min((int)(off / (DK * 4)), last);
-                off = row * (DK * 4) + (off % (DK * 4));
+            for (int j = 0; j < KPW; ++j)
+                dma_piece(kb, koff[j], lds_base + (unsigned)(buf * KTILE + (wave * KPW + j) * 256) * 4u);
+        } else {                               // ragged tile: clamp the source row, keep the chunk
+#pragma unroll
+            for (int j = 0; j < KPW; ++j) {
+                const unsigned row = min((int)(koff[j] / (DK * 4)), last);
+                dma_piece(kb, row * (DK * 4) + (koff[j] % (DK * 4)),
+                          lds_base + (unsigned)(buf * KTILE + (wave * KPW + j) * 256) * 4u);
             }
-            dma_piece(kb, off, lds_base + (unsigned)(buf * KTILE + (wave * KPW + j) * 256) * 4u);
         }
     };
     auto dma_v = [&](int tile, int buf) __attribute__((always_inline)) {
         const int base = kv_begin + tile * kKvTile;
         const int last = kv_end - 1 - base;
         const char *vb = reinterpret_cast<const char *>(a.V + (size_t)base * DV);
+        if (last >= kKvTile - 1) {
 #pragma unroll
-        for (int j = 0; j < VPW; ++j) {
-            unsigned off = voff[j];
-            if (last < kKvTile - 1) {
-                const unsigned row = min((int)(off / (DV * 4)), last);
-                off = row * (DV * 4) + (off % (DV * 4));
+            for (int j = 0; j < VPW; ++j)
+                dma_piece(vb, voff[j], lds_base + (unsigned)((2 * KTILE + buf * VTILE) + (wave * VPW + j) * 256) * 4u);
+        } else {
+#pragma unroll
+            for (int j = 0; j < VPW; ++j) {
+                const unsigned row = min((int)(voff[j] / (DV * 4)), last);
+                dma_piece(vb, row * (DV * 4) + (voff[j] % (DV * 4)),
+                          lds_base + (unsigned)((2 * KTILE + buf * VTILE) + (wave * VPW + j) * 256) * 4u);
             }
-            dma_piece(vb, off, lds_base + (unsigned)((2 * KTILE + buf * VTILE) + (wave * VPW + j) * 256) * 4u);
         }
     };
 
