@@ -24,7 +24,10 @@
 #include "sdpa_internal.h"
 
 #include <math.h>
+#include <stdint.h>
 #include <stdlib.h>
+
+#include <type_traits>
 
 namespace sdpa {
 
@@ -289,6 +292,351 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
 }
 
 // ---------------------------------------------------------------------------
+// Software-pipelined variant (the fp32 kernel's recipe, sdpa_fwd_f32.hip, for bf16 operands):
+//   * K tiles go global -> LDS by LDS-DMA from inline asm (no staging registers, no ds_write),
+//     16-byte chunks XOR-swizzled (chunk ^ (row & 15)) on the source side and undone by the
+//     fragment reads; K is staged two tiles ahead in two buffers.  Vt tiles (64-byte rows) keep
+//     the register path into padded 72-byte rows: a lane-linear DMA image of them would make every
+//     ds_read_b64 of the P.V operand 2-way conflicted.
+//   * two score tiles are live: S^T(t+1) = K(t+1).Q^T runs on the matrix pipe while S(t) becomes
+//     P(t) (fma, exp2, bf16 pack) on the VALU -- which, unlike for f32-input MFMA, really does
+//     run beside the bf16 MFMA -- and the row max of S(t+1) is reduced under the P.V MFMAs.
+//   * the reference exponent m_ref only moves when a tile's max rises by more than 2^24; the
+//     true row max is folded back at the epilogue (same scheme as the fp32 pipelined kernel).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float bpin_exp2(float x) {
+    float y;
+    asm volatile("v_exp_f32 %0, %1\n\ts_nop 0" : "=v"(y) : "v"(x));
+    return y;
+}
+__device__ __forceinline__ unsigned bpin_pack(float lo, float hi) {
+    unsigned r;
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float bpin_max3(float a, float b, float c) {
+    float y;
+    asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(y) : "v"(a), "v"(b), "v"(c));
+    return y;
+}
+
+template <int DK, int DVC, int ABL = 0>
+__global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_pipe_kernel(
+    Bf16Args a, int kv_per_split, int n_qblocks, int n_chunks, float scale) {
+    constexpr int NKS = DK / 16;               // QK^T k-steps = MFMAs per score tile
+    constexpr int NT = DVC / 32;
+    constexpr int KCH = DK / 8;                // 16-byte chunks per K row
+    constexpr int KTILE = kKvTile * DK;        // bf16 elements, unpadded (swizzled)
+    constexpr int VLD = 36;
+    constexpr int VTILE = DVC * VLD;
+    constexpr int KPW = (kKvTile * KCH / 64) / 4;   // 1-KiB DMA pieces per wave per K tile
+    constexpr int RPP = 64 / KCH > 0 ? 64 / KCH : 1; // K rows per DMA piece (1 at DK = 512)
+    constexpr int VPT = DVC / 64;
+    constexpr int SWZ = KCH >= 16 ? 15 : KCH - 1;
+    static_assert(KCH >= 8 && KPW >= 1, "DK must be 64..512");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+    unsigned short *const Ks = smem16;                    // [2][KTILE]
+    unsigned short *const Vs = smem16 + 2 * KTILE;        // [2][VTILE]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31;
+    const int hi = lane >> 5;
+
+    int work = xcd_remap_b(blockIdx.x, gridDim.x);
+    const int qblock = work % n_qblocks;
+    work /= n_qblocks;
+    const int chunk = work % n_chunks;
+    const int split = work / n_chunks;
+    const int qrow = qblock * kQRowsPerBlock + wave * 32 + li;
+    const int dv0 = chunk * DVC;
+
+    const int kv_begin = split * kv_per_split;
+    const int kv_end = min(a.n_local, kv_begin + kv_per_split);
+    const int T = kv_end > kv_begin ? (kv_end - kv_begin + kKvTile - 1) / kKvTile : 0;
+    const float c = scale * 1.44269504088896340736f;
+
+    u32x4 qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        if (qrow < a.m)
+            qf[ks] = *reinterpret_cast<const u32x4 *>(a.Q + (size_t)qrow * DK + 16 * ks + 8 * hi);
+        else
+            qf[ks] = u32x4{0u, 0u, 0u, 0u};
+    }
+
+    f32x16 oacc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+    constexpr float kDeferLog2 = 24.0f;
+    float m_ref = 0.f, max_rel = 0.f, l_run = 0.f;       // exp2 domain, see the fp32 kernel
+
+    // ---- K staging by LDS-DMA
+    unsigned koff[KPW];
+#pragma unroll
+    for (int j = 0; j < KPW; ++j) {
+        const int row = (wave * KPW + j) * RPP + lane / KCH;
+        const int cpos = lane % KCH;
+        koff[j] = (unsigned)(row * DK * 2 + ((cpos ^ (row & SWZ)) << 4));
+    }
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane(
+        (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)smem16);
+    auto dma_piece = [&](const char *gbase, unsigned lane_off, unsigned lds_byte) __attribute__((always_inline)) {
+        if constexpr (ABL & 1) return;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %2\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %3\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(lane_off), "s"(lds_byte), "s"(gbase)
+                     : "memory");
+    };
+    auto dma_k = [&](int tile, int buf) __attribute__((always_inline)) {
+        const int base = kv_begin + tile * kKvTile;
+        const int last = kv_end - 1 - base;
+        const char *kb = reinterpret_cast<const char *>(a.K + (size_t)base * DK);
+        if (last >= kKvTile - 1) {
+#pragma unroll
+            for (int j = 0; j < KPW; ++j)
+                dma_piece(kb, koff[j], lds_base + (unsigned)(buf * KTILE * 2 + (wave * KPW + j) * 1024));
+        } else {
+#pragma unroll
+            for (int j = 0; j < KPW; ++j) {
+                const unsigned row = min((int)(koff[j] / (DK * 2)), last);
+                dma_piece(kb, row * (DK * 2) + (koff[j] % (DK * 2)),
+                          lds_base + (unsigned)(buf * KTILE * 2 + (wave * KPW + j) * 1024));
+            }
+        }
+    };
+    // ---- Vt staging through registers
+    u32x4 vreg[VPT];
+    unsigned voff[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int idx = tid + 256 * i;
+        voff[i] = (unsigned)(((size_t)(dv0 + idx / 4) * a.ldvt + 8 * (idx % 4)) * 2u);
+    }
+    auto v_gload = [&](int tile) __attribute__((always_inline)) {
+        if constexpr (ABL & 1) return;
+        const char *vb = reinterpret_cast<const char *>(a.Vt + kv_begin + tile * kKvTile);
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) vreg[i] = *reinterpret_cast<const u32x4 *>(vb + voff[i]);
+    };
+    auto v_lstore = [&](int buf) __attribute__((always_inline)) {
+        if constexpr (ABL & 1) return;
+        unsigned short *vd = Vs + buf * VTILE;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int idx = tid + 256 * i;
+            unsigned short *dst = vd + (idx / 4) * VLD + 8 * (idx % 4);
+            *reinterpret_cast<u32x2 *>(dst) = u32x2{vreg[i].x, vreg[i].y};
+            *reinterpret_cast<u32x2 *>(dst + 4) = u32x2{vreg[i].z, vreg[i].w};
+        }
+    };
+    auto stage_fence = [&]() __attribute__((always_inline)) {
+        if constexpr (ABL & 8) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+    // K fragment byte addresses inside a K buffer (chunk 2ks+hi of row li, un-swizzled)
+    constexpr int NKA = NKS < 8 ? NKS : 8;
+    unsigned kaddr[NKA];
+#pragma unroll
+    for (int u = 0; u < NKA; ++u) kaddr[u] = (unsigned)(li * DK * 2 + (((2 * u + hi) ^ (li & SWZ)) << 4));
+    auto kfrag = [&](int buf, int ks) __attribute__((always_inline)) -> u32x4 {
+        if constexpr (ABL & 2) return qf[(ks + 1) % NKS];
+        return *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(Ks + buf * KTILE) +
+                                                kaddr[ks % NKA] + (ks / NKA) * 256);
+    };
+    auto mask_ragged = [&](f32x16 &sx, int tile) __attribute__((always_inline)) {
+        const int valid = kv_end - (kv_begin + tile * kKvTile);
+        if (valid < kKvTile) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (crow16(r, hi) >= valid) sx[r] = -INFINITY;
+        }
+    };
+    // scores in sx are raw dots; rel(s) = s*c - m_ref.  Folds a tile's max into the state.
+    auto absorb_rel = [&](float tmax_raw) __attribute__((always_inline)) {
+        float tmax = fmaf(tmax_raw, c, -m_ref);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        if (__any(tmax > kDeferLog2)) {
+            const float jump = fmaxf(tmax, 0.f);
+            const float alpha = __builtin_amdgcn_exp2f(-jump);
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[tt][r] *= alpha;
+            l_run *= alpha;
+            m_ref += jump;
+            max_rel -= jump;
+            tmax -= jump;
+        }
+        max_rel = fmaxf(max_rel, tmax);
+    };
+
+    constexpr int PPK = NKS >= 16 ? 1 : 16 / NKS;        // P values finished per QK^T MFMA slot
+    constexpr int KPP = NKS >= 16 ? NKS / 16 : 1;        // QK^T MFMAs per P value
+
+    auto step = [&](auto has_next, f32x16 &su, f32x16 &sm, int t) __attribute__((always_inline)) {
+        constexpr bool HAS_NEXT = decltype(has_next)::value;
+        const int vbuf = t & 1, kbuf = (t + 1) & 1;
+        if (t + 2 < T) dma_k(t + 2, t & 1);
+        if (t + 1 < T) v_gload(t + 1);
+        u32x4 pb[2];
+        unsigned pw[8];
+
+        auto p_slice = [&](int r0, int cnt) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = r0; r < r0 + cnt; ++r) {
+                su[r] = bpin_exp2(fmaf(su[r], c, -m_ref));
+                l_run += su[r];
+                if (r & 1) pw[r >> 1] = bpin_pack(su[r - 1], su[r]);
+            }
+        };
+
+        if constexpr (HAS_NEXT) {
+            // [A] S^T(t+1) on the matrix pipe  ||  P(t) on the VALU
+            // K fragments are read KD steps ahead of their MFMA (a bf16 MFMA retires in 32 cycles, an
+            // LDS read takes ~4x that; deeper rings measured slower: they spill inside the loop)
+            constexpr int KD = NKS < 6 ? NKS : (DK + 2 * DVC > 512 ? 3 : 2);
+            u32x4 kq[KD];
+#pragma unroll
+            for (int i = 0; i < KD; ++i) kq[i] = kfrag(kbuf, i);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sm[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const u32x4 kf = kq[ks % KD];
+                __builtin_amdgcn_sched_barrier(0);
+                sm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
+                                                             __builtin_bit_cast(bf16x8, qf[ks]), sm, 0, 0, 0);
+                if (ks + KD < NKS) kq[ks % KD] = kfrag(kbuf, ks + KD);
+                if (ks % KPP == 0) p_slice((ks / KPP) * PPK, PPK);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            p_slice(0, 16);
+        }
+        pb[0] = u32x4{pw[0], pw[1], pw[2], pw[3]};
+        pb[1] = u32x4{pw[4], pw[5], pw[6], pw[7]};
+
+        // [B] O^T += Vt(t).P(t)^T on the matrix pipe  ||  row max of S^T(t+1), Vt(t+1) -> LDS
+        if constexpr (HAS_NEXT) mask_ragged(sm, t + 1);
+        const unsigned short *vt = Vs + vbuf * VTILE + li * VLD + 4 * hi;
+        float tmax = -INFINITY;
+        constexpr int SLOTS = 2 * NT;                     // P.V MFMAs of this step
+        constexpr int VD = 2;                              // V fragment prefetch depth
+        auto vfrag = [&](int slot) __attribute__((always_inline)) -> u32x4 {
+            const int h = slot / NT, tt = slot % NT;
+            if constexpr (ABL & 2) return qf[(tt + h) % NKS];
+            const unsigned short *vp = vt + (32 * tt) * VLD + 16 * h;
+            const u32x2 lo = *reinterpret_cast<const u32x2 *>(vp);        // keys 16h+4hi .. +3
+            const u32x2 up = *reinterpret_cast<const u32x2 *>(vp + 8);    // keys 16h+8+4hi .. +3
+            return u32x4{lo.x, lo.y, up.x, up.y};
+        };
+        u32x4 vq[VD];
+#pragma unroll
+        for (int i = 0; i < VD; ++i) vq[i] = vfrag(i);
+#pragma unroll
+        for (int slot = 0; slot < SLOTS; ++slot) {
+            const int h = slot / NT, tt = slot % NT;
+            const u32x4 vf = vq[slot % VD];
+            __builtin_amdgcn_sched_barrier(0);
+            oacc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
+                                                               __builtin_bit_cast(bf16x8, pb[h]),
+                                                               oacc[tt], 0, 0, 0);
+            if (slot + VD < SLOTS) vq[slot % VD] = vfrag(slot + VD);
+            if constexpr (HAS_NEXT) {
+                // 16 maxes spread over the MFMA slots, starting one slot late
+                if (slot >= 1) {
+                    constexpr int per = (16 + SLOTS - 2) / (SLOTS - 1);
+                    const int r0 = (slot - 1) * per;
+#pragma unroll
+                    for (int r = r0; r < r0 + per && r < 16; r += 2)
+                        tmax = (r + 1 < 16 && r + 1 < r0 + per) ? bpin_max3(tmax, sm[r], sm[r + 1])
+                                                                : bpin_max3(tmax, sm[r], sm[r]);
+                }
+            }
+            if (slot == NT - 1 && t + 1 < T) v_lstore((t + 1) & 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (HAS_NEXT) absorb_rel(tmax);
+        stage_fence();
+    };
+
+    f32x16 sA, sB;
+    if (T > 0) {
+        dma_k(0, 0);
+        v_gload(0);
+        if (T > 1) dma_k(1, 1);
+        v_lstore(0);
+        stage_fence();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sA[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const u32x4 kf = kfrag(0, ks);
+            sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
+                                                         __builtin_bit_cast(bf16x8, qf[ks]), sA, 0, 0, 0);
+        }
+        mask_ragged(sA, 0);
+        float tmax = sA[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sA[r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        m_ref = tmax * c;                               // finite: every tile has a valid key row
+        __syncthreads();                                // K(0) fully consumed before K(2) lands on it
+
+        int t = 0;
+        for (; t + 2 < T; t += 2) {
+            step(std::true_type(), sA, sB, t);
+            step(std::true_type(), sB, sA, t + 1);
+        }
+        if (T - t == 2) {
+            step(std::true_type(), sA, sB, t);
+            step(std::false_type(), sB, sA, t + 1);
+        } else {
+            step(std::false_type(), sA, sB, t);
+        }
+    }
+
+    // ---- epilogue: fold the true row max back in, write this chunk's columns
+    const float fold = __builtin_amdgcn_exp2f(-max_rel);
+    const float l_tot = (l_run + __shfl_xor(l_run, 32)) * fold;
+    float *out = a.contrib;
+    float *omax = a.lmax, *osum = a.lsum;
+    int ldo = a.ldo;
+    if (a.kv_splits > 1) {
+        ldo = a.ws_ld;
+        out = a.ws_contrib + (size_t)split * a.m * ldo;
+        omax = a.ws_lmax + (size_t)split * a.m;
+        osum = a.ws_lsum + (size_t)split * a.m;
+    }
+    if (qrow < a.m) {
+        float *orow = out + (size_t)qrow * ldo + dv0;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int col = 32 * tt + crow16(r, hi);
+                if (dv0 + col < a.dv) orow[col] = oacc[tt][r] * fold;
+            }
+        if (hi == 0 && chunk == 0) {
+            omax[qrow] = T > 0 ? (m_ref + max_rel) * 0.69314718055994530942f : -INFINITY;
+            osum[qrow] = l_tot;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // converts: fp64 -> bf16 (RNE), row-major with zero-padded columns, and the transposed V image
 // ---------------------------------------------------------------------------
 __global__ void cvt_d2bf_kernel(const double *__restrict__ src, unsigned short *__restrict__ dst,
@@ -347,6 +695,29 @@ int pick_kv_splits_bf16(int m, int n_local, int dk, int dv) {
 }
 
 template <int DK, int DVC, int ABL = 0>
+static hipError_t launch_bf16_pipe(const Bf16Args &a, hipStream_t s) {
+    const int nqb = (a.m + kQRowsPerBlock - 1) / kQRowsPerBlock;
+    const int chunks = bf16_pad_dv(a.dv) / DVC;
+    const int ntiles = (a.n_local + kKvTile - 1) / kKvTile;
+    const int tiles_per_split = (ntiles + a.kv_splits - 1) / a.kv_splits;
+    const int kv_per_split = tiles_per_split > 0 ? tiles_per_split * kKvTile : kKvTile;
+    const size_t lds = (size_t)2 * (kKvTile * DK + DVC * 36) * sizeof(unsigned short);
+    static bool attr_done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_bf16_pipe_kernel<DK, DVC, ABL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done[dev] = true;
+    }
+    const float scale = 1.0f / sqrtf((float)a.dk);   // attention-mpi.c:208
+    hipLaunchKernelGGL((fused_bf16_pipe_kernel<DK, DVC, ABL>), dim3(nqb * chunks * a.kv_splits), dim3(256), lds,
+                       s, a, kv_per_split, nqb, chunks, scale);
+    return hipGetLastError();
+}
+
+template <int DK, int DVC, int ABL = 0>
 static hipError_t launch_bf16(const Bf16Args &a, hipStream_t s) {
     const int nqb = (a.m + kQRowsPerBlock - 1) / kQRowsPerBlock;
     const int chunks = bf16_pad_dv(a.dv) / DVC;
@@ -374,6 +745,15 @@ hipError_t launch_shard_partial_bf16(const Bf16Args &a, hipStream_t s) {
     if (a.dk > 512 || a.ldq != kp || a.ldk != kp) return hipErrorInvalidValue;
     hipError_t e = hipErrorInvalidValue;
     static const int tune = getenv("SDPA_TUNE") ? atoi(getenv("SDPA_TUNE")) : 0;
+    if (kp == 512 && vc == 256 && ((tune >> 8) & 15)) {   // timing-only ablations, pipelined kernel
+        switch ((tune >> 8) & 15) {
+            case 1: return launch_bf16_pipe<512, 256, 1>(a, s);     // no DMA / V staging
+            case 2: return launch_bf16_pipe<512, 256, 2>(a, s);     // no LDS fragment reads
+            case 8: return launch_bf16_pipe<512, 256, 8>(a, s);     // no barrier (racy)
+            case 9: return launch_bf16_pipe<512, 256, 9>(a, s);     // no staging, no barrier
+            default: return launch_bf16_pipe<512, 256, 11>(a, s);   // MFMA + softmax only
+        }
+    }
     if (kp == 512 && vc == 256 && ((tune >> 4) & 7)) {   // timing-only ablations
         switch ((tune >> 4) & 7) {
             case 1: return launch_bf16<512, 256, 1>(a, s);
@@ -383,7 +763,9 @@ hipError_t launch_shard_partial_bf16(const Bf16Args &a, hipStream_t s) {
             default: return launch_bf16<512, 256, 7>(a, s);
         }
     }
-#define SDPA_BCASE(KP, VC) if (kp == KP && vc == VC) e = launch_bf16<KP, VC>(a, s);
+    const bool pipe = !(tune & 4) && (reinterpret_cast<uintptr_t>(a.K) & 15) == 0;   // $SDPA_TUNE&4: old kernel
+#define SDPA_BCASE(KP, VC) \
+    if (kp == KP && vc == VC) e = pipe ? launch_bf16_pipe<KP, VC>(a, s) : launch_bf16<KP, VC>(a, s);
     SDPA_BCASE(64, 64)  SDPA_BCASE(64, 128)  SDPA_BCASE(64, 256)
     SDPA_BCASE(128, 64) SDPA_BCASE(128, 128) SDPA_BCASE(128, 256)
     SDPA_BCASE(256, 64) SDPA_BCASE(256, 128) SDPA_BCASE(256, 256)
