@@ -106,8 +106,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
-    ap.add_argument("--q-batch", type=int, default=0, help="Q rows per batch (0 = m at N=1, m/4 at N>1)")
+    ap.add_argument("--q-batch", type=int, default=0, help="Q rows per batch (0 = m at N=1, m/2 at N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--plan", default="kv", choices=["kv", "qrows"],
+                    help="multi-GPU plan: kv = K/V rows sharded + the reference's merge collectives "
+                         "(the headline); qrows = query rows sharded, K/V replicated, no merge collective")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
                     help="operand precision of the fused kernel (the headline metric is f32)")
     args = ap.parse_args()
@@ -137,21 +140,50 @@ def main():
     be = pkg.HipBackend(dev)
     w = WORKLOADS[args.workload]
     m, n, d = w["m"], w["n"], w["d"]
-    cnt, off = pkg.owner_count(n, world, rank), pkg.owner_disp(n, world, rank)
+    qrows = args.plan == "qrows"
+    if qrows:      # every rank holds all of K/V and its own slice of the query rows
+        cnt, off = n, 0
+        m_loc, m_off = pkg.owner_count(m, world, rank), pkg.owner_disp(m, world, rank)
+    else:
+        cnt, off = pkg.owner_count(n, world, rank), pkg.owner_disp(n, world, rank)
+        m_loc, m_off = m, 0
 
     # synthetic resident inputs, U(-1,1) (SURVEY.md 8d "D1"), fp64 as the boundary hands them over
     g = torch.Generator(device=dev)
     g.manual_seed(20240 + 0)
     Q64 = torch.rand((m, d), generator=g, device=dev, dtype=torch.float64) * 2 - 1
-    g.manual_seed(20240 + 1 + rank)
+    g.manual_seed(20240 + 1 + (0 if qrows else rank))
     K64 = torch.rand((cnt, d), generator=g, device=dev, dtype=torch.float64) * 2 - 1
     V64 = torch.rand((cnt, d), generator=g, device=dev, dtype=torch.float64) * 2 - 1
 
     B = args.q_batch if args.q_batch > 0 else (m if world == 1 else max(1, m // 2))
     B = min(B, m)
     nb = (m + B - 1) // B
-    sa = pkg.ShardedAttention(be, rank, world, dist, force_collectives=force_dist, precision=args.precision)
+    sa = pkg.ShardedAttention(be, 0 if qrows else rank, 1 if qrows else world, None if qrows else dist,
+                              force_collectives=force_dist and not qrows, precision=args.precision)
     kernel_events = []
+    if qrows:
+        Q64 = Q64[m_off:m_off + m_loc].contiguous()
+        B, nb = max(1, m_loc), 1
+        m_max = pkg.owner_count(m, world, 0)
+
+    def step_qrows(record):
+        sa.load_kv_shard_f64(K64, V64, n, d, d)
+        qf = sa.convert_q(Q64)
+        if record:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        contrib, lmax, lsum = sa.batch_partial(qf)
+        if record:
+            e1.record()
+            kernel_events.append((e0, e1, qf.shape[0]))
+        out = be.empty((m_max, d), torch.float64)
+        out[:m_loc] = be.finish_f64(contrib, lsum, d)
+        if dist is None:
+            return [out]
+        parts = [be.empty((m_max, d), torch.float64) for _ in range(world)] if rank == 0 else None
+        dist.gather(out, parts, dst=0)
+        return parts
 
     def step(record):
         sa.load_kv_shard_f64(K64, V64, n, d, d)                          # attention-mpi.c:224-225
@@ -181,12 +213,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    run = step_qrows if qrows else step
     for _ in range(args.warmup):
-        step(False)
+        run(False)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = step(True)
+        res = run(True)
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -232,14 +265,16 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": args.precision,
-            "data": "synthetic U(-1,1) fp64 Q/K/V resident in HBM (Q replicated, K/V row-sharded)",
+            "data": "synthetic U(-1,1) fp64 Q/K/V resident in HBM (%s)" %
+                    ("Q row-sharded, K/V replicated" if qrows else "Q replicated, K/V row-sharded"),
             "config": {"workload": "%s: m=%d n=%d dk=dv=%d, %s compute / fp64 in-out" % (args.workload, m, n, d, args.precision),
                        "q_batch": B, "q_batches": nb,
                        "kv_rows_per_gpu": cnt,
                        "kv_splits_in_gpu": (pkg.load().sdpa_dev_kv_splits_bf16 if args.precision == "bf16"
                                             else pkg.load().sdpa_dev_kv_splits)(min(B, m), cnt, d, d),
-                       "parallelism": "kv-shard x%d (all-reduce MAX, all-reduce SUM, reduce SUM over RCCL)" % world
-                                      if world > 1 else "single GPU"},
+                       "parallelism": ("single GPU" if world == 1 else
+                                       "q-row shard x%d (K/V replicated, gather of finished rows)" % world if qrows else
+                                       "kv-shard x%d (all-reduce MAX, all-reduce SUM, reduce SUM over RCCL)" % world)},
             "tflops": total_flop / (elapsed / args.steps) / 1e12,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak,

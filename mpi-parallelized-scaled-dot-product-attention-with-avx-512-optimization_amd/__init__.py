@@ -11,9 +11,9 @@ The directory name contains hyphens (it is the name the task prescribes), so imp
 """
 from . import _lib
 from ._lib import SdpaError, header_symbols, load
-from .engine import (DEFAULT_Q_BATCH, HipBackend, ShardedAttention, attention, attention_mpi, init,
+from .engine import (DEFAULT_Q_BATCH, HipBackend, ShardedAttention, attention, attention_mpi, attention_qrows, init,
                      last_timing, owner_count, owner_disp, round4, shutdown)
 
 __all__ = ["SdpaError", "header_symbols", "load", "HipBackend", "ShardedAttention", "attention",
-           "attention_mpi", "init", "last_timing", "owner_count", "owner_disp", "round4", "shutdown",
+           "attention_mpi", "attention_qrows", "init", "last_timing", "owner_count", "owner_disp", "round4", "shutdown",
            "DEFAULT_Q_BATCH", "_lib"]

@@ -333,6 +333,64 @@ class ShardedAttention:
         return outs
 
 
+def attention_qrows(Q, K, V, m, n, dk, dv, rank, world, dist=None, group=None, backend=None):
+    """The other natural sharding of this path: query rows are independent
+    (attention.c:28), so each rank takes rows [owner_disp(m), +owner_count(m)) against the WHOLE
+    K/V and no merge collective exists at all -- only the distribution (K, V broadcast, Q rows
+    scattered) and the gather of finished fp64 rows to rank 0.  An alternative to the K/V-sharded
+    plan the reference uses, for problems whose K/V fit one GPU (every BASELINE shape does).
+    Rank 0 passes the fp64 matrices, the others None; returns the result on rank 0."""
+    be = backend if backend is not None else HipBackend()
+    root = 0
+    if world > 1:
+        dims = torch.tensor([m, n, dk, dv] if rank == root else [0, 0, 0, 0], dtype=torch.int64,
+                            device=be.comm_device)
+        dist.broadcast(dims, src=root, group=group)
+        m, n, dk, dv = (int(x) for x in dims.tolist())
+    cnt, off = owner_count(m, world, rank), owner_disp(m, world, rank)
+    cmax = owner_count(m, world, 0)
+    if rank == root:
+        K64 = be.to_device(K, torch.float64).contiguous()
+        V64 = be.to_device(V, torch.float64).contiguous()
+        Q64 = be.to_device(Q, torch.float64).contiguous()
+    else:
+        K64 = be.empty((n, dk), torch.float64)
+        V64 = be.empty((n, dv), torch.float64)
+        Q64 = None
+    qloc = be.empty((cmax, dk), torch.float64)
+    if world > 1:
+        dist.broadcast(K64, src=root, group=group)
+        dist.broadcast(V64, src=root, group=group)
+        parts = None
+        if rank == root:
+            parts = []
+            for r in range(world):
+                c, d = owner_count(m, world, r), owner_disp(m, world, r)
+                buf = be.empty((cmax, dk), torch.float64).zero_()
+                buf[:c] = Q64[d:d + c]
+                parts.append(buf)
+        dist.scatter(qloc, parts, src=root, group=group)
+    else:
+        qloc = Q64
+    sa = ShardedAttention(be)
+    sa.load_kv_shard_f64(K64, V64, n, dk, dv)
+    out = be.empty((cmax, dv), torch.float64).zero_()
+    if cnt > 0:
+        contrib, lmax, lsum = sa.batch_partial(sa.convert_q(qloc[:cnt].contiguous()))
+        out[:cnt] = be.finish_f64(contrib, lsum, dv)
+    if world == 1:
+        return out[:cnt].cpu().numpy()
+    gathered = [be.empty((cmax, dv), torch.float64) for _ in range(world)] if rank == root else None
+    dist.gather(out, gathered, dst=root, group=group)
+    if rank != root:
+        return None
+    result = np.empty((m, dv), dtype=np.float64)
+    for r in range(world):
+        c, d = owner_count(m, world, r), owner_disp(m, world, r)
+        result[d:d + c] = gathered[r][:c].cpu().numpy()
+    return result
+
+
 def attention_mpi(Q, K, V, m, n, dk, dv, rank, world, dist=None, group=None, backend=None,
                   q_batch=DEFAULT_Q_BATCH):
     """Mirror of the MPI `attention()` (attention-mpi.c:191-407): rank 0 passes the fp64 matrices,

@@ -242,3 +242,22 @@ def test_headline_shape_row_subset(pkg, O):
     assert t["n_gpus"] >= 1 and t["q_batches"] == 2      # default Q batch = 16384 rows
     again = pkg.attention(Q, K, V)
     assert np.array_equal(again, got), "same inputs must give bit-identical results run to run"
+
+
+def test_qrows_plan_single_rank(pkg, orc, O):
+    """the Q-row-sharded alternative plan at world size 1 (engine.attention_qrows)"""
+    Q, K, V = O.make_inputs(150, 400, 64, 64, "D2", seed=12)
+    got = pkg.attention_qrows(Q, K, V, 150, 400, 64, 64, 0, 1)
+    check(got, orc.attention_f64(Q, K, V), V, "qrows")
+
+
+def test_cli_bf16_env_and_qbatch(tmp_path, O):
+    """the CLI's environment switches: bf16 operands still pass the template's 0.02 check, and a
+    small SDPA_QBATCH runs the multi-batch pipeline"""
+    Q, K, V, ans = O.read_case(os.path.join(GOLD, "cfg1_small_D1.bin"))
+    for env in ({"SDPA_PRECISION": "bf16"}, {"SDPA_QBATCH": "32"}):
+        r = subprocess.run([CLI, os.path.join(GOLD, "cfg1_small_D1.bin")], capture_output=True, text=True,
+                           env=dict(os.environ, SDPA_VERBOSE="1", **env))
+        assert r.returncode == 0 and r.stdout.startswith("Correct!\nElapsed time: "), r.stderr
+        if "SDPA_QBATCH" in env:
+            assert "q_batches=3" in r.stderr

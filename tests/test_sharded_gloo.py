@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, shape, dist_name, q_batch, out_path):
+def _worker(rank, world, port, shape, dist_name, q_batch, out_path, mode="kv"):
     import importlib
     for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
@@ -36,7 +36,15 @@ def _worker(rank, world, port, shape, dist_name, q_batch, out_path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         m, n, dk, dv = shape
-        if rank == 0:
+        if mode == "qrows":
+            if rank == 0:
+                Q, K, V = O.make_inputs(m, n, dk, dv, dist_name, seed=21)
+                np.save(out_path, pkg.attention_qrows(Q, K, V, m, n, dk, dv, rank, world, dist=dist,
+                                                      backend=OracleBackend()))
+            else:
+                assert pkg.attention_qrows(None, None, None, -1, -1, -1, -1, rank, world, dist=dist,
+                                           backend=OracleBackend()) is None
+        elif rank == 0:
             Q, K, V = O.make_inputs(m, n, dk, dv, dist_name, seed=21)
             res = pkg.attention_mpi(Q, K, V, m, n, dk, dv, rank, world, dist=dist,
                                     backend=OracleBackend(), q_batch=q_batch)
@@ -66,3 +74,15 @@ def test_attention_mpi_over_gloo(world, shape, dist_name, q_batch, tmp_path, orc
     # and it reproduces the single-process restatement of the same pipeline to fp32 rounding
     same = orc.attention_sharded_f32(Q, K, V, world)
     assert np.abs(got - same).max() <= 1e-5 * max(1.0, np.abs(V).max())
+
+
+@pytest.mark.parametrize("world,shape", [(2, (71, 130, 72, 40)), (3, (2, 50, 16, 8))])
+def test_attention_qrows_over_gloo(world, shape, tmp_path, orc, O):
+    """the Q-row-sharded alternative plan (no merge collective); world 3 with m=2 leaves a rank idle"""
+    out = str(tmp_path / "res.npy")
+    mp.spawn(_worker, args=(world, _free_port(), shape, "D2", 0, out, "qrows"), nprocs=world, join=True)
+    got = np.load(out)
+    m, n, dk, dv = shape
+    Q, K, V = O.make_inputs(m, n, dk, dv, "D2", seed=21)
+    want = orc.attention_f64(Q, K, V)
+    assert got.shape == want.shape and np.abs(got - want).max() <= fp32_tol(V)
