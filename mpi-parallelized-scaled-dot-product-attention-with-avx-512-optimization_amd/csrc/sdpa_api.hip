@@ -352,7 +352,7 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
     const double t_kv = now_us();
 
     // ---- Q batches -------------------------------------------------------------------
-    int B = 16384;
+    int B = 8192;
     if (const char *env = getenv("SDPA_QBATCH")) B = atoi(env) > 0 ? atoi(env) : B;
     if ((flags & SDPA_F_NO_PIPELINE) || B > m) B = m;
     const int nb = (m + B - 1) / B;
