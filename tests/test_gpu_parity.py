@@ -282,3 +282,15 @@ def test_random_shape_sweep_f32(pkg, be, orc, O):
         assert rel <= 1.0, "shape %s: err/tol = %.3f" % ((m, n, dk, dv, dist), rel)
         worst = max(worst, rel)
     print("worst err/tol over the sweep: %.3f" % worst)
+
+
+def test_error_ratio_vs_reference_fp32_pipeline(pkg, be, orc, O):
+    """our fp32 error against the fp64 answer, next to the error of the reference's
+    own fp32 pipeline (restated, P=1 and P=8); expected ratio <~ 2"""
+    for (m, n, d, dist) in [(200, 4096, 128, "D3"), (300, 1000, 64, "D2"), (128, 2048, 128, "D1")]:
+        Q, K, V = O.make_inputs(m, n, d, d, dist, seed=31)
+        want = orc.attention_f64(Q, K, V)
+        e_gpu = np.abs(dev_attention(pkg, be, Q, K, V) - want).max()
+        e_ref = max(np.abs(orc.attention_sharded_f32(Q, K, V, p) - want).max() for p in (1, 8))
+        print("m=%d n=%d d=%d %s: err_gpu %.2e  err_ref_fp32 %.2e  ratio %.2f" % (m, n, d, dist, e_gpu, e_ref, e_gpu / e_ref))
+        assert e_gpu <= 4.0 * e_ref + 1e-7
