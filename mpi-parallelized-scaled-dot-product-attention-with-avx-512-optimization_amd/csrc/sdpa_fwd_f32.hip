@@ -215,8 +215,6 @@ __global__ __launch_bounds__(256, 2) void fused_partial_kernel(PartialArgs a, in
     }
     __syncthreads();
 
-    const int base_prio = (a.tune & 1) ? ((blockIdx.x >> 8) & 1) : 0;
-    if (base_prio) __builtin_amdgcn_s_setprio(1);
 
     for (int t = 0; t < ntiles; ++t) {
         const int cur = t & 1;
@@ -262,7 +260,6 @@ __global__ __launch_bounds__(256, 2) void fused_partial_kernel(PartialArgs a, in
         }
 
         // ---- online softmax, one query row per lane pair (lane, lane^32)
-        if (a.tune & 2) __builtin_amdgcn_s_setprio(2);
         float tmax = s[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
@@ -284,7 +281,6 @@ __global__ __launch_bounds__(256, 2) void fused_partial_kernel(PartialArgs a, in
             l_run += s[r];
         }
 
-        if (a.tune & 2) { if (base_prio) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         // ---- O^T += V_tile^T . P^T   (A = V columns from LDS, B = P from registers)
         // V fragments are read two steps (8 MFMAs) ahead; the next tile's staged registers go
         // to the other LDS buffer half-way through, under the MFMAs.

@@ -23,7 +23,8 @@ struct PartialArgs {
     int ws_ld;                     // row stride of ws_contrib = dv rounded up to 4
     float *ws_lmax;                // [kv_splits x m]
     float *ws_lsum;                // [kv_splits x m]
-    int tune;                      // experiment switches ($SDPA_TUNE), 0 = shipped default
+    int tune;                      // $SDPA_TUNE: 4 = register-staged kernel instead of the pipelined one,
+                                   // 16/32/64 (+combinations) = timing-only ablations; 0 = shipped default
 };
 
 // bf16 variant: Q,K row-major bf16 (ld = dk padded to 64/128/256/512, pad columns zero),

@@ -152,3 +152,19 @@ def test_random_shape_sweep_bf16(pkg, be, orc, O):
         want = orc.attention_f64(Q, K, V)
         assert np.isfinite(got).all(), (m, n, dk, dv, dist)
         assert np.abs(got - want).max() <= bf16_tol(V), (m, n, dk, dv, dist)
+
+
+def test_bf16_race_screen_repeatability(pkg, be, O):
+    for (m, n, dk, dv) in [(384, 5000, 128, 128), (200, 2100, 512, 512)]:
+        Q, K, V = O.make_inputs(m, n, dk, dv, "D2", seed=78)
+        sa = pkg.ShardedAttention(be, precision="bf16")
+        sa.load_kv_from_root(K, V, n, dk, dv)
+        qb = sa.convert_q(torch.from_numpy(Q).cuda())
+        first = None
+        for it in range(25):
+            contrib, lmax, lsum = sa.batch_partial(qb)
+            cur = (contrib[:, :dv].clone(), lmax.clone(), lsum.clone())
+            if first is None:
+                first = cur
+            else:
+                assert all(torch.equal(a_, b_) for a_, b_ in zip(cur, first)), "launch %d differs" % it

@@ -294,3 +294,26 @@ def test_error_ratio_vs_reference_fp32_pipeline(pkg, be, orc, O):
         e_ref = max(np.abs(orc.attention_sharded_f32(Q, K, V, p) - want).max() for p in (1, 8))
         print("m=%d n=%d d=%d %s: err_gpu %.2e  err_ref_fp32 %.2e  ratio %.2f" % (m, n, d, dist, e_gpu, e_ref, e_gpu / e_ref))
         assert e_gpu <= 4.0 * e_ref + 1e-7
+
+
+def test_race_screen_repeatability(pkg, be, orc, O):
+    """The pipelined kernel hands K/V tiles between waves through LDS-DMA + barriers; a missing
+    wait shows up as rare wrong tiles.  Screen: 25 launches each of three shapes (with in-GPU
+    splits, ragged tails, both MFMA kernels) must be BITWISE identical to the first, which is
+    checked against the oracle."""
+    for (m, n, dk, dv, dist) in [(640, 6000, 128, 128, "D2"), (513, 3333, 64, 64, "D3"), (300, 2500, 96, 72, "D2")]:
+        Q, K, V = O.make_inputs(m, n, dk, dv, dist, seed=77)
+        sa = pkg.ShardedAttention(be)
+        sa.load_kv_from_root(K, V, n, dk, dv)
+        qf = sa.convert_q(torch.from_numpy(Q).cuda())
+        first = None
+        for it in range(25):
+            contrib, lmax, lsum = sa.batch_partial(qf)
+            cur = (contrib.clone(), lmax.clone(), lsum.clone())
+            if first is None:
+                first = cur
+                got = be.finish_f64(contrib, lsum, dv).cpu().numpy()
+                check(got, orc.attention_f64(Q, K, V), V, "first launch")
+            else:
+                assert all(torch.equal(a_[:, :dv] if a_.dim() == 2 else a_, b_[:, :dv] if b_.dim() == 2 else b_)
+                           for a_, b_ in zip(cur, first)), "launch %d differs from launch 0" % it
