@@ -139,11 +139,14 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
-    ap.add_argument("--q-batch", type=int, default=0, help="Q rows per batch (0 = m at N=1, m/2 at N>1)")
+    ap.add_argument("--q-batch", type=int, default=0, help="Q rows per batch (0 = all m rows in one batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--plan", default="kv", choices=["kv", "qrows"],
                     help="multi-GPU plan: kv = K/V rows sharded + the reference's merge collectives "
                          "(the headline); qrows = query rows sharded, K/V replicated, no merge collective")
+    ap.add_argument("--emulate-ranks", type=int, default=0,
+                    help="single-GPU dry run of ONE rank's share of an N-rank K/V-sharded job "
+                         "(K/V rows = n/N); a tuning aid, the printed line is not a benchmark result")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
                     help="operand precision of the fused kernel (the headline metric is f32)")
     args = ap.parse_args()
@@ -180,6 +183,8 @@ def main():
     else:
         cnt, off = pkg.owner_count(n, world, rank), pkg.owner_disp(n, world, rank)
         m_loc, m_off = m, 0
+    if args.emulate_ranks > 1 and world == 1:
+        cnt = pkg.owner_count(n, args.emulate_ranks, 0)
 
     # synthetic resident inputs, U(-1,1) (SURVEY.md 8d "D1"), fp64 as the boundary hands them over
     g = torch.Generator(device=dev)
@@ -189,7 +194,10 @@ def main():
     K64 = torch.rand((cnt, d), generator=g, device=dev, dtype=torch.float64) * 2 - 1
     V64 = torch.rand((cnt, d), generator=g, device=dev, dtype=torch.float64) * 2 - 1
 
-    B = args.q_batch if args.q_batch > 0 else (m if world == 1 else max(1, m // 2))
+    # one Q batch by default at every N: a dry run of one rank's share (tools/gpu_emulate_ranks.sh)
+    # showed per-rank step time 1.21 / 1.29 / 1.46 ms at N=8 for 1 / 2 / 4 batches -- shorter K/V
+    # ranges per launch cost more than overlapping the reduce with the next batch's kernel buys
+    B = args.q_batch if args.q_batch > 0 else m
     B = min(B, m)
     nb = (m + B - 1) // B
     sa = pkg.ShardedAttention(be, 0 if qrows else rank, 1 if qrows else world, None if qrows else dist,
@@ -289,7 +297,8 @@ def main():
             except Exception:  # noqa: BLE001
                 traffic = None
         line = {
-            "metric": "Q-rows/sec, fused online-softmax attention m=%d n=%d dk=dv=%d" % (m, n, d),
+            "metric": ("DRY RUN of 1 of %d ranks, not a result: " % args.emulate_ranks if args.emulate_ranks > 1 else "") +
+                      "Q-rows/sec, fused online-softmax attention m=%d n=%d dk=dv=%d" % (m, n, d),
             "value": m / (elapsed / args.steps),
             "unit": "Q-rows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
