@@ -144,6 +144,9 @@ def main():
     ap.add_argument("--plan", default="kv", choices=["kv", "qrows"],
                     help="multi-GPU plan: kv = K/V rows sharded + the reference's merge collectives "
                          "(the headline); qrows = query rows sharded, K/V replicated, no merge collective")
+    ap.add_argument("--merge", default="allreduce", choices=["allreduce", "gather"],
+                    help="shard merge: the reference's all-reduce(MAX)+all-reduce(SUM) (default), or one "
+                         "all-gather of the (lmax,lsum) pairs -- same algebra, one collective fewer")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="single-GPU dry run of ONE rank's share of an N-rank K/V-sharded job "
                          "(K/V rows = n/N); a tuning aid, the printed line is not a benchmark result")
@@ -201,7 +204,8 @@ def main():
     B = min(B, m)
     nb = (m + B - 1) // B
     sa = pkg.ShardedAttention(be, 0 if qrows else rank, 1 if qrows else world, None if qrows else dist,
-                              force_collectives=force_dist and not qrows, precision=args.precision)
+                              force_collectives=force_dist and not qrows, precision=args.precision,
+                              merge=args.merge)
     kernel_events = []
     if qrows:
         Q64 = Q64[m_off:m_off + m_loc].contiguous()
@@ -316,7 +320,8 @@ def main():
                                             else pkg.load().sdpa_dev_kv_splits)(min(B, m), cnt, d, d),
                        "parallelism": ("single GPU" if world == 1 else
                                        "q-row shard x%d (K/V replicated, gather of finished rows)" % world if qrows else
-                                       "kv-shard x%d (all-reduce MAX, all-reduce SUM, reduce SUM over RCCL)" % world)},
+                                       ("kv-shard x%d (all-reduce MAX, all-reduce SUM, reduce SUM over RCCL)" % world if args.merge == "allreduce"
+                                        else "kv-shard x%d (all-gather of (lmax,lsum), reduce SUM over RCCL)" % world))},
             "tflops": total_flop / (elapsed / args.steps) / 1e12,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak,

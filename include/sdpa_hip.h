@@ -143,6 +143,12 @@ SDPA_API int sdpa_dev_merge_rescale(float *contrib, int ldo, float *lsum, const 
 /* Merge step 5 (:358-362): inv = gsum==0 ? 0 : 1/gsum; contrib row *= inv.    */
 SDPA_API int sdpa_dev_merge_normalise(float *contrib, int ldo, const float *gsum, int m,
                                       int dv, void *stream);
+/* Merge steps 2-5 in one pass for hosts that ALL-GATHER the per-shard statistics instead of
+ * running the two all-reduces (same algebra): stats[parts][2][m] fp32 with
+ * stats[p][0][r] = lmax and stats[p][1][r] = lsum of shard p; `self` is this shard's index.
+ * contrib row *= expf(lmax_self - gmax) / gsum, gmax/gsum as attention-mpi.c:342-355.        */
+SDPA_API int sdpa_dev_merge_gathered(float *contrib, int ldo, const float *stats, int parts,
+                                     int self, int m, int dv, void *stream);
 /* Single-shard finish: step 5 with gsum = lsum fused with the fp32->fp64
  * writeback of :373,:396.  result[m x dv] dense fp64.                         */
 SDPA_API int sdpa_dev_finish_f64(const float *contrib, int ldo, const float *lsum,

@@ -54,6 +54,7 @@ _PROTOS = {
     "sdpa_dev_merge_rescale": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p,
                                         _c_int, _c_int, _c_void_p]),
     "sdpa_dev_merge_normalise": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p]),
+    "sdpa_dev_merge_gathered": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
     "sdpa_dev_finish_f64": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p]),
     "sdpa_dev_bf16_ld": (_c_int, [_c_int]),
     "sdpa_dev_bf16_dvp": (_c_int, [_c_int]),

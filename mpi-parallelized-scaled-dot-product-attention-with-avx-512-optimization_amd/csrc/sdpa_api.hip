@@ -712,6 +712,16 @@ int sdpa_dev_merge_normalise(float *contrib, int ldo, const float *gsum, int m, 
     return SDPA_OK;
 }
 
+int sdpa_dev_merge_gathered(float *contrib, int ldo, const float *stats, int parts, int self, int m,
+                            int dv, void *stream) {
+    if (!contrib || !stats || parts <= 0 || self < 0 || self >= parts || m <= 0 || dv <= 0 ||
+        check_ld(ldo, dv))
+        return SDPA_EINVAL;
+    SDPA_TRY(require_device());
+    HIP_TRY(sdpa::launch_merge_gathered(contrib, ldo, stats, parts, self, m, dv, (hipStream_t)stream));
+    return SDPA_OK;
+}
+
 int sdpa_dev_finish_f64(const float *contrib, int ldo, const float *lsum, double *result, int m,
                         int dv, void *stream) {
     if (!contrib || !lsum || !result || m <= 0 || dv <= 0 || check_ld(ldo, dv)) return SDPA_EINVAL;

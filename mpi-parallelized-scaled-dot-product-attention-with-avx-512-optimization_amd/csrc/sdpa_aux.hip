@@ -99,6 +99,38 @@ __global__ void merge_normalise_kernel(float *contrib, int ldo, const float *gsu
     }
 }
 
+// Steps 2-5 of the reference's merge (attention-mpi.c:340-362) in one pass, for hosts that
+// all-gather the per-shard (lmax, lsum) pairs instead of running the two all-reduces:
+// stats[p][0][r] = lmax of shard p, stats[p][1][r] = lsum of shard p.
+//   gmax = max_p lmax_p;  gsum = sum_p lsum_p * exp(lmax_p - gmax);
+//   contrib row *= exp(lmax_self - gmax) * (gsum == 0 ? 0 : 1/gsum)
+// Same algebra, one collective and one kernel fewer (SURVEY.md 8e allows the variant).
+__global__ void merge_gathered_kernel(float *contrib, int ldo, const float *stats, int parts, int self,
+                                      int m, int dv) {
+    const int c4n = ldo / 4;
+    const long total = (long)m * c4n;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(idx / c4n);
+        const int c4 = (int)(idx - (long)r * c4n);
+        if (4 * c4 >= dv) continue;
+        float gmax = -INFINITY;
+        for (int p = 0; p < parts; ++p) gmax = fmaxf(gmax, stats[((size_t)p * 2) * m + r]);
+        float gsum = 0.f;
+        for (int p = 0; p < parts; ++p) {
+            const float lm = stats[((size_t)p * 2) * m + r];
+            const float corr = (lm == -INFINITY) ? 0.f : expf(lm - gmax);
+            gsum += stats[((size_t)p * 2 + 1) * m + r] * corr;
+        }
+        const float lself = stats[((size_t)self * 2) * m + r];
+        const float w = (gsum == 0.f || lself == -INFINITY) ? 0.f : expf(lself - gmax) / gsum;
+        float4 *q = reinterpret_cast<float4 *>(contrib + (size_t)r * ldo) + c4;
+        float4 v = *q;
+        v.x *= w; v.y *= w; v.z *= w; v.w *= w;
+        *q = v;
+    }
+}
+
 // result[r*dv + c] = (double)(contrib[r*ldo + c] * (lsum==0 ? 0 : 1/lsum))
 __global__ void finish_f64_kernel(const float *__restrict__ contrib, int ldo,
                                   const float *__restrict__ lsum, double *__restrict__ result,
@@ -140,6 +172,14 @@ hipError_t launch_merge_normalise(float *contrib, int ldo, const float *gsum, in
     if (m <= 0) return hipSuccess;
     hipLaunchKernelGGL(merge_normalise_kernel, dim3(stream_grid((long)m * (ldo / 4))), dim3(256), 0, s,
                        contrib, ldo, gsum, m, dv);
+    return hipGetLastError();
+}
+
+hipError_t launch_merge_gathered(float *contrib, int ldo, const float *stats, int parts, int self,
+                                 int m, int dv, hipStream_t s) {
+    if (m <= 0) return hipSuccess;
+    hipLaunchKernelGGL(merge_gathered_kernel, dim3(stream_grid((long)m * (ldo / 4))), dim3(256), 0, s,
+                       contrib, ldo, stats, parts, self, m, dv);
     return hipGetLastError();
 }
 

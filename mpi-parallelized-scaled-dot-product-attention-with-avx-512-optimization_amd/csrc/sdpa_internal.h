@@ -66,6 +66,8 @@ hipError_t launch_merge_rescale(float *contrib, int ldo, float *lsum, const floa
                                 const float *gmax, int m, int dv, hipStream_t s);
 hipError_t launch_merge_normalise(float *contrib, int ldo, const float *gsum, int m, int dv,
                                   hipStream_t s);
+hipError_t launch_merge_gathered(float *contrib, int ldo, const float *stats, int parts, int self,
+                                 int m, int dv, hipStream_t s);
 hipError_t launch_finish_f64(const float *contrib, int ldo, const float *lsum, double *result,
                              int m, int dv, hipStream_t s);
 

@@ -212,6 +212,13 @@ class HipBackend:
                                                     contrib.shape[0], dv, self._stream()),
                   "sdpa_dev_merge_normalise")
 
+    def merge_gathered(self, contrib, stats, self_index, dv):
+        """attention-mpi.c:342-362 in one pass from all-gathered (lmax, lsum) pairs (in place)."""
+        with torch.cuda.device(self.device):
+            check(self.lib.sdpa_dev_merge_gathered(contrib.data_ptr(), contrib.shape[1], stats.data_ptr(),
+                                                   stats.shape[0], self_index, contrib.shape[0], dv,
+                                                   self._stream()), "sdpa_dev_merge_gathered")
+
     def finish_f64(self, contrib, lsum, dv):
         """single shard: step 5 with gsum = lsum fused with the fp64 writeback (:358-362,:373)."""
         out = self.empty((contrib.shape[0], dv), torch.float64)
@@ -228,9 +235,10 @@ class ShardedAttention:
     single rank)."""
 
     def __init__(self, backend, rank=0, world=1, dist=None, group=None, root=0, force_collectives=False,
-                 precision="f32"):
-        assert precision in ("f32", "bf16")
+                 precision="f32", merge="allreduce"):
+        assert precision in ("f32", "bf16") and merge in ("allreduce", "gather")
         self.precision = precision
+        self.merge = merge        # "allreduce": the reference's two-phase merge; "gather": one all-gather
         self.be = backend
         self.rank, self.world, self.root = rank, world, root
         self.dist = dist if (world > 1 or force_collectives) else None
@@ -307,6 +315,14 @@ class ShardedAttention:
         if dist is None:
             be.merge_normalise(contrib, lsum, self.dv)
             return contrib, None
+        if self.merge == "gather":
+            mine = torch.stack((lmax, lsum))                              # [2, m]
+            stats = be.empty((self.world if self.world > 1 else 1, 2, lmax.shape[0]), torch.float32)
+            dist.all_gather(list(stats.unbind(0)), mine, group=self.group)
+            be.merge_gathered(contrib, stats, self.rank if self.world > 1 else 0, self.dv)   # :342-362
+            work = dist.reduce(contrib, dst=self.root, op=dist.ReduceOp.SUM, group=self.group,
+                               async_op=async_reduce)                     # :380
+            return contrib, work
         gmax = lmax.clone()
         dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=self.group)     # :342
         be.merge_rescale(contrib, lsum, lmax, gmax, self.dv)              # :346-351
@@ -392,7 +408,7 @@ def attention_qrows(Q, K, V, m, n, dk, dv, rank, world, dist=None, group=None, b
 
 
 def attention_mpi(Q, K, V, m, n, dk, dv, rank, world, dist=None, group=None, backend=None,
-                  q_batch=DEFAULT_Q_BATCH):
+                  q_batch=DEFAULT_Q_BATCH, merge="allreduce"):
     """Mirror of the MPI `attention()` (attention-mpi.c:191-407): rank 0 passes the fp64 matrices,
     every other rank passes None and may pass garbage dims; returns the fp64 [m,dv] result on
     rank 0 (None elsewhere)."""
@@ -403,7 +419,7 @@ def attention_mpi(Q, K, V, m, n, dk, dv, rank, world, dist=None, group=None, bac
                             device=be.comm_device)
         dist.broadcast(dims, src=root, group=group)                       # :196
         m, n, dk, dv = (int(x) for x in dims.tolist())
-    sa = ShardedAttention(be, rank, world, dist, group, root)
+    sa = ShardedAttention(be, rank, world, dist, group, root, merge=merge)
     sa.load_kv_from_root(K, V, n, dk, dv)
 
     B = min(q_batch, m)

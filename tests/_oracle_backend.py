@@ -49,6 +49,13 @@ class OracleBackend:
         inv = torch.where(gsum == 0, torch.zeros_like(gsum), 1.0 / gsum)
         contrib.mul_(inv[:, None])
 
+    def merge_gathered(self, contrib, stats, self_index, dv):
+        lmax, lsum = stats[:, 0, :], stats[:, 1, :]
+        gmax = lmax.max(dim=0).values
+        gsum = (lsum * torch.exp(lmax - gmax)).sum(dim=0)
+        w = torch.where(gsum == 0, torch.zeros_like(gsum), torch.exp(lmax[self_index] - gmax) / gsum)
+        contrib.mul_(w[:, None])
+
     def finish_f64(self, contrib, lsum, dv):
         inv = torch.where(lsum == 0, torch.zeros_like(lsum), 1.0 / lsum)
         return (contrib[:, :dv] * inv[:, None]).to(torch.float64)

@@ -317,3 +317,23 @@ def test_race_screen_repeatability(pkg, be, orc, O):
             else:
                 assert all(torch.equal(a_[:, :dv] if a_.dim() == 2 else a_, b_[:, :dv] if b_.dim() == 2 else b_)
                            for a_, b_ in zip(cur, first)), "launch %d differs from launch 0" % it
+
+
+def test_gathered_merge_equals_two_phase(pkg, be, orc, O):
+    """sdpa_dev_merge_gathered (one pass from all-gathered (lmax,lsum)) == rescale + normalise"""
+    m, n, dk, dv, parts = 96, 1000, 64, 64, 5
+    Q, K, V = O.make_inputs(m, n, dk, dv, "D4", seed=9)
+    want = orc.attention_f64(Q, K, V)
+    qf = be.cvt_d2f(torch.from_numpy(Q).cuda())
+    triples = []
+    for r in range(parts):
+        c, d = pkg.owner_count(n, parts, r), pkg.owner_disp(n, parts, r)
+        sa = pkg.ShardedAttention(be)
+        sa.load_kv_from_root(K[d:d + c], V[d:d + c], c, dk, dv)
+        triples.append(sa.batch_partial(qf))
+    triples.append(be.shard_partial(qf, torch.empty(0, dk, device="cuda"), torch.empty(0, dv, device="cuda"), dk, dv))
+    stats = torch.stack([torch.stack((t[1], t[2])) for t in triples]).contiguous()    # [P+1, 2, m]
+    for r, (contrib, _, _) in enumerate(triples):
+        be.merge_gathered(contrib, stats, r, dv)
+    got = be.cvt_f2d(torch.stack([t[0] for t in triples]).sum(dim=0), dv).cpu().numpy()
+    check(got, want, V, "gathered merge, one empty shard")

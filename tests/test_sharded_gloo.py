@@ -47,11 +47,13 @@ def _worker(rank, world, port, shape, dist_name, q_batch, out_path, mode="kv"):
         elif rank == 0:
             Q, K, V = O.make_inputs(m, n, dk, dv, dist_name, seed=21)
             res = pkg.attention_mpi(Q, K, V, m, n, dk, dv, rank, world, dist=dist,
-                                    backend=OracleBackend(), q_batch=q_batch)
+                                    backend=OracleBackend(), q_batch=q_batch,
+                                    merge="gather" if mode == "kv-gather" else "allreduce")
             np.save(out_path, res)
         else:   # non-root ranks hold nothing and pass garbage dims (attention-mpi.c:508-517)
             res = pkg.attention_mpi(None, None, None, -1, -1, -1, -1, rank, world, dist=dist,
-                                    backend=OracleBackend(), q_batch=q_batch)
+                                    backend=OracleBackend(), q_batch=q_batch,
+                                    merge="gather" if mode == "kv-gather" else "allreduce")
             assert res is None
     finally:
         dist.destroy_process_group()
@@ -86,3 +88,14 @@ def test_attention_qrows_over_gloo(world, shape, tmp_path, orc, O):
     Q, K, V = O.make_inputs(m, n, dk, dv, "D2", seed=21)
     want = orc.attention_f64(Q, K, V)
     assert got.shape == want.shape and np.abs(got - want).max() <= fp32_tol(V)
+
+
+@pytest.mark.parametrize("world,shape,q_batch", [(2, (70, 130, 72, 40), 32), (3, (16, 2, 8, 8), 8)])
+def test_attention_mpi_gather_merge_over_gloo(world, shape, q_batch, tmp_path, orc, O):
+    """the one-all-gather variant of the shard merge (same algebra as attention-mpi.c:340-362)"""
+    out = str(tmp_path / "res.npy")
+    mp.spawn(_worker, args=(world, _free_port(), shape, "D2", q_batch, out, "kv-gather"), nprocs=world, join=True)
+    got = np.load(out)
+    m, n, dk, dv = shape
+    Q, K, V = O.make_inputs(m, n, dk, dv, "D2", seed=21)
+    assert np.abs(got - orc.attention_f64(Q, K, V)).max() <= fp32_tol(V)
