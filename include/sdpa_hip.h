@@ -108,7 +108,8 @@ SDPA_API int sdpa_owner_disp(int n, int size, int rank);
  * is a hipStream_t (NULL = the default stream).  Calls only enqueue work.
  * Leading dimensions are in elements, must be multiples of 4 and >= the column
  * count; columns [cols, ld) of every fp32 matrix handed to
- * sdpa_dev_shard_partial_f32 must be zero (sdpa_dev_cvt_d2f writes them so).  */
+ * sdpa_dev_shard_partial_f32 must be zero (sdpa_dev_cvt_d2f writes them so).
+ * Operand base pointers must be 16-byte aligned (SDPA_EINVAL otherwise).        */
 
 /* fp64 -> fp32, round-to-nearest-even; dst[r*ld + c], pad columns zeroed.
  * Replaces cvt_d2f_avx512 (attention-mpi.c:31-64).                           */

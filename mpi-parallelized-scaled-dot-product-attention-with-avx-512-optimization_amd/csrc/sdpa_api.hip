@@ -19,6 +19,7 @@
 
 #include <dlfcn.h>
 #include <math.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -162,6 +163,8 @@ double now_us() {
 }
 
 int check_ld(int ld, int cols) { return (ld >= cols && ld % 4 == 0) ? SDPA_OK : SDPA_EINVAL; }
+
+bool misaligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
 
 int require_device() {
     int cnt = 0;
@@ -679,6 +682,8 @@ int sdpa_dev_shard_partial_f32(const float *Qf, int ldq, const float *Kf, int ld
     if (n_local > 0 && (!Kf || !Vf)) return SDPA_EINVAL;
     if (check_ld(ldq, dk) || check_ld(ldk, dk) || check_ld(ldv, dv) || check_ld(ldo, dv))
         return SDPA_EINVAL;
+    if (misaligned16(Qf) || misaligned16(Kf) || misaligned16(Vf) || misaligned16(contrib))
+        return SDPA_EINVAL;              // the kernels use 16-byte accesses on every operand
     if (dv > 1024) return SDPA_EUNSUP;
     SDPA_TRY(require_device());
     PartialArgs a = {};
@@ -773,6 +778,7 @@ int sdpa_dev_shard_partial_bf16(const void *Qb, int ldq, const void *Kb, int ldk
     if (dk > 512 || dv > 1024) return SDPA_EUNSUP;
     if (ldq != sdpa::bf16_pad_dk(dk) || ldk != ldq || ldvt < n_local || ldvt % 32 != 0 || check_ld(ldo, dv))
         return SDPA_EINVAL;
+    if (misaligned16(Qb) || misaligned16(Kb) || misaligned16(Vt) || misaligned16(contrib)) return SDPA_EINVAL;
     if ((double)sdpa::bf16_pad_dv(dv) * (double)ldvt * 2.0 >= 4294967296.0) return SDPA_EUNSUP;
     SDPA_TRY(require_device());
     sdpa::Bf16Args a = {};

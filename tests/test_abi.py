@@ -50,6 +50,7 @@ def test_argument_validation_precedes_device_use(pkg):
     assert lib.sdpa_dev_cvt_d2f(p, p, 4, 8, 4, None) == E        # ld < cols
     assert lib.sdpa_dev_shard_partial_f32(p, 4, p, 4, p, 4, p, 4, p, p, 0, 4, 4, 4, None, 0, None) == E
     assert lib.sdpa_dev_shard_partial_f32(p, 4, p, 4, p, 4, p, 3, p, p, 4, 4, 4, 4, None, 0, None) == E
+    assert lib.sdpa_dev_shard_partial_f32(p + 4, 4, p, 4, p, 4, p, 4, p, p, 2, 2, 4, 4, None, 0, None) == E  # misaligned
     assert lib.sdpa_owner_count(5, 0, 0) == E
     assert lib.sdpa_dev_kv_splits(8192, 8192, 128, 128) == 8
     assert lib.sdpa_dev_kv_splits(32768, 65536, 128, 128) == 2
