@@ -372,7 +372,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(m, n, d)
         else:
             line["cpu_baseline"] = None
-        if world == 1 and not qrows:
+        if world == 1 and not qrows and args.emulate_ranks <= 1 and not force_dist:
             try:
                 del Q64, K64, V64
                 torch.cuda.empty_cache()
