@@ -366,6 +366,14 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
         else
             qf[ks] = u32x4{0u, 0u, 0u, 0u};
     }
+    // In the one-wave-per-SIMD shapes (d = 512) re-define the Q fragments as ACCUMULATOR-file
+    // values: an empty asm with an "a" constraint makes them AGPR-class virtual registers, and an
+    // MFMA may read its A/B operands straight from AGPRs -- so the 128 wave-persistent Q registers
+    // sit beside the O accumulators instead of filling the VGPR half that prefetch needs.
+    if constexpr (DK + 2 * DVC > 512) {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+a"(qf[ks]));
+    }
 
     f32x16 oacc[NT];
 #pragma unroll
