@@ -28,6 +28,14 @@
 //     few query blocks; the split merge is the reference's own (max,sum,contrib)
 //     merge algebra (:340-362) applied inside one GPU.
 //
+// Kernels in this file:
+//   fused_pipelined_kernel<DK,DV>   dense dk, dv in {64,128}: LDS-DMA staging, XOR-swizzled K image,
+//                                   two live score tiles (the shipped path of every BASELINE fp32
+//                                   config; 142 TFLOP/s = 90.5 % of peak at the metric shape)
+//   fused_partial_kernel<DKP,DVP>   any dk, dv <= 128 (padded to 32/64/128): register-staged
+//   generic_partial_kernel          dk or dv > 128: VALU-only correctness path
+//   split_merge_kernel              merge of the in-GPU K/V splits
+//
 #include "sdpa_internal.h"
 
 #include <math.h>
