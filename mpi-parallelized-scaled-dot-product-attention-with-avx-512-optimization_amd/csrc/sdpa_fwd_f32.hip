@@ -32,8 +32,9 @@
 //   fused_pipelined_kernel<DK,DV>   dense dk, dv in {64,128}: LDS-DMA staging, XOR-swizzled K image,
 //                                   two live score tiles (the shipped path of every BASELINE fp32
 //                                   config; 142 TFLOP/s = 90.5 % of peak at the metric shape)
-//   fused_partial_kernel<DKP,DVP>   any dk, dv <= 128 (padded to 32/64/128): register-staged
-//   generic_partial_kernel          dk or dv > 128: VALU-only correctness path
+//   fused_partial_kernel<DKP,DVP>   any dk <= 256 (padded to 32/64/128/256), any dv (chunks of <= 128
+//                                   columns): register-staged
+//   generic_partial_kernel          dk > 256: VALU-only correctness path
 //   split_merge_kernel              merge of the in-GPU K/V splits
 //
 #include "sdpa_internal.h"
@@ -103,9 +104,12 @@ template <> struct VFrag<1> {
     static __device__ __forceinline__ VFrag load(const float *p) { VFrag f; f.v[0] = *p; return f; }
 };
 
+// dv > 128 is processed in chunks of 128 columns by separate workgroups (n_chunks > 1; the score
+// tile is recomputed per chunk); dk up to 256 keeps the whole Q fragment in registers (128 VGPRs,
+// one wave per SIMD then).
 template <int DKP, int DVP>
-__global__ __launch_bounds__(256, 2) void fused_partial_kernel(PartialArgs a, int kv_per_split,
-                                                                int n_qblocks, float scale) {
+__global__ __launch_bounds__(256, (DKP > 128) ? 1 : 2) void fused_partial_kernel(
+    PartialArgs a, int kv_per_split, int n_qblocks, int n_chunks, float scale) {
     constexpr int NU = DKP / 8;     // 16-byte K reads (4 MFMA k-steps each) per tile per lane
     constexpr int NT = DVP / 32;    // 32-column O^T tiles; also floats per V read
     constexpr int KLD = DKP + 4;    // padded K row (floats): ds_read_b128 column reads conflict-free
@@ -124,10 +128,13 @@ __global__ __launch_bounds__(256, 2) void fused_partial_kernel(PartialArgs a, in
     const int li = lane & 31;               // MFMA row/col index of this lane
     const int hi = lane >> 5;               // which k-slot / accumulator half
 
-    const int work = xcd_remap(blockIdx.x, gridDim.x);
-    const int split = work / n_qblocks;
-    const int qblock = work - split * n_qblocks;
+    int work = xcd_remap(blockIdx.x, gridDim.x);
+    const int qblock = work % n_qblocks;
+    work /= n_qblocks;
+    const int chunk = work % n_chunks;
+    const int split = work / n_chunks;
     const int qrow = qblock * kQRowsPerBlock + wave * 32 + li;   // this lane's query row
+    const int dv0 = chunk * DVP;                                  // first V / output column
 
     const int kv_begin = split * kv_per_split;
     const int kv_end = min(a.n_local, kv_begin + kv_per_split);
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void fused_partial_kernel(PartialArgs a, in
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
         const int idx = tid + 256 * i;
-        voff[i] = (unsigned)((idx / (DVP / 4)) * a.ldv + min(4 * (idx % (DVP / 4)), ldv_last)) * 4u;
+        voff[i] = (unsigned)((idx / (DVP / 4)) * a.ldv + min(dv0 + 4 * (idx % (DVP / 4)), ldv_last)) * 4u;
     }
     auto tile_gload = [&](int tile) __attribute__((always_inline)) {
         const int base = kv_begin + tile * kKvTile;          // wave-uniform
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void fused_partial_kernel(PartialArgs a, in
             for (int i = 0; i < VPT; ++i) {
                 const int idx = tid + 256 * i;
                 const int row = min(idx / (DVP / 4), last);
-                const int col = min(4 * (idx % (DVP / 4)), ldv_last);
+                const int col = min(dv0 + 4 * (idx % (DVP / 4)), ldv_last);
                 vreg[i] = *reinterpret_cast<const f32x4 *>(vb + (unsigned)(row * a.ldv + col) * 4u);
             }
         }
@@ -328,12 +335,12 @@ __global__ __launch_bounds__(256, 2) void fused_partial_kernel(PartialArgs a, in
         osum = a.ws_lsum + (size_t)split * a.m;
     }
     if (qrow < a.m) {
-        float *orow = out + (size_t)qrow * ldo;
+        float *orow = out + (size_t)qrow * ldo + dv0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int col0 = NT * crow(r, hi);
             if constexpr (NT == 4) {
-                if (col0 + 3 < a.dv) {
+                if (dv0 + col0 + 3 < a.dv) {
                     *reinterpret_cast<float4 *>(orow + col0) =
                         make_float4(oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]);
                     continue;
@@ -341,9 +348,9 @@ __global__ __launch_bounds__(256, 2) void fused_partial_kernel(PartialArgs a, in
             }
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt)
-                if (col0 + tt < a.dv) orow[col0 + tt] = oacc[tt][r];
+                if (dv0 + col0 + tt < a.dv) orow[col0 + tt] = oacc[tt][r];
         }
-        if (hi == 0) {
+        if (hi == 0 && chunk == 0) {
             omax[qrow] = m_run * scale;
             osum[qrow] = l_tot;
         }
@@ -805,15 +812,17 @@ __global__ __launch_bounds__(256) void generic_partial_kernel(PartialArgs a, flo
 // ---------------------------------------------------------------------------
 // host-side launch logic
 // ---------------------------------------------------------------------------
-static inline int pad_dim(int d) { return d <= 32 ? 32 : (d <= 64 ? 64 : 128); }
+static inline int pad_dim(int d) { return d <= 32 ? 32 : (d <= 64 ? 64 : (d <= 128 ? 128 : 256)); }
+static inline int dv_chunk(int dv) { return dv <= 32 ? 32 : (dv <= 64 ? 64 : 128); }
+static inline int dv_chunks(int dv) { return (dv + dv_chunk(dv) - 1) / dv_chunk(dv); }
 
 int pick_kv_splits(int m, int n_local, int dk, int dv) {
-    if (dk > kMaxFastDim || dv > kMaxFastDim) return 1;
+    if (dk > kMaxMfmaDk) return 1;               // VALU-only fallback kernel: no splits
     if (m <= 0 || n_local <= 0) return 1;
-    const int nqb = (m + kQRowsPerBlock - 1) / kQRowsPerBlock;
+    const int nqb = ((m + kQRowsPerBlock - 1) / kQRowsPerBlock) * dv_chunks(dv);
     const int ntiles = (n_local + kKvTile - 1) / kKvTile;
-    // aim for 2 resident workgroups on each of the 256 CUs, at least 4 tiles a split
-    int want = (512 + nqb - 1) / nqb;
+    // aim for 2 resident workgroups on each of the 256 CUs (1 when dk > 128), >= 4 tiles a split
+    int want = ((dk > 128 ? 256 : 512) + nqb - 1) / nqb;
     int cap = ntiles / 4;
     if (cap < 1) cap = 1;
     if (want > cap) want = cap;
@@ -840,6 +849,7 @@ static hipError_t launch_fast(const PartialArgs &a, hipStream_t s) {
     const int ntiles = (a.n_local + kKvTile - 1) / kKvTile;
     const int tiles_per_split = (ntiles + a.kv_splits - 1) / a.kv_splits;
     const int kv_per_split = tiles_per_split > 0 ? tiles_per_split * kKvTile : kKvTile;
+    const int chunks = dv_chunks(a.dv);
     const size_t lds = (size_t)2 * kKvTile * ((DKP + 4) + DVP) * sizeof(float);
     static bool attr_done[64] = {};
     int dev = 0;
@@ -852,8 +862,8 @@ static hipError_t launch_fast(const PartialArgs &a, hipStream_t s) {
         attr_done[dev] = true;
     }
     const float scale = 1.0f / sqrtf((float)a.dk);   // attention-mpi.c:208
-    hipLaunchKernelGGL((fused_partial_kernel<DKP, DVP>), dim3(nqb * a.kv_splits), dim3(256), lds, s,
-                       a, kv_per_split, nqb, scale);
+    hipLaunchKernelGGL((fused_partial_kernel<DKP, DVP>), dim3(nqb * chunks * a.kv_splits), dim3(256), lds,
+                       s, a, kv_per_split, nqb, chunks, scale);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (a.kv_splits > 1) {
@@ -898,7 +908,7 @@ hipError_t launch_shard_partial(const PartialArgs &a_in, hipStream_t s) {
     PartialArgs a = a_in;
     static const int tune_env = getenv("SDPA_TUNE") ? atoi(getenv("SDPA_TUNE")) : 0;
     a.tune = tune_env;
-    if (a.dk > kMaxFastDim || a.dv > kMaxFastDim) {
+    if (a.dk > kMaxMfmaDk) {
         if (a.dv > 64 * kGenericMaxCols) return hipErrorInvalidValue;
         const size_t lds = (size_t)4 * a.ldq * sizeof(float);
         if (lds > 64 * 1024) return hipErrorInvalidValue;
@@ -925,8 +935,9 @@ hipError_t launch_shard_partial(const PartialArgs &a_in, hipStream_t s) {
         if (a.dk == 128 && a.dv == 64) return launch_pipelined<128, 64>(a, s);
         if (a.dk == 64 && a.dv == 128) return launch_pipelined<64, 128>(a, s);
     }
-    const int kp = pad_dim(a.dk), vp = pad_dim(a.dv);
+    const int kp = pad_dim(a.dk), vp = dv_chunk(a.dv);
 #define SDPA_CASE(KP, VP) if (kp == KP && vp == VP) return launch_fast<KP, VP>(a, s);
+    SDPA_CASE(256, 128) SDPA_CASE(256, 64) SDPA_CASE(256, 32)
     SDPA_CASE(128, 128) SDPA_CASE(128, 64) SDPA_CASE(128, 32)
     SDPA_CASE(64, 128)  SDPA_CASE(64, 64)  SDPA_CASE(64, 32)
     SDPA_CASE(32, 128)  SDPA_CASE(32, 64)  SDPA_CASE(32, 32)
