@@ -135,7 +135,12 @@ struct Engine {
     std::vector<Gpu> g;
     Rccl rccl;
     sdpa_timing last = {};
-} E;
+};
+// Heap-allocated and never destroyed on purpose: at process exit the order in which this library's
+// static destructors and the HIP runtime's run is not ours to choose (inside a Python process the
+// runtime belongs to PyTorch), and nothing here needs tearing down then -- sdpa_shutdown() is the
+// explicit release.
+Engine &E = *new Engine;
 
 inline int round4(int x) { return (x + 3) / 4 * 4; }
 

@@ -337,3 +337,22 @@ def test_gathered_merge_equals_two_phase(pkg, be, orc, O):
         be.merge_gathered(contrib, stats, r, dv)
     got = be.cvt_f2d(torch.stack([t[0] for t in triples]).sum(dim=0), dv).cpu().numpy()
     check(got, want, V, "gathered merge, one empty shard")
+
+
+@pytest.mark.parametrize("m,n,dk,dv", [(192, 4096, 64, 64), (160, 4096, 128, 128), (100, 3000, 48, 40), (64, 2048, 200, 136)])
+def test_steep_softmax_exercises_the_rescale_paths(m, n, dk, dv, pkg, be, orc, O):
+    """Scores with a standard deviation of ~25: the row max keeps jumping by far more than the
+    deferred-rescale threshold (2^24) between tiles, so the rare rescale branches of every kernel
+    (pipelined, register-staged, chunked) run many times; the softmax is nearly an arg-max."""
+    rng = np.random.default_rng(dk + dv)
+    s = 5.0 * (dk / 16.0) ** 0.25            # q.k/sqrt(dk) has std s^2 * ... ~ 25 at any dk
+    Q = rng.standard_normal((m, dk)) * s
+    K = rng.standard_normal((n, dk)) * s
+    V = rng.standard_normal((n, dv)) * 3.0
+    scores = (Q @ K.T) / np.sqrt(dk)
+    assert scores.max(axis=1).min() - scores[:, :32].max(axis=1).max() < 0 or True   # (documentation only)
+    assert (scores.max(axis=1) - scores[:, :32].max(axis=1)).max() > 17.0           # > 2^24 in the exp2 domain
+    got = dev_attention(pkg, be, Q, K, V)
+    check(got, orc.attention_f64(Q, K, V), V, "steep")
+    # and through the host-level path with several in-GPU splits / batches
+    check(pkg.attention(Q, K, V), orc.attention_f64(Q, K, V), V, "steep host")
