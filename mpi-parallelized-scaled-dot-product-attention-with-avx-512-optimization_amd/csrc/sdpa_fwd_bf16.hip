@@ -320,6 +320,14 @@ __device__ __forceinline__ float bpin_max3(float a, float b, float c) {
     return y;
 }
 
+// fragment prefetch depths of the one-wave-per-SIMD shapes (K ring, V ring)
+#ifndef SDPA_BF16_KD1
+#define SDPA_BF16_KD1 3
+#endif
+#ifndef SDPA_BF16_VD1
+#define SDPA_BF16_VD1 2
+#endif
+
 template <int DK, int DVC, int ABL = 0>
 __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_pipe_kernel(
     Bf16Args a, int kv_per_split, int n_qblocks, int n_chunks, float scale) {
@@ -358,6 +366,9 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
     const int T = kv_end > kv_begin ? (kv_end - kv_begin + kKvTile - 1) / kKvTile : 0;
     const float c = scale * 1.44269504088896340736f;
 
+    // in the 512-register mode every MFMA result lands in the accumulator file, so one score
+    // tile (16) sits there beside O: that many Q registers stay on the VGPR side
+    constexpr int kQfInVgpr = 4;
     u32x4 qf[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
@@ -372,7 +383,7 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
     // sit beside the O accumulators instead of filling the VGPR half that prefetch needs.
     if constexpr (DK + 2 * DVC > 512) {
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+a"(qf[ks]));
+        for (int ks = 0; ks < NKS - kQfInVgpr; ++ks) asm volatile("" : "+a"(qf[ks]));
     }
 
     f32x16 oacc[NT];
@@ -490,6 +501,22 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
         max_rel = fmaxf(max_rel, tmax);
     };
 
+    // One wave per SIMD: keep the O accumulators AGPR-class across the step boundary.  Left to
+    // itself hipcc carries them as VGPR values (the rare rescale multiplies them) and shuttles all
+    // of them through v_accvgpr_read/write around the P.V MFMAs of EVERY step.
+    auto pin_o = [&]() __attribute__((always_inline)) {
+        if constexpr (DK + 2 * DVC > 512) {
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) asm volatile("" : "+a"(oacc[tt]));
+        }
+    };
+
+    // ... and the score tiles VGPR-class (the softmax reads every element): with Q and O the
+    // accumulator file is exactly full, a score tile parked there pushes Q fragments to scratch.
+    auto pin_s = [&](f32x16 &sx) __attribute__((always_inline)) {
+        if constexpr (DK + 2 * DVC > 512) asm volatile("" : "+v"(sx));
+    };
+
     constexpr int PPK = NKS >= 16 ? 1 : 16 / NKS;        // P values finished per QK^T MFMA slot
     constexpr int KPP = NKS >= 16 ? NKS / 16 : 1;        // QK^T MFMAs per P value
 
@@ -514,7 +541,7 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
             // [A] S^T(t+1) on the matrix pipe  ||  P(t) on the VALU
             // K fragments are read KD steps ahead of their MFMA (a bf16 MFMA retires in 32 cycles, an
             // LDS read takes ~4x that; deeper rings measured slower: they spill inside the loop)
-            constexpr int KD = NKS < 6 ? NKS : (DK + 2 * DVC > 512 ? 3 : 2);
+            constexpr int KD = NKS < 6 ? NKS : (DK + 2 * DVC > 512 ? SDPA_BF16_KD1 : 2);
             u32x4 kq[KD];
 #pragma unroll
             for (int i = 0; i < KD; ++i) kq[i] = kfrag(kbuf, i);
@@ -530,6 +557,7 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
                 if (ks % KPP == 0) p_slice((ks / KPP) * PPK, PPK);
             }
             __builtin_amdgcn_sched_barrier(0);
+            pin_s(sm);
         } else {
             p_slice(0, 16);
         }
@@ -541,7 +569,7 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
         const unsigned short *vt = Vs + vbuf * VTILE + li * VLD + 4 * hi;
         float tmax = -INFINITY;
         constexpr int SLOTS = 2 * NT;                     // P.V MFMAs of this step
-        constexpr int VD = 2;                              // V fragment prefetch depth
+        constexpr int VD = (DK + 2 * DVC > 512) ? SDPA_BF16_VD1 : 2;   // V fragment prefetch depth
         auto vfrag = [&](int slot) __attribute__((always_inline)) -> u32x4 {
             const int h = slot / NT, tt = slot % NT;
             if constexpr (ABL & 2) return qf[(tt + h) % NKS];
@@ -576,7 +604,9 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
             if (slot == NT - 1 && t + 1 < T) v_lstore((t + 1) & 1);
         }
         __builtin_amdgcn_sched_barrier(0);
+        pin_o();
         if constexpr (HAS_NEXT) absorb_rel(tmax);
+        pin_o();
         stage_fence();
     };
 
