@@ -160,7 +160,11 @@ SDPA_API int sdpa_dev_finish_f64(const float *contrib, int ldo, const float *lsu
  * fp32 accumulation; tolerance 1e-2*max(1,max|V|).  Operand images:
  *   Qb[m x ld], Kb[n_local x ld]   bf16 row-major, ld = sdpa_dev_bf16_ld(dk) (dk padded to
  *                                  64/128/256/512), pad columns zero;
- *   Vt[dvp x ldvt]                 bf16, V TRANSPOSED: Vt[c*ldvt + j] = V[j][c];
+ *   Vt[dvp x ldvt]                 bf16, V TRANSPOSED with the keys of a row permuted inside
+ *                                  16-key groups: Vt[c*ldvt + sdpa_dev_bf16_kvpos(j)] = V[j][c],
+ *                                  kvpos(j) = j with bits 2 and 3 swapped (group order 0-3, 8-11,
+ *                                  4-7, 12-15: the eight keys one MFMA lane multiplies are then
+ *                                  16 contiguous bytes);
  *                                  dvp = sdpa_dev_bf16_dvp(dv), ldvt = sdpa_dev_bf16_ldn(n_local)
  *                                  (n_local padded to 32), pads zero.
  * sdpa_dev_cvt_d2bf / sdpa_dev_cvt_d2bf_t write these images from dense fp64.
@@ -168,6 +172,7 @@ SDPA_API int sdpa_dev_finish_f64(const float *contrib, int ldo, const float *lsu
 SDPA_API int  sdpa_dev_bf16_ld(int dk);
 SDPA_API int  sdpa_dev_bf16_dvp(int dv);
 SDPA_API long sdpa_dev_bf16_ldn(long n_local);
+SDPA_API long sdpa_dev_bf16_kvpos(long j);
 SDPA_API int  sdpa_dev_cvt_d2bf(const double *src, void *dst, long rows, int cols, int ld,
                                 void *stream);
 SDPA_API int  sdpa_dev_cvt_d2bf_t(const double *src, void *dst, long rows, int cols, int cols_pad,

@@ -59,6 +59,7 @@ _PROTOS = {
     "sdpa_dev_bf16_ld": (_c_int, [_c_int]),
     "sdpa_dev_bf16_dvp": (_c_int, [_c_int]),
     "sdpa_dev_bf16_ldn": (_c_long, [_c_long]),
+    "sdpa_dev_bf16_kvpos": (_c_long, [_c_long]),
     "sdpa_dev_cvt_d2bf": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p]),
     "sdpa_dev_cvt_d2bf_t": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_long, _c_void_p]),
     "sdpa_dev_kv_splits_bf16": (_c_int, [_c_int] * 4),

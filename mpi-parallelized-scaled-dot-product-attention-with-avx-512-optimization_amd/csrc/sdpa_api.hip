@@ -516,12 +516,7 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
                 a.lsum = (float *)g.lsum[s].p;
                 a.m = bs;  a.n_local = n_loc;  a.dk = dk;  a.dv = dv;
                 a.kv_splits = splits_here = sdpa::pick_kv_splits_bf16(bs, n_loc, dk, dv);
-                if (a.kv_splits > 1) {
-                    a.ws_ld = ldo;
-                    a.ws_contrib = (float *)g.ws.p;
-                    a.ws_lmax = a.ws_contrib + (size_t)a.kv_splits * bs * a.ws_ld;
-                    a.ws_lsum = a.ws_lmax + (size_t)a.kv_splits * bs;
-                }
+                sdpa::bf16_carve_workspace(a, g.ws.p, ldo);
                 if (n_loc > 0) {
                     HIP_TRY(sdpa::launch_shard_partial_bf16(a, g.s_run));
                 } else {   // empty shard: the fp32 launcher's T = 0 path writes (0, -inf, 0)
@@ -743,6 +738,7 @@ int sdpa_dev_finish_f64(const float *contrib, int ldo, const float *lsum, double
 int sdpa_dev_bf16_ld(int dk) { return (dk <= 0 || dk > 512) ? SDPA_EUNSUP : sdpa::bf16_pad_dk(dk); }
 int sdpa_dev_bf16_dvp(int dv) { return (dv <= 0 || dv > 1024) ? SDPA_EUNSUP : sdpa::bf16_pad_dv(dv); }
 long sdpa_dev_bf16_ldn(long n_local) { return n_local < 0 ? SDPA_EINVAL : sdpa::bf16_pad_n(n_local); }
+long sdpa_dev_bf16_kvpos(long j) { return j < 0 ? SDPA_EINVAL : sdpa::bf16_kvpos(j); }
 
 int sdpa_dev_cvt_d2bf(const double *src, void *dst, long rows, int cols, int ld, void *stream) {
     if (rows < 0 || cols <= 0 || ld < cols) return SDPA_EINVAL;
@@ -770,8 +766,7 @@ int sdpa_dev_kv_splits_bf16(int m, int n_local, int dk, int dv) {
 
 size_t sdpa_dev_workspace_bytes_bf16(int m, int n_local, int dk, int dv) {
     if (m <= 0 || n_local < 0 || dk <= 0 || dv <= 0) return 0;
-    const int s = sdpa::pick_kv_splits_bf16(m, n_local, dk, dv);
-    return s <= 1 ? 0 : (size_t)s * m * ((size_t)round4(dv) + 2) * sizeof(float);
+    return sdpa::bf16_workspace_bytes(m, n_local, dk, dv);
 }
 
 int sdpa_dev_shard_partial_bf16(const void *Qb, int ldq, const void *Kb, int ldk, const void *Vt,
@@ -792,13 +787,9 @@ int sdpa_dev_shard_partial_bf16(const void *Qb, int ldq, const void *Kb, int ldk
     a.contrib = contrib; a.ldo = ldo; a.lmax = lmax; a.lsum = lsum;
     a.m = m; a.n_local = n_local; a.dk = dk; a.dv = dv;
     a.kv_splits = sdpa::pick_kv_splits_bf16(m, n_local, dk, dv);
-    if (a.kv_splits > 1) {
-        if (!workspace || workspace_bytes < sdpa_dev_workspace_bytes_bf16(m, n_local, dk, dv)) return SDPA_EINVAL;
-        a.ws_ld = round4(dv);
-        a.ws_contrib = (float *)workspace;
-        a.ws_lmax = a.ws_contrib + (size_t)a.kv_splits * m * a.ws_ld;
-        a.ws_lsum = a.ws_lmax + (size_t)a.kv_splits * m;
-    }
+    const size_t need = sdpa::bf16_workspace_bytes(m, n_local, dk, dv);
+    if (need && (!workspace || workspace_bytes < need)) return SDPA_EINVAL;
+    sdpa::bf16_carve_workspace(a, workspace, round4(dv));
     HIP_TRY(sdpa::launch_shard_partial_bf16(a, (hipStream_t)stream));
     return SDPA_OK;
 }

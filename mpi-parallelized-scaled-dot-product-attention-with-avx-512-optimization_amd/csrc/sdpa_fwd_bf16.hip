@@ -16,6 +16,9 @@
 //     of half-wave hi uses key rows 16s + {4hi..4hi+3, 8+4hi..8+4hi+3}, which are exactly the
 //     rows accumulator registers 8s..8s+7 of that lane hold -- P goes from the softmax
 //     registers into the B operand with a bf16 pack only.
+//   * so that those eight keys are 16 CONTIGUOUS bytes of a Vt row, the image stores key j of a
+//     row at position kvpos(j) = j with bits 2 and 3 swapped (each 16-key group is laid out
+//     0-3, 8-11, 4-7, 12-15).  The convert kernel writes it that way; bf16_kvpos() is the map.
 //   * d = 512 does not fit one wave's registers as a 32x512 fp32 O tile next to a 32x512 Q
 //     fragment twice over, so dv is processed in chunks of <= 256 columns by separate
 //     workgroups (blockIdx carries the chunk); the score tile is recomputed per chunk.
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
         }
 
         // ---- O^T += Vt_tile . P^T
-        const unsigned short *vt = Vs + cur * VTILE + li * VLD + 4 * hi;
+        const unsigned short *vt = Vs + cur * VTILE + li * VLD + 8 * hi;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
                     vf = qf[(tt + h) % NKS];
                 } else {
                     const u32x2 lo = *reinterpret_cast<const u32x2 *>(vp);        // keys 16h+4hi .. +3
-                    const u32x2 up = *reinterpret_cast<const u32x2 *>(vp + 8);    // keys 16h+8+4hi .. +3
+                    const u32x2 up = *reinterpret_cast<const u32x2 *>(vp + 4);    // keys 16h+8+4hi .. +3
                     vf = u32x4{lo.x, lo.y, up.x, up.y};
                 }
                 oacc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
@@ -360,6 +363,8 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
     const int split = work / n_chunks;
     const int qrow = qblock * kQRowsPerBlock + wave * 32 + li;
     const int dv0 = chunk * DVC;
+    // second pass behind the wide kernel: only the blocks it flagged
+    if (a.redo != nullptr && a.redo[split * n_qblocks + qblock] == 0) return;
 
     const int kv_begin = split * kv_per_split;
     const int kv_end = min(a.n_local, kv_begin + kv_per_split);
@@ -566,7 +571,7 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
 
         // [B] O^T += Vt(t).P(t)^T on the matrix pipe  ||  row max of S^T(t+1), Vt(t+1) -> LDS
         if constexpr (HAS_NEXT) mask_ragged(sm, t + 1);
-        const unsigned short *vt = Vs + vbuf * VTILE + li * VLD + 4 * hi;
+        const unsigned short *vt = Vs + vbuf * VTILE + li * VLD + 8 * hi;
         float tmax = -INFINITY;
         constexpr int SLOTS = 2 * NT;                     // P.V MFMAs of this step
         constexpr int VD = (DK + 2 * DVC > 512) ? SDPA_BF16_VD1 : 2;   // V fragment prefetch depth
@@ -575,7 +580,7 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
             if constexpr (ABL & 2) return qf[(tt + h) % NKS];
             const unsigned short *vp = vt + (32 * tt) * VLD + 16 * h;
             const u32x2 lo = *reinterpret_cast<const u32x2 *>(vp);        // keys 16h+4hi .. +3
-            const u32x2 up = *reinterpret_cast<const u32x2 *>(vp + 8);    // keys 16h+8+4hi .. +3
+            const u32x2 up = *reinterpret_cast<const u32x2 *>(vp + 4);    // keys 16h+8+4hi .. +3
             return u32x4{lo.x, lo.y, up.x, up.y};
         };
         u32x4 vq[VD];
@@ -675,6 +680,356 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
 }
 
 // ---------------------------------------------------------------------------
+// Wide variant (dv > 256): one wave per SIMD, the wave's whole 32 x 512 fp32 O^T tile in the
+// accumulator file (all 256 AGPRs), so dv up to 512 is ONE chunk and S^T is computed once.
+//   * the 512-register mode of hipcc puts every MFMA-builtin result in AGPRs; with O filling them
+//     the score tiles must be VGPR values, so the QK^T chain is issued as inline-asm MFMAs with
+//     VGPR C/D operands (first link with the inline constant 0 as C).  The compiler does not see
+//     an MFMA in an asm statement and inserts no MFMA->VALU wait states for it: every first
+//     VALU read of a score tile is placed at least two independent MFMAs (16 issue slots) after
+//     the last link, or behind an explicit s_nop pair (prologue, ragged mask).
+//   * K and Vt tiles both arrive by LDS-DMA, double-buffered, one barrier per tile; no staging
+//     registers.  Vt rows are 64 bytes per tile (32 keys); 16-byte chunk c of dv row r sits at
+//     position c ^ ((r >> 2) & 3), which makes the P.V operand read -- one ds_read_b128 per lane
+//     per MFMA thanks to the kvpos() key order -- conflict-free across each 16-lane group.
+//   * per step and wave: 2 x NKS.. MFMAs (32 + 32 at d = 512) against ~75 VALU instructions.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void mfma_bf16_vgpr_first(f32x16 &d, const u32x4 &x, const u32x4 &y) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(x), "v"(y));
+}
+__device__ __forceinline__ void mfma_bf16_vgpr(f32x16 &d, const u32x4 &x, const u32x4 &y) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(x), "v"(y));
+}
+// 16 wait states: covers an 8-pass MFMA's result latency before a VALU read (needs 11)
+__device__ __forceinline__ void mfma_result_fence(f32x16 &d) {
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(d));
+}
+// max over the two half-waves without LDS: v_permlane32_swap exchanges lanes 32..63 of the first
+// operand with lanes 0..31 of the second
+__device__ __forceinline__ float halfwave_max(float x) {
+    float lo = x, up = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(up));
+    return fmaxf(lo, up);
+}
+
+template <int DK, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
+    Bf16Args a, int kv_per_split, int n_qblocks, int n_chunks, float scale) {
+    constexpr int DVC = 512;
+    constexpr int NKS = DK / 16;               // QK^T k-steps = MFMAs per score tile
+    constexpr int NT = DVC / 32;               // 32-row blocks of O^T
+    constexpr int KCH = DK / 8;                // 16-byte chunks per K row
+    constexpr int KTILE = kKvTile * DK;        // bf16 elements, unpadded (swizzled)
+    constexpr int VTILE = DVC * kKvTile;       // bf16 elements: 64-byte rows, swizzled
+    constexpr int KPW = (kKvTile * KCH / 64) / 4;   // 1-KiB DMA pieces per wave per K tile
+    constexpr int RPP = 64 / KCH > 0 ? 64 / KCH : 1; // K rows per DMA piece
+    constexpr int VPW = (DVC * 4 / 64) / 4;         // 1-KiB DMA pieces per wave per Vt tile (16 rows each)
+    constexpr int SWZ = KCH >= 16 ? 15 : KCH - 1;
+    static_assert(KCH >= 8 && KPW >= 1, "DK must be 64..512");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+    unsigned short *const Ks = smem16;                    // [2][KTILE]
+    unsigned short *const Vs = smem16 + 2 * KTILE;        // [2][VTILE]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31;
+    const int hi = lane >> 5;
+
+    int work = xcd_remap_b(blockIdx.x, gridDim.x);
+    const int qblock = work % n_qblocks;
+    work /= n_qblocks;
+    const int chunk = work % n_chunks;
+    const int split = work / n_chunks;
+    const int qrow = qblock * kQRowsPerBlock + wave * 32 + li;
+    const int dv0 = chunk * DVC;
+
+    const int kv_begin = split * kv_per_split;
+    const int kv_end = min(a.n_local, kv_begin + kv_per_split);
+    const int T = kv_end > kv_begin ? (kv_end - kv_begin + kKvTile - 1) / kKvTile : 0;
+    const float c = scale * 1.44269504088896340736f;
+
+    u32x4 qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        if (qrow < a.m)
+            qf[ks] = *reinterpret_cast<const u32x4 *>(a.Q + (size_t)qrow * DK + 16 * ks + 8 * hi);
+        else
+            qf[ks] = u32x4{0u, 0u, 0u, 0u};
+    }
+
+    f32x16 oacc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+    auto pin_o = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) asm volatile("" : "+a"(oacc[tt]));
+    };
+    pin_o();
+    constexpr float kDeferLog2 = 32.0f;                   // P <= 2^32; beyond that the block is redone
+    float m_ref = 0.f, max_rel = 0.f, l_run = 0.f;       // exp2 domain, see the fp32 kernel
+
+    // ---- K and Vt staging by LDS-DMA
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane(
+        (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)smem16);
+    auto dma_piece = [&](const char *gbase, unsigned lane_off, unsigned lds_byte) __attribute__((always_inline)) {
+        if constexpr (ABL & 1) return;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %2\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %3\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(lane_off), "s"(lds_byte), "s"(gbase)
+                     : "memory");
+    };
+    // K tile: piece p (1 KiB of LDS) = RPP rows; lane -> row p*RPP + lane/KCH, LDS chunk position
+    // lane%KCH, which holds global chunk (lane%KCH) ^ (row & SWZ).  Only the per-lane part of the
+    // address lives in a register: the piece's row base goes into the scalar base pointer and the
+    // row-dependent swizzle bits are XORed in at issue (wave-uniform, one VALU op).
+    const unsigned klane = (unsigned)((lane / KCH) * DK * 2 + (((lane % KCH) ^ ((lane / KCH) & SWZ)) << 4));
+    auto dma_k = [&](int tile, int buf) __attribute__((always_inline)) {
+        const int base = kv_begin + tile * kKvTile;
+        const int last = kv_end - 1 - base;
+        const char *kb = reinterpret_cast<const char *>(a.K + (size_t)base * DK);
+        if (last >= kKvTile - 1) {
+#pragma unroll
+            for (int j = 0; j < KPW; ++j) {
+                const int row0 = (wave * KPW + j) * RPP;             // wave-uniform, a multiple of RPP:
+                const unsigned swz = (unsigned)((row0 & SWZ) << 4);   // (row0 + x) & SWZ == (row0 & SWZ) ^ x
+                dma_piece(kb + (size_t)row0 * (DK * 2), klane ^ swz,
+                          lds_base + (unsigned)(buf * KTILE * 2 + (wave * KPW + j) * 1024));
+            }
+        } else {
+            // rows past the shard's end re-read its last row (finite data; their scores are masked)
+#pragma unroll
+            for (int j = 0; j < KPW; ++j) {
+                const int row0 = (wave * KPW + j) * RPP;
+                const unsigned swz = (unsigned)((row0 & SWZ) << 4);
+                const unsigned row = (unsigned)min(row0 + (int)(lane / KCH), last);
+                dma_piece(kb, row * (DK * 2) + ((klane ^ swz) % (DK * 2)),
+                          lds_base + (unsigned)(buf * KTILE * 2 + (wave * KPW + j) * 1024));
+            }
+        }
+    };
+    // Vt tile: piece p = 16 dv rows x 64 bytes; lane -> row p*16 + lane/4, LDS chunk position
+    // lane%4, which holds global chunk (lane%4) ^ ((row >> 2) & 3) = (lane%4) ^ ((lane >> 4) & 3).
+    // Rows past dv and keys past n_local are zero in the image, so no clamps.
+    const unsigned vlane = (unsigned)((size_t)(lane >> 2) * a.ldvt * 2u) + (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+    auto dma_v = [&](int tile, int buf) __attribute__((always_inline)) {
+        const char *vb = reinterpret_cast<const char *>(a.Vt + kv_begin + tile * kKvTile);
+#pragma unroll
+        for (int j = 0; j < VPW; ++j)
+            dma_piece(vb + (size_t)(dv0 + (wave * VPW + j) * 16) * a.ldvt * 2u, vlane,
+                      lds_base + (unsigned)(2 * KTILE * 2 + buf * VTILE * 2 + (wave * VPW + j) * 1024));
+    };
+    auto stage_fence = [&]() __attribute__((always_inline)) {
+        if constexpr (ABL & 8) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+    // K fragment byte addresses inside a K buffer (chunk 2ks+hi of row li, un-swizzled)
+    constexpr int NKA = NKS < 8 ? NKS : 8;
+    unsigned kaddr[NKA];
+#pragma unroll
+    for (int u = 0; u < NKA; ++u) kaddr[u] = (unsigned)(li * DK * 2 + (((2 * u + hi) ^ (li & SWZ)) << 4));
+    auto kfrag = [&](int buf, int ks) __attribute__((always_inline)) -> u32x4 {
+        if constexpr (ABL & 2) return qf[(ks + 1) % NKS];
+        return *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(Ks + buf * KTILE) +
+                                                kaddr[ks % NKA] + (ks / NKA) * 256);
+    };
+    // Vt fragment: keys 16h + {4hi..+3, 8+4hi..+3} of dv row 32tt + li = chunk 2h+hi of that row
+    unsigned vaddr[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) vaddr[h] = (unsigned)(li * 64 + (((2 * h + hi) ^ ((li >> 2) & 3)) << 4));
+    auto vfrag = [&](int buf, int slot) __attribute__((always_inline)) -> u32x4 {
+        const int h = slot / NT, tt = slot % NT;
+        if constexpr (ABL & 2) return qf[(tt + h) % NKS];
+        return *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(Vs + buf * VTILE) +
+                                                vaddr[h] + tt * 2048);
+    };
+    // the caller guarantees the MFMA chain that wrote sx has retired (mfma_result_fence / slots)
+    auto mask_ragged = [&](f32x16 &sx, int tile) __attribute__((always_inline)) {
+        const int valid = kv_end - (kv_begin + tile * kKvTile);
+        if (valid < kKvTile) {
+            mfma_result_fence(sx);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (crow16(r, hi) >= valid) sx[r] = -INFINITY;
+        }
+    };
+    constexpr int PPK = NKS >= 16 ? 1 : 16 / NKS;        // P values started per QK^T MFMA slot
+    constexpr int KPP = NKS >= 16 ? NKS / 16 : 1;        // QK^T MFMAs per P value
+
+    // returns true (wave-uniform) when the tile scored in this step does not fit the reference exponent
+    // `fenced`: put the explicit MFMA-result fence behind the score chain.  The steady-state loop
+    // does not need it (reads are placed >= 11 issue slots later and hipcc leaves that code
+    // alone); the tail steps do, because hipcc spills around them and may touch the tile at once.
+    auto step = [&](auto has_next, auto fenced, f32x16 &su, f32x16 &sm, int t) __attribute__((always_inline)) -> bool {
+        constexpr bool HAS_NEXT = decltype(has_next)::value;
+        constexpr bool FENCED = decltype(fenced)::value;
+        const int vbuf = t & 1, kbuf = (t + 1) & 1;
+        if (t + 2 < T) dma_k(t + 2, t & 1);
+        if (t + 1 < T) dma_v(t + 1, (t + 1) & 1);
+        u32x4 pb[2];
+        unsigned pw[8];
+        // exp of element r is issued one slot before its sum/pack, so the transcendental's
+        // latency is never waited on
+        auto p_exp = [&](int r) __attribute__((always_inline)) {
+            su[r] = bpin_exp2(fmaf(su[r], c, -m_ref));
+        };
+        auto p_acc = [&](int r) __attribute__((always_inline)) {
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(l_run) : "v"(su[r]));   // pinned: hipcc sinks 32 adds into one chain
+            if (r & 1) pw[r >> 1] = bpin_pack(su[r - 1], su[r]);
+        };
+
+        if constexpr (HAS_NEXT) {
+            // [A] S^T(t+1) on the matrix pipe (VGPR chain)  ||  P(t) on the VALU
+            constexpr int KD = NKS < 6 ? NKS : 3;
+            u32x4 kq[KD];
+#pragma unroll
+            for (int i = 0; i < KD; ++i) kq[i] = kfrag(kbuf, i);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const u32x4 kf = kq[ks % KD];
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks == 0) mfma_bf16_vgpr_first(sm, kf, qf[0]);
+                else mfma_bf16_vgpr(sm, kf, qf[ks]);
+                if (ks + KD < NKS) kq[ks % KD] = kfrag(kbuf, ks + KD);
+                if (ks % KPP == 0) {
+#pragma unroll
+                    for (int r = (ks / KPP) * PPK; r < (ks / KPP) * PPK + PPK; ++r) {
+                        p_exp(r);
+                        if (r > 0) p_acc(r - 1);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (FENCED) mfma_result_fence(sm);
+            p_acc(15);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                p_exp(r);
+                if (r > 0) p_acc(r - 1);
+            }
+            p_acc(15);
+        }
+        pb[0] = u32x4{pw[0], pw[1], pw[2], pw[3]};
+        pb[1] = u32x4{pw[4], pw[5], pw[6], pw[7]};
+
+        // [B] O^T += Vt(t).P(t)^T on the matrix pipe  ||  row max of S^T(t+1)
+        if constexpr (HAS_NEXT) mask_ragged(sm, t + 1);
+        float tmax = -INFINITY;
+        constexpr int SLOTS = 2 * NT;                     // P.V MFMAs of this step
+        constexpr int VD = 2;                              // V fragment prefetch depth
+        u32x4 vq[VD];
+#pragma unroll
+        for (int i = 0; i < VD; ++i) vq[i] = vfrag(vbuf, i);
+#pragma unroll
+        for (int slot = 0; slot < SLOTS; ++slot) {
+            const int tt = slot % NT, h = slot / NT;
+            const u32x4 vf = vq[slot % VD];
+            __builtin_amdgcn_sched_barrier(0);
+            oacc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
+                                                               __builtin_bit_cast(bf16x8, pb[h]),
+                                                               oacc[tt], 0, 0, 0);
+            if (slot + VD < SLOTS) vq[slot % VD] = vfrag(vbuf, slot + VD);
+            if constexpr (HAS_NEXT) {
+                // first read of the score tile: four MFMAs + four LDS reads (>= 11 issue slots,
+                // the MFMA->VALU requirement for an 8-pass MFMA) behind the chain's last link
+                if (slot >= 4 && slot < 12) tmax = bpin_max3(tmax, sm[2 * (slot - 4)], sm[2 * (slot - 4) + 1]);
+                if (slot == 14) tmax = halfwave_max(fmaf(tmax, c, -m_ref));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        pin_o();
+        bool pending = false;
+        if constexpr (HAS_NEXT) {
+            pending = __any(tmax > kDeferLog2);
+            max_rel = fmaxf(max_rel, tmax);
+        }
+        stage_fence();
+        return pending;
+    };
+
+    f32x16 sA, sB;
+    if (T > 0) {
+        dma_k(0, 0);
+        dma_v(0, 0);
+        if (T > 1) dma_k(1, 1);
+        stage_fence();
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const u32x4 kf = kfrag(0, ks);
+            if (ks == 0) mfma_bf16_vgpr_first(sA, kf, qf[0]);
+            else mfma_bf16_vgpr(sA, kf, qf[ks]);
+        }
+        mfma_result_fence(sA);
+        mask_ragged(sA, 0);
+        float tmax = sA[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sA[r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        m_ref = tmax * c;                               // finite: every tile has a valid key row
+        __syncthreads();                                // K(0) fully consumed before K(2) lands on it
+
+        // Steady state.  A tile whose row max exceeds the reference exponent by more than
+        // 2^kDeferLog2 would need the accumulators rescaled -- and ANY VALU access to the 256
+        // AGPR-resident O values in or around this loop (even on a never-taken branch, even an
+        // early exit) makes hipcc copy and spill accumulator tiles on the hot path.  So this
+        // kernel has no rescale at all: the wave only records that its (q block, split) does not
+        // fit, carries on (its numbers are then meaningless), and the launcher runs the general
+        // kernel right behind this one over the flagged blocks, which rewrites their rows.
+        int t = 0;
+        bool redo = false;
+        for (; t + 2 < T; t += 2) {
+            redo |= step(std::true_type(), std::false_type(), sA, sB, t);
+            redo |= step(std::true_type(), std::false_type(), sB, sA, t + 1);
+        }
+        if (T - t == 2) {
+            redo |= step(std::true_type(), std::true_type(), sA, sB, t);
+            step(std::false_type(), std::true_type(), sB, sA, t + 1);
+        } else {
+            step(std::false_type(), std::true_type(), sA, sB, t);
+        }
+        if (redo && lane == 0) a.redo[split * n_qblocks + qblock] = 1;
+    }
+
+    // ---- epilogue: fold the true row max back in, write this chunk's columns
+    const float fold = __builtin_amdgcn_exp2f(-max_rel);
+    const float l_tot = (l_run + __shfl_xor(l_run, 32)) * fold;
+    float *out = a.contrib;
+    float *omax = a.lmax, *osum = a.lsum;
+    int ldo = a.ldo;
+    if (a.kv_splits > 1) {
+        ldo = a.ws_ld;
+        out = a.ws_contrib + (size_t)split * a.m * ldo;
+        omax = a.ws_lmax + (size_t)split * a.m;
+        osum = a.ws_lsum + (size_t)split * a.m;
+    }
+    if (qrow < a.m) {
+        float *orow = out + (size_t)qrow * ldo + dv0;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int col = 32 * tt + crow16(r, hi);
+                if (dv0 + col < a.dv) orow[col] = oacc[tt][r] * fold;
+            }
+        if (hi == 0 && chunk == 0) {
+            omax[qrow] = T > 0 ? (m_ref + max_rel) * 0.69314718055994530942f : -INFINITY;
+            osum[qrow] = l_tot;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // converts: fp64 -> bf16 (RNE), row-major with zero-padded columns, and the transposed V image
 // ---------------------------------------------------------------------------
 __global__ void cvt_d2bf_kernel(const double *__restrict__ src, unsigned short *__restrict__ dst,
@@ -688,8 +1043,9 @@ __global__ void cvt_d2bf_kernel(const double *__restrict__ src, unsigned short *
     }
 }
 
-// dst[cidx * ldt + r] = bf16(src[r * cols + cidx]) for r < rows, 0 for rows <= r < ldt; rows of
-// dst beyond `cols` (up to cols_pad) are zero.  32x32 tiles through LDS so both sides coalesce.
+// dst[cidx * ldt + kvpos(r)] = bf16(src[r * cols + cidx]) for r < rows, 0 for rows <= r < ldt;
+// rows of dst beyond `cols` (up to cols_pad) are zero.  32x32 tiles through LDS so both sides
+// coalesce (kvpos permutes inside 16-element groups, ldt is a multiple of 32).
 __global__ void cvt_d2bf_t_kernel(const double *__restrict__ src, unsigned short *__restrict__ dst,
                                   long rows, int cols, int cols_pad, long ldt) {
     __shared__ unsigned short tile[32][33];
@@ -706,7 +1062,7 @@ __global__ void cvt_d2bf_t_kernel(const double *__restrict__ src, unsigned short
     for (int k = ty; k < 32; k += 8) {
         const int cc = c0 + k;
         const long r = r0 + tx;
-        if (cc < cols_pad && r < ldt) dst[(size_t)cc * ldt + r] = tile[tx][k];
+        if (cc < cols_pad && r < ldt) dst[(size_t)cc * ldt + r0 + bf16_kvpos(tx)] = tile[tx][k];
     }
 }
 
@@ -714,9 +1070,31 @@ __global__ void cvt_d2bf_t_kernel(const double *__restrict__ src, unsigned short
 // host-side launch logic
 // ---------------------------------------------------------------------------
 int bf16_pad_dk(int dk) { return dk <= 64 ? 64 : dk <= 128 ? 128 : dk <= 256 ? 256 : 512; }
-int bf16_chunk_dv(int dv) { return dv <= 64 ? 64 : dv <= 128 ? 128 : 256; }
+int bf16_chunk_dv(int dv) { return dv <= 64 ? 64 : dv <= 128 ? 128 : dv <= 256 ? 256 : 512; }
 int bf16_pad_dv(int dv) { const int ch = bf16_chunk_dv(dv); return (dv + ch - 1) / ch * ch; }
 long bf16_pad_n(long n) { return (n + 31) / 32 * 32; }
+
+// workspace: [kv_splits x m x ws_ld] contrib, [kv_splits x m] lmax, [kv_splits x m] lsum when the
+// shard is split, then (dv > 256) one redo flag per (split, q block) for the wide kernel
+size_t bf16_workspace_bytes(int m, int n_local, int dk, int dv) {
+    if (m <= 0) return 0;
+    const int s = pick_kv_splits_bf16(m, n_local, dk, dv);
+    const int ws_ld = (dv + 3) / 4 * 4;
+    size_t bytes = s <= 1 ? 0 : (size_t)s * m * ((size_t)ws_ld + 2) * sizeof(float);
+    if (bf16_chunk_dv(dv) == 512) bytes += (size_t)((m + kQRowsPerBlock - 1) / kQRowsPerBlock) * s * sizeof(int);
+    return bytes;
+}
+void bf16_carve_workspace(Bf16Args &a, void *ws, int ws_ld) {
+    char *p = static_cast<char *>(ws);
+    if (a.kv_splits > 1) {
+        a.ws_ld = ws_ld;
+        a.ws_contrib = reinterpret_cast<float *>(p);
+        a.ws_lmax = a.ws_contrib + (size_t)a.kv_splits * a.m * a.ws_ld;
+        a.ws_lsum = a.ws_lmax + (size_t)a.kv_splits * a.m;
+        p = reinterpret_cast<char *>(a.ws_lsum + (size_t)a.kv_splits * a.m);
+    }
+    a.redo = bf16_chunk_dv(a.dv) == 512 ? reinterpret_cast<int *>(p) : nullptr;
+}
 
 int pick_kv_splits_bf16(int m, int n_local, int dk, int dv) {
     if (m <= 0 || n_local <= 0) return 1;
@@ -752,6 +1130,29 @@ static hipError_t launch_bf16_pipe(const Bf16Args &a, hipStream_t s) {
     const float scale = 1.0f / sqrtf((float)a.dk);   // attention-mpi.c:208
     hipLaunchKernelGGL((fused_bf16_pipe_kernel<DK, DVC, ABL>), dim3(nqb * chunks * a.kv_splits), dim3(256), lds,
                        s, a, kv_per_split, nqb, chunks, scale);
+    return hipGetLastError();
+}
+
+template <int DK, int ABL = 0>
+static hipError_t launch_bf16_wide(const Bf16Args &a, hipStream_t s) {
+    const int nqb = (a.m + kQRowsPerBlock - 1) / kQRowsPerBlock;
+    const int chunks = bf16_pad_dv(a.dv) / 512;
+    const int ntiles = (a.n_local + kKvTile - 1) / kKvTile;
+    const int tiles_per_split = (ntiles + a.kv_splits - 1) / a.kv_splits;
+    const int kv_per_split = tiles_per_split > 0 ? tiles_per_split * kKvTile : kKvTile;
+    const size_t lds = (size_t)2 * (kKvTile * DK + 512 * kKvTile) * sizeof(unsigned short);
+    static bool attr_done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_bf16_wide_kernel<DK, ABL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done[dev] = true;
+    }
+    const float scale = 1.0f / sqrtf((float)a.dk);   // attention-mpi.c:208
+    hipLaunchKernelGGL((fused_bf16_wide_kernel<DK, ABL>), dim3(nqb * chunks * a.kv_splits), dim3(256), lds, s,
+                       a, kv_per_split, nqb, chunks, scale);
     return hipGetLastError();
 }
 
@@ -799,6 +1200,39 @@ hipError_t launch_shard_partial_bf16(const Bf16Args &a, hipStream_t s) {
             case 4: return launch_bf16<512, 256, 4>(a, s);
             case 6: return launch_bf16<512, 256, 6>(a, s);
             default: return launch_bf16<512, 256, 7>(a, s);
+        }
+    }
+    // every byte offset inside the Vt image is carried in 32 bits by the staging code
+    if ((size_t)bf16_pad_dv(a.dv) * (size_t)a.ldvt * 2u > 0xffffffffull) return hipErrorInvalidValue;
+    if (vc == 512) {
+        if ((reinterpret_cast<uintptr_t>(a.K) & 15) || (reinterpret_cast<uintptr_t>(a.Vt) & 15) || !a.redo)
+            return hipErrorInvalidValue;
+        const int nqb = (a.m + kQRowsPerBlock - 1) / kQRowsPerBlock;
+        e = hipMemsetAsync(a.redo, 0, (size_t)nqb * a.kv_splits * sizeof(int), s);
+        if (e != hipSuccess) return e;
+        if (kp == 512 && ((tune >> 8) & 15)) {                // timing-only ablations
+            switch ((tune >> 8) & 15) {
+                case 1: e = launch_bf16_wide<512, 1>(a, s); break;    // no DMA
+                case 2: e = launch_bf16_wide<512, 2>(a, s); break;    // no LDS fragment reads
+                case 8: e = launch_bf16_wide<512, 8>(a, s); break;    // no barrier (racy)
+                case 9: e = launch_bf16_wide<512, 9>(a, s); break;
+                default: e = launch_bf16_wide<512, 11>(a, s); break;  // MFMA + softmax only
+            }
+        } else {
+            switch (kp) {
+                case 64: e = launch_bf16_wide<64>(a, s); break;
+                case 128: e = launch_bf16_wide<128>(a, s); break;
+                case 256: e = launch_bf16_wide<256>(a, s); break;
+                default: e = launch_bf16_wide<512>(a, s); break;
+            }
+        }
+        if (e != hipSuccess) return e;
+        // general kernel (256-column chunks, in-loop rescale) over the blocks the wide one flagged
+        switch (kp) {
+            case 64: e = launch_bf16_pipe<64, 256>(a, s); break;
+            case 128: e = launch_bf16_pipe<128, 256>(a, s); break;
+            case 256: e = launch_bf16_pipe<256, 256>(a, s); break;
+            default: e = launch_bf16_pipe<512, 256>(a, s); break;
         }
     }
     const bool pipe = !(tune & 4) && (reinterpret_cast<uintptr_t>(a.K) & 15) == 0;   // $SDPA_TUNE&4: old kernel

@@ -29,7 +29,8 @@ struct PartialArgs {
 };
 
 // bf16 variant: Q,K row-major bf16 (ld = dk padded to 64/128/256/512, pad columns zero),
-// Vt = V transposed, bf16 [dv_pad x ldvt] (ldvt = n_local padded to 32, pads zero).
+// Vt = V transposed, bf16 [dv_pad x ldvt] (ldvt = n_local padded to 32, pads zero), key j of a
+// row stored at bf16_kvpos(j).
 struct Bf16Args {
     const unsigned short *Q;  int ldq;
     const unsigned short *K;  int ldk;
@@ -42,13 +43,21 @@ struct Bf16Args {
     float *ws_contrib;  int ws_ld;
     float *ws_lmax;
     float *ws_lsum;
+    int *redo;                     // [kv_splits x q blocks] flags, dv > 256 only (bf16_carve_workspace)
 };
 
 int  bf16_pad_dk(int dk);
 int  bf16_chunk_dv(int dv);
 int  bf16_pad_dv(int dv);
 long bf16_pad_n(long n);
+// position of key j inside a Vt row: bits 2 and 3 of j swapped (an involution) -- each 16-key
+// group is stored 0-3, 8-11, 4-7, 12-15 so one MFMA lane's eight keys are 16 contiguous bytes
+__host__ __device__ inline constexpr long bf16_kvpos(long j) {
+    return (j & ~12L) | ((j & 4) << 1) | ((j & 8) >> 1);
+}
 int  pick_kv_splits_bf16(int m, int n_local, int dk, int dv);
+size_t bf16_workspace_bytes(int m, int n_local, int dk, int dv);
+void bf16_carve_workspace(Bf16Args &a, void *ws, int ws_ld);   // needs a.m, a.dv, a.kv_splits
 hipError_t launch_shard_partial_bf16(const Bf16Args &a, hipStream_t s);
 hipError_t launch_cvt_d2bf(const double *src, unsigned short *dst, long rows, int cols, int ld, hipStream_t s);
 hipError_t launch_cvt_d2bf_t(const double *src, unsigned short *dst, long rows, int cols, int cols_pad,

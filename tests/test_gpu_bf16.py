@@ -45,10 +45,18 @@ def test_bf16_converts(be, pkg):
     v = torch.randn(100, 40, dtype=torch.float64, device="cuda")
     vt = be.cvt_d2bf_t(v)
     assert vt.shape == (64, 128)
-    assert torch.equal(vt[:40, :100], v.to(torch.float32).to(torch.bfloat16).t())
-    assert torch.all(vt[40:] == 0) and torch.all(vt[:, 100:] == 0)
+    # key j of a row sits at kvpos(j): bits 2 and 3 of j swapped (include/sdpa_hip.h)
+    pos = torch.tensor([be.lib.sdpa_dev_bf16_kvpos(j) for j in range(128)], device="cuda")
+    assert sorted(pos.tolist()) == list(range(128))
+    assert pos[:16].tolist() == [0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15]
+    want = torch.zeros(64, 128, dtype=torch.bfloat16, device="cuda")
+    want[:40, pos[:100]] = v.to(torch.float32).to(torch.bfloat16).t()
+    assert torch.equal(vt, want)
     big = torch.randn(4096, 512, dtype=torch.float64, device="cuda")
-    assert torch.equal(be.cvt_d2bf_t(big), big.to(torch.float32).to(torch.bfloat16).t().contiguous())
+    bpos = torch.tensor([be.lib.sdpa_dev_bf16_kvpos(j) for j in range(4096)], device="cuda")
+    bwant = torch.empty(512, 4096, dtype=torch.bfloat16, device="cuda")
+    bwant[:, bpos] = big.to(torch.float32).to(torch.bfloat16).t()
+    assert torch.equal(be.cvt_d2bf_t(big), bwant)
 
 
 SHAPES = [
@@ -65,7 +73,13 @@ SHAPES = [
     (48,  300,  512, 512, "D1"),      # BASELINE config 5 dims: two dv chunks of 256
     (40,  200,  100, 200, "D2"),      # dv padded to 256, dk to 128
     (32,   96,  512,  64, "D1"),
-    (129, 700,  300, 700, "D1"),      # dk -> 512, dv -> 3 chunks
+    (129, 700,  300, 700, "D1"),      # dk -> 512, dv -> 2 wide chunks of 512
+    (96,  1000,  64, 300, "D4"),      # wide kernel (dv > 256), dk padded to 64, late spike key
+    (64,  2048, 128, 512, "D3"),      # wide, dk 128, peaky
+    (70,  333,  256, 384, "D2"),      # wide, dk 256, ragged last tile
+    (300, 4096, 512, 512, "D2"),      # wide with in-GPU K/V splits
+    (200,   5,  512, 512, "D2"),      # wide, n < tile
+    (33,   64,  400, 257, "D1"),      # wide, both dims padded
 ]
 
 
@@ -78,6 +92,34 @@ def test_bf16_shapes(m, n, dk, dv, dist, pkg, be, orc, O):
     assert np.abs(got - want).max() <= bf16_tol(V)
     same_inputs = orc.attention_f64(to_bf16_f64(Q), to_bf16_f64(K), to_bf16_f64(V))
     assert np.abs(got - same_inputs).max() <= 4e-3 * max(1.0, np.abs(V).max())
+
+
+def test_bf16_wide_steep_scores_take_the_redo_pass(pkg, be, O):
+    """dv > 256 runs the wide kernel, which has no accumulator rescale: a q block whose row max
+    climbs more than 2^32 above its first tile's is flagged and redone by the general kernel.
+    Block 0 (rows 0..127) climbs 0.5 nat per key, block 1 has flat scores and must stay on the
+    wide kernel's own result."""
+    m, n, d = 256, 1024, 512
+    rng = np.random.default_rng(11)
+    Q = np.zeros((m, d)); K = np.zeros((n, d))
+    Q[:128, 0] = np.sqrt(d)                       # score_j = K[j, 0]
+    K[:, 0] = 0.5 * np.arange(n)                  # exact in bf16 up to 128, rounded above: same inputs both sides
+    K[:, 1:] = rng.standard_normal((n, d - 1)) * 0.1
+    V = rng.standard_normal((n, d))
+    got = dev_attention_bf16(pkg, be, Q, K, V)
+    want = O.numpy_attention_f64(to_bf16_f64(Q), to_bf16_f64(K), to_bf16_f64(V))
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= 4e-3 * max(1.0, np.abs(V).max())
+    # flat block: plain mean of V
+    assert np.abs(got[128:] - to_bf16_f64(V).mean(axis=0)).max() <= 4e-3 * max(1.0, np.abs(V).max())
+    # with K/V splits on top (few q blocks, long n)
+    n2 = 8192
+    K2 = np.zeros((n2, d)); K2[:, 0] = 0.25 * np.arange(n2); K2[:, 1:] = rng.standard_normal((n2, d - 1)) * 0.1
+    V2 = rng.standard_normal((n2, d))
+    assert pkg.load().sdpa_dev_kv_splits_bf16(m, n2, d, d) > 1
+    got2 = dev_attention_bf16(pkg, be, Q, K2, V2)
+    want2 = O.numpy_attention_f64(to_bf16_f64(Q), to_bf16_f64(K2), to_bf16_f64(V2))
+    assert np.isfinite(got2).all() and np.abs(got2 - want2).max() <= 4e-3 * max(1.0, np.abs(V2).max())
 
 
 def test_bf16_kv_splits_and_triple(pkg, be, O):
