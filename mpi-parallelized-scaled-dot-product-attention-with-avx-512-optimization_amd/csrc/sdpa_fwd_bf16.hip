@@ -683,16 +683,29 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
 // Wide variant (dv > 256): one wave per SIMD, the wave's whole 32 x 512 fp32 O^T tile in the
 // accumulator file (all 256 AGPRs), so dv up to 512 is ONE chunk and S^T is computed once.
 //   * the 512-register mode of hipcc puts every MFMA-builtin result in AGPRs; with O filling them
-//     the score tiles must be VGPR values, so the QK^T chain is issued as inline-asm MFMAs with
+//     the score tile must be a VGPR value, so the QK^T chain is issued as inline-asm MFMAs with
 //     VGPR C/D operands (first link with the inline constant 0 as C).  The compiler does not see
-//     an MFMA in an asm statement and inserts no MFMA->VALU wait states for it: every first
-//     VALU read of a score tile is placed at least two independent MFMAs (16 issue slots) after
-//     the last link, or behind an explicit s_nop pair (prologue, ragged mask).
-//   * K and Vt tiles both arrive by LDS-DMA, double-buffered, one barrier per tile; no staging
-//     registers.  Vt rows are 64 bytes per tile (32 keys); 16-byte chunk c of dv row r sits at
-//     position c ^ ((r >> 2) & 3), which makes the P.V operand read -- one ds_read_b128 per lane
-//     per MFMA thanks to the kvpos() key order -- conflict-free across each 16-lane group.
-//   * per step and wave: 2 x NKS.. MFMAs (32 + 32 at d = 512) against ~75 VALU instructions.
+//     an MFMA in an asm statement and inserts no MFMA->VALU wait states for it: the first VALU
+//     read of the score tile is placed four MFMAs + four LDS reads (>= 11 issue slots) behind the
+//     last link, or behind an explicit s_nop pair (prologue, ragged mask, tail steps).
+//   * O is touched by nothing but MFMAs between the zero-fill and the epilogue.  Any VALU access
+//     to those 256 registers in or around the loop -- a rescale on a never-taken branch, an early
+//     exit -- makes hipcc copy and spill accumulator tiles on the hot path.  So the kernel has NO
+//     rescale: the reference exponent is fixed by the first tile, a wave whose later row max
+//     exceeds it by more than 2^32 flags its (q block, split), and the launcher runs the general
+//     kernel (256-column chunks, in-loop rescale) behind this one over the flagged blocks only.
+//   * K (three buffers) and Vt (two) arrive by LDS-DMA issued piece by piece between MFMAs, one
+//     barrier per tile in the middle of the step; no staging registers.  Vt rows are 64 bytes
+//     per tile (32 keys); 16-byte chunk c of dv row r sits at position c ^ ((r >> 2) & 3), which
+//     makes the P.V operand read -- one ds_read_b128 per lane per MFMA thanks to the kvpos() key
+//     order -- conflict-free across each 16-lane group.  160 KiB of LDS at dk = 512.
+//   * all softmax VALU work of tile t+1 runs under step t's P.V MFMAs (independent
+//     accumulators), never beside the dependent score chain; one score tile is live.
+//   * per step and wave at d = 512: 32 + 32 MFMAs, ~75 VALU instructions, 64 ds_read_b128,
+//     16 DMA pieces.  Measured (BASELINE config 5): 4.0 ms = 1.18 PFLOP/s; the MFMA skeleton alone
+//     (no LDS, no DMA, no VALU) takes 2.95 ms = 1.65 PFLOP/s, which is what this part sustains on
+//     v_mfma_f32_32x32x16_bf16 with toggling operands at all (tools/probes/mfma_probe.hip:
+//     2.2 PFLOP/s with constant operands, 1.66-1.80 with random ones -- power, not issue).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void mfma_bf16_vgpr_first(f32x16 &d, const u32x4 &x, const u32x4 &y) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(x), "v"(y));
@@ -712,6 +725,14 @@ __device__ __forceinline__ float halfwave_max(float x) {
     return fmaxf(lo, up);
 }
 
+// fragment prefetch depths (K ring under the score chain, Vt ring under the P.V MFMAs)
+#ifndef SDPA_WIDE_KD
+#define SDPA_WIDE_KD 3
+#endif
+#ifndef SDPA_WIDE_VD
+#define SDPA_WIDE_VD 2
+#endif
+
 template <int DK, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
     Bf16Args a, int kv_per_split, int n_qblocks, int n_chunks, float scale) {
@@ -728,8 +749,8 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
     static_assert(KCH >= 8 && KPW >= 1, "DK must be 64..512");
 
     extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
-    unsigned short *const Ks = smem16;                    // [2][KTILE]
-    unsigned short *const Vs = smem16 + 2 * KTILE;        // [2][VTILE]
+    unsigned short *const Ks = smem16;                    // [3][KTILE]
+    unsigned short *const Vs = smem16 + 3 * KTILE;        // [2][VTILE]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -775,16 +796,28 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
     // ---- K and Vt staging by LDS-DMA
     const unsigned lds_base = __builtin_amdgcn_readfirstlane(
         (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)smem16);
+    // M0 (the LDS destination of a DMA) is written without save/restore here: hipcc treats M0 as
+    // reserved and re-initialises it next to each of its own uses, and every instruction issued by
+    // the single wave of a SIMD counts in this kernel.  One independent instruction has to sit
+    // between the M0 write and the load that reads it (s_nop, or the address XOR below).
     auto dma_piece = [&](const char *gbase, unsigned lane_off, unsigned lds_byte) __attribute__((always_inline)) {
         if constexpr (ABL & 1) return;
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\t"
-                     "s_mov_b32 m0, %2\n\t"
+        asm volatile("s_mov_b32 m0, %1\n\t"
                      "s_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, %3\n\t"
-                     "s_mov_b32 m0, %0"
-                     : "=&s"(keep)
+                     "global_load_lds_dwordx4 %0, %2"
+                     :
                      : "v"(lane_off), "s"(lds_byte), "s"(gbase)
+                     : "memory");
+    };
+    // same, lane offset = lane_part ^ swz computed in the wait slot
+    auto dma_piece_xor = [&](const char *gbase, unsigned lane_part, unsigned swz, unsigned lds_byte) __attribute__((always_inline)) {
+        if constexpr (ABL & 1) return;
+        unsigned off;
+        asm volatile("s_mov_b32 m0, %2\n\t"
+                     "v_xor_b32 %0, %3, %1\n\t"
+                     "global_load_lds_dwordx4 %0, %4"
+                     : "=&v"(off)
+                     : "v"(lane_part), "s"(lds_byte), "s"(swz), "s"(gbase)
                      : "memory");
     };
     // K tile: piece p (1 KiB of LDS) = RPP rows; lane -> row p*RPP + lane/KCH, LDS chunk position
@@ -792,44 +825,40 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
     // address lives in a register: the piece's row base goes into the scalar base pointer and the
     // row-dependent swizzle bits are XORed in at issue (wave-uniform, one VALU op).
     const unsigned klane = (unsigned)((lane / KCH) * DK * 2 + (((lane % KCH) ^ ((lane / KCH) & SWZ)) << 4));
-    auto dma_k = [&](int tile, int buf) __attribute__((always_inline)) {
+    // One K piece (j of this wave's KPW) of tile `tile` into K buffer `buf` (both wave-uniform
+    // run-time values).  Rows past the shard's end re-read its last row (finite data; their
+    // scores are masked); with one row per piece (DK = 512) that clamp is scalar.
+    auto dma_k_piece = [&](int tile, int buf, int j) __attribute__((always_inline)) {
         const int base = kv_begin + tile * kKvTile;
         const int last = kv_end - 1 - base;
         const char *kb = reinterpret_cast<const char *>(a.K + (size_t)base * DK);
-        if (last >= kKvTile - 1) {
-#pragma unroll
-            for (int j = 0; j < KPW; ++j) {
-                const int row0 = (wave * KPW + j) * RPP;             // wave-uniform, a multiple of RPP:
-                const unsigned swz = (unsigned)((row0 & SWZ) << 4);   // (row0 + x) & SWZ == (row0 & SWZ) ^ x
-                dma_piece(kb + (size_t)row0 * (DK * 2), klane ^ swz,
-                          lds_base + (unsigned)(buf * KTILE * 2 + (wave * KPW + j) * 1024));
-            }
+        const int row0 = (wave * KPW + j) * RPP;                  // wave-uniform, a multiple of RPP:
+        const unsigned swz = (unsigned)((row0 & SWZ) << 4);       // (row0 + x) & SWZ == (row0 & SWZ) ^ x
+        const unsigned dst = lds_base + (unsigned)(buf * KTILE * 2 + (wave * KPW + j) * 1024);
+        if constexpr (RPP == 1) {
+            dma_piece_xor(kb + (size_t)min(row0, last) * (DK * 2), klane, swz, dst);
         } else {
-            // rows past the shard's end re-read its last row (finite data; their scores are masked)
-#pragma unroll
-            for (int j = 0; j < KPW; ++j) {
-                const int row0 = (wave * KPW + j) * RPP;
-                const unsigned swz = (unsigned)((row0 & SWZ) << 4);
-                const unsigned row = (unsigned)min(row0 + (int)(lane / KCH), last);
-                dma_piece(kb, row * (DK * 2) + ((klane ^ swz) % (DK * 2)),
-                          lds_base + (unsigned)(buf * KTILE * 2 + (wave * KPW + j) * 1024));
-            }
+            unsigned off;                                         // volatile: not hoisted into KPW live registers
+            asm volatile("v_xor_b32 %0, %1, %2" : "=v"(off) : "s"(swz), "v"(klane));
+            const unsigned row = (unsigned)min(row0 + (int)(lane / KCH), last);
+            dma_piece(kb, row * (DK * 2) + (off % (DK * 2)), dst);
         }
     };
     // Vt tile: piece p = 16 dv rows x 64 bytes; lane -> row p*16 + lane/4, LDS chunk position
     // lane%4, which holds global chunk (lane%4) ^ ((row >> 2) & 3) = (lane%4) ^ ((lane >> 4) & 3).
     // Rows past dv and keys past n_local are zero in the image, so no clamps.
     const unsigned vlane = (unsigned)((size_t)(lane >> 2) * a.ldvt * 2u) + (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
-    auto dma_v = [&](int tile, int buf) __attribute__((always_inline)) {
+    auto dma_v_piece = [&](int tile, int buf, int j) __attribute__((always_inline)) {
         const char *vb = reinterpret_cast<const char *>(a.Vt + kv_begin + tile * kKvTile);
-#pragma unroll
-        for (int j = 0; j < VPW; ++j)
-            dma_piece(vb + (size_t)(dv0 + (wave * VPW + j) * 16) * a.ldvt * 2u, vlane,
-                      lds_base + (unsigned)(2 * KTILE * 2 + buf * VTILE * 2 + (wave * VPW + j) * 1024));
+        dma_piece(vb + (size_t)(dv0 + (wave * VPW + j) * 16) * a.ldvt * 2u, vlane,
+                  lds_base + (unsigned)(3 * KTILE * 2 + buf * VTILE * 2 + (wave * VPW + j) * 1024));
     };
-    auto stage_fence = [&]() __attribute__((always_inline)) {
+    // Wait until at most `KEEP` of this wave's DMA pieces are in flight (they retire in issue
+    // order), then meet the other waves: everything older is in LDS for everybody.
+    auto stage_fence = [&](auto keep) __attribute__((always_inline)) {
+        constexpr int KEEP = decltype(keep)::value;
         if constexpr (ABL & 8) return;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
         __syncthreads();
     };
 
@@ -838,9 +867,11 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
     unsigned kaddr[NKA];
 #pragma unroll
     for (int u = 0; u < NKA; ++u) kaddr[u] = (unsigned)(li * DK * 2 + (((2 * u + hi) ^ (li & SWZ)) << 4));
-    auto kfrag = [&](int buf, int ks) __attribute__((always_inline)) -> u32x4 {
+    // the K buffer being read rotates through three: its byte offset lives IN kaddr[] (advanced
+    // in place once per step), so a fragment read is still one ds_read_b128 with an immediate
+    auto kfrag = [&](int ks) __attribute__((always_inline)) -> u32x4 {
         if constexpr (ABL & 2) return qf[(ks + 1) % NKS];
-        return *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(Ks + buf * KTILE) +
+        return *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(Ks) +
                                                 kaddr[ks % NKA] + (ks / NKA) * 256);
     };
     // Vt fragment: keys 16h + {4hi..+3, 8+4hi..+3} of dv row 32tt + li = chunk 2h+hi of that row
@@ -858,76 +889,82 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
         const int valid = kv_end - (kv_begin + tile * kKvTile);
         if (valid < kKvTile) {
             mfma_result_fence(sx);
+            const int vh = valid - 4 * hi;                 // compare against literals: no 16 hoisted row indices
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (crow16(r, hi) >= valid) sx[r] = -INFINITY;
+                if (crow16(r, 0) >= vh) sx[r] = -INFINITY;
         }
     };
     constexpr int PPK = NKS >= 16 ? 1 : 16 / NKS;        // P values started per QK^T MFMA slot
     constexpr int KPP = NKS >= 16 ? NKS / 16 : 1;        // QK^T MFMAs per P value
 
+    // Pipeline of one step t (tile t is "current", t+1 "next"), one barrier per step:
+    //   [A] S^T(t+1) = K(t+1).Q^T, a dependent chain of VGPR-form MFMAs, with nothing beside it
+    //       but fragment reads and the DMA issue of K(t+3): VALU work next to a DEPENDENT MFMA
+    //       chain delays the next link (the wave issues in order), next to independent MFMAs it
+    //       is nearly free (tools/probes/mfma_probe.hip)
+    //   fence: all DMA older than this step's K pieces has landed (K(t+2), Vt(t)) + barrier
+    //   [B] O^T += Vt(t).P(t)^T, 32 independent MFMAs  ||  all softmax VALU work of tile t+1
+    //       (exp2, row sum, bf16 pack -> P(t+1) for the next step; row max)  ||  DMA issue of Vt(t+1)
+    // P needs no row max (fixed reference exponent), so the score tile is dead after [B]: one
+    // score tile and two packed P tiles are live, not two score tiles.
+    // K has three buffers (K(t+3) lands while K(t+1) is read and K(t+2) waits), Vt two (Vt(t+1)
+    // is issued behind the barrier that ends every wave's reads of Vt(t-1)); DMA pieces are
+    // issued one at a time between MFMAs, so their scalar set-up hides in the matrix pipe's shadow.
+    // kr / kw: K buffer read in this step / written by this step's DMA (wave-uniform, rotating).
     // returns true (wave-uniform) when the tile scored in this step does not fit the reference exponent
     // `fenced`: put the explicit MFMA-result fence behind the score chain.  The steady-state loop
     // does not need it (reads are placed >= 11 issue slots later and hipcc leaves that code
     // alone); the tail steps do, because hipcc spills around them and may touch the tile at once.
-    auto step = [&](auto has_next, auto fenced, f32x16 &su, f32x16 &sm, int t) __attribute__((always_inline)) -> bool {
+    int kr = 1, kw = 0;
+    f32x16 sx;                                             // the score tile
+    // exp of element r is issued one slot before its sum/pack: the transcendental's latency is
+    // never waited on, and it needs no s_nop behind it
+    auto p_exp = [&](int r) __attribute__((always_inline)) {
+        asm volatile("v_exp_f32 %0, %1" : "=v"(sx[r]) : "v"(fmaf(sx[r], c, -m_ref)));
+    };
+    auto p_acc = [&](int r, unsigned (&pw)[8]) __attribute__((always_inline)) {
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(l_run) : "v"(sx[r]));   // pinned: hipcc sinks the adds into one chain
+        if (r & 1) pw[r >> 1] = bpin_pack(sx[r - 1], sx[r]);
+    };
+    auto step = [&](auto has_next, auto fenced, const u32x4 (&pb)[2], u32x4 (&pn)[2], int t) __attribute__((always_inline)) -> bool {
         constexpr bool HAS_NEXT = decltype(has_next)::value;
         constexpr bool FENCED = decltype(fenced)::value;
-        const int vbuf = t & 1, kbuf = (t + 1) & 1;
-        if (t + 2 < T) dma_k(t + 2, t & 1);
-        if (t + 1 < T) dma_v(t + 1, (t + 1) & 1);
-        u32x4 pb[2];
-        unsigned pw[8];
-        // exp of element r is issued one slot before its sum/pack, so the transcendental's
-        // latency is never waited on
-        auto p_exp = [&](int r) __attribute__((always_inline)) {
-            su[r] = bpin_exp2(fmaf(su[r], c, -m_ref));
-        };
-        auto p_acc = [&](int r) __attribute__((always_inline)) {
-            asm volatile("v_add_f32 %0, %0, %1" : "+v"(l_run) : "v"(su[r]));   // pinned: hipcc sinks 32 adds into one chain
-            if (r & 1) pw[r >> 1] = bpin_pack(su[r - 1], su[r]);
-        };
-
+        const int vbuf = t & 1;
+        pin_o();
         if constexpr (HAS_NEXT) {
-            // [A] S^T(t+1) on the matrix pipe (VGPR chain)  ||  P(t) on the VALU
-            constexpr int KD = NKS < 6 ? NKS : 3;
+            // [A]
+            const int tk = min(t + 3, T - 1);              // past the end: a harmless reload into a free buffer
+            constexpr int KD = NKS < SDPA_WIDE_KD ? NKS : SDPA_WIDE_KD;
             u32x4 kq[KD];
 #pragma unroll
-            for (int i = 0; i < KD; ++i) kq[i] = kfrag(kbuf, i);
+            for (int i = 0; i < KD; ++i) kq[i] = kfrag(i);
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 const u32x4 kf = kq[ks % KD];
                 __builtin_amdgcn_sched_barrier(0);
-                if (ks == 0) mfma_bf16_vgpr_first(sm, kf, qf[0]);
-                else mfma_bf16_vgpr(sm, kf, qf[ks]);
-                if (ks + KD < NKS) kq[ks % KD] = kfrag(kbuf, ks + KD);
-                if (ks % KPP == 0) {
-#pragma unroll
-                    for (int r = (ks / KPP) * PPK; r < (ks / KPP) * PPK + PPK; ++r) {
-                        p_exp(r);
-                        if (r > 0) p_acc(r - 1);
-                    }
-                }
+                if (ks == 0) mfma_bf16_vgpr_first(sx, kf, qf[0]);
+                else mfma_bf16_vgpr(sx, kf, qf[ks]);
+                if (ks + KD < NKS) kq[ks % KD] = kfrag(ks + KD);
+                if (ks % 4 == 0) dma_k_piece(tk, kw, ks / 4);      // NKS / KPW == 4 for every DK
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (FENCED) mfma_result_fence(sm);
-            p_acc(15);
+            if constexpr (FENCED) mfma_result_fence(sx);
+            stage_fence(std::integral_constant<int, KPW>());
         } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                p_exp(r);
-                if (r > 0) p_acc(r - 1);
-            }
-            p_acc(15);
+            stage_fence(std::integral_constant<int, 0>());
         }
-        pb[0] = u32x4{pw[0], pw[1], pw[2], pw[3]};
-        pb[1] = u32x4{pw[4], pw[5], pw[6], pw[7]};
+        pin_o();
 
-        // [B] O^T += Vt(t).P(t)^T on the matrix pipe  ||  row max of S^T(t+1)
-        if constexpr (HAS_NEXT) mask_ragged(sm, t + 1);
+        // [B]
+        if constexpr (HAS_NEXT) mask_ragged(sx, t + 1);
         float tmax = -INFINITY;
+        unsigned pw[8];
         constexpr int SLOTS = 2 * NT;                     // P.V MFMAs of this step
-        constexpr int VD = 2;                              // V fragment prefetch depth
+        constexpr int VD = SDPA_WIDE_VD;                   // V fragment prefetch depth
+        // next step reads the next K buffer: advance the fragment addresses in place
+        const int kr_next = kr == 2 ? 0 : kr + 1;
+        const unsigned kstep = (unsigned)((kr_next - kr) * KTILE * 2);
         u32x4 vq[VD];
 #pragma unroll
         for (int i = 0; i < VD; ++i) vq[i] = vfrag(vbuf, i);
@@ -941,43 +978,78 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
                                                                oacc[tt], 0, 0, 0);
             if (slot + VD < SLOTS) vq[slot % VD] = vfrag(vbuf, slot + VD);
             if constexpr (HAS_NEXT) {
+                if (slot % 4 == 1) dma_v_piece(t + 1, vbuf ^ 1, slot / 4);       // VPW == 8 pieces over 32 slots
                 // first read of the score tile: four MFMAs + four LDS reads (>= 11 issue slots,
-                // the MFMA->VALU requirement for an 8-pass MFMA) behind the chain's last link
-                if (slot >= 4 && slot < 12) tmax = bpin_max3(tmax, sm[2 * (slot - 4)], sm[2 * (slot - 4) + 1]);
-                if (slot == 14) tmax = halfwave_max(fmaf(tmax, c, -m_ref));
+                // the MFMA->VALU requirement for an 8-pass MFMA) behind the chain's last link.
+                // The row max reads the raw scores, so it goes before the exps overwrite them.
+                if constexpr (!(ABL & 4)) {
+                    if (slot >= 4 && slot < 12) tmax = bpin_max3(tmax, sx[2 * (slot - 4)], sx[2 * (slot - 4) + 1]);
+                    if (slot == 12) tmax = halfwave_max(fmaf(tmax, c, -m_ref));
+                    if (slot >= 12 && slot < 28) {
+                        p_exp(slot - 12);
+                        if (slot > 12) p_acc(slot - 13, pw);
+                    }
+                    if (slot == 28) p_acc(15, pw);
+                } else if (slot == 4) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) pw[q] = __builtin_bit_cast(unsigned, sx[q]);
+                }
+                if (slot >= 20 && slot < 20 + NKA) kaddr[slot - 20] += kstep;
             }
         }
         __builtin_amdgcn_sched_barrier(0);
         pin_o();
         bool pending = false;
         if constexpr (HAS_NEXT) {
+            pn[0] = u32x4{pw[0], pw[1], pw[2], pw[3]};
+            pn[1] = u32x4{pw[4], pw[5], pw[6], pw[7]};
             pending = __any(tmax > kDeferLog2);
             max_rel = fmaxf(max_rel, tmax);
+            kr = kr_next;
+            kw = kw == 2 ? 0 : kw + 1;
         }
-        stage_fence();
         return pending;
     };
 
-    f32x16 sA, sB;
     if (T > 0) {
-        dma_k(0, 0);
-        dma_v(0, 0);
-        if (T > 1) dma_k(1, 1);
-        stage_fence();
+#pragma unroll
+        for (int j = 0; j < KPW; ++j) dma_k_piece(0, 0, j);
+#pragma unroll
+        for (int j = 0; j < VPW; ++j) dma_v_piece(0, 0, j);
+#pragma unroll
+        for (int j = 0; j < KPW; ++j) dma_k_piece(min(1, T - 1), 1, j);
+#pragma unroll
+        for (int j = 0; j < KPW; ++j) dma_k_piece(min(2, T - 1), 2, j);
+        stage_fence(std::integral_constant<int, 0>());
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            const u32x4 kf = kfrag(0, ks);
-            if (ks == 0) mfma_bf16_vgpr_first(sA, kf, qf[0]);
-            else mfma_bf16_vgpr(sA, kf, qf[ks]);
+            const u32x4 kf = kfrag(ks);
+            if (ks == 0) mfma_bf16_vgpr_first(sx, kf, qf[0]);
+            else mfma_bf16_vgpr(sx, kf, qf[ks]);
         }
-        mfma_result_fence(sA);
-        mask_ragged(sA, 0);
-        float tmax = sA[0];
+        mfma_result_fence(sx);
+        mask_ragged(sx, 0);
+        float tmax = sx[0];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sA[r]);
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sx[r]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
         m_ref = tmax * c;                               // finite: every tile has a valid key row
-        __syncthreads();                                // K(0) fully consumed before K(2) lands on it
+        // P(0)
+        u32x4 pA[2], pB[2];
+        {
+            unsigned pw[8];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                p_exp(r);
+                if (r > 0) p_acc(r - 1, pw);
+            }
+            p_acc(15, pw);
+            pA[0] = u32x4{pw[0], pw[1], pw[2], pw[3]};
+            pA[1] = u32x4{pw[4], pw[5], pw[6], pw[7]};
+        }
+        __syncthreads();                                // K(0) fully consumed before K(3) lands on it
+#pragma unroll
+        for (int u = 0; u < NKA; ++u) kaddr[u] += (unsigned)(KTILE * 2);   // step 0 reads K(1) in buffer 1
 
         // Steady state.  A tile whose row max exceeds the reference exponent by more than
         // 2^kDeferLog2 would need the accumulators rescaled -- and ANY VALU access to the 256
@@ -989,14 +1061,14 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
         int t = 0;
         bool redo = false;
         for (; t + 2 < T; t += 2) {
-            redo |= step(std::true_type(), std::false_type(), sA, sB, t);
-            redo |= step(std::true_type(), std::false_type(), sB, sA, t + 1);
+            redo |= step(std::true_type(), std::false_type(), pA, pB, t);
+            redo |= step(std::true_type(), std::false_type(), pB, pA, t + 1);
         }
         if (T - t == 2) {
-            redo |= step(std::true_type(), std::true_type(), sA, sB, t);
-            step(std::false_type(), std::true_type(), sB, sA, t + 1);
+            redo |= step(std::true_type(), std::true_type(), pA, pB, t);
+            step(std::false_type(), std::true_type(), pB, pA, t + 1);
         } else {
-            step(std::false_type(), std::true_type(), sA, sB, t);
+            step(std::false_type(), std::true_type(), pA, pB, t);
         }
         if (redo && lane == 0) a.redo[split * n_qblocks + qblock] = 1;
     }
@@ -1140,7 +1212,7 @@ static hipError_t launch_bf16_wide(const Bf16Args &a, hipStream_t s) {
     const int ntiles = (a.n_local + kKvTile - 1) / kKvTile;
     const int tiles_per_split = (ntiles + a.kv_splits - 1) / a.kv_splits;
     const int kv_per_split = tiles_per_split > 0 ? tiles_per_split * kKvTile : kKvTile;
-    const size_t lds = (size_t)2 * (kKvTile * DK + 512 * kKvTile) * sizeof(unsigned short);
+    const size_t lds = ((size_t)3 * kKvTile * DK + (size_t)2 * 512 * kKvTile) * sizeof(unsigned short);
     static bool attr_done[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
@@ -1216,7 +1288,10 @@ hipError_t launch_shard_partial_bf16(const Bf16Args &a, hipStream_t s) {
                 case 2: e = launch_bf16_wide<512, 2>(a, s); break;    // no LDS fragment reads
                 case 8: e = launch_bf16_wide<512, 8>(a, s); break;    // no barrier (racy)
                 case 9: e = launch_bf16_wide<512, 9>(a, s); break;
-                default: e = launch_bf16_wide<512, 11>(a, s); break;  // MFMA + softmax only
+                case 11: e = launch_bf16_wide<512, 11>(a, s); break;  // MFMA + softmax only
+                case 4: e = launch_bf16_wide<512, 4>(a, s); break;    // no softmax VALU
+                case 13: e = launch_bf16_wide<512, 13>(a, s); break;  // LDS fragment reads + MFMA only
+                default: e = launch_bf16_wide<512, 15>(a, s); break;  // MFMA skeleton only
             }
         } else {
             switch (kp) {

@@ -38,6 +38,43 @@ __global__ __launch_bounds__(256) void chain(float *out, int iters, unsigned see
     if (s == 12345.678f) out[0] = s;
 }
 
+
+// same as chain<NACC> but with operands that toggle: random bf16 bit patterns, four different A
+// and B fragments in rotation (a power/clock question, not an issue-rate one)
+__device__ __forceinline__ unsigned hash32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+template <int NACC>
+__global__ __launch_bounds__(256) void chain_rand(float *out, int iters, unsigned seed) {
+    u32x4 av[4], bv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned h = hash32(seed + threadIdx.x * 9781u + blockIdx.x * 6271u + i * 131u);
+        // keep exponents moderate so nothing overflows: sign + random mantissa, exponent ~ 2^-4..2^3
+        auto mk = [&](unsigned r) { return (r & 0x807f807fu) | 0x3d803d80u | ((r >> 3) & 0x03000300u); };
+        av[i] = u32x4{mk(h), mk(hash32(h + 1)), mk(hash32(h + 2)), mk(hash32(h + 3))};
+        bv[i] = u32x4{mk(hash32(h + 4)), mk(hash32(h + 5)), mk(hash32(h + 6)), mk(hash32(h + 7))};
+    }
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 64; ++k)
+            acc[k % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[k % 4]),
+                                                                    __builtin_bit_cast(bf16x8, bv[(k / 4) % 4]), acc[k % NACC], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (s == 12345.678f) out[0] = s;
+}
+
 // step shape of the d=512 kernel: 32-long dependent chain with NV VALU ops after every 2nd MFMA,
 // then 16 MFMAs over 8 accumulators
 template <int NV>
@@ -171,6 +208,10 @@ int main(int argc, char **argv) {
         printf("-- %d wave(s) per SIMD\n", bpc);
         run("chain<1>", [&](int g, int n) { hipLaunchKernelGGL(chain<1>, dim3(g), dim3(256), 0, 0, out, n, 1u); }, 64, blocks, it);
         run("chain<8>", [&](int g, int n) { hipLaunchKernelGGL(chain<8>, dim3(g), dim3(256), 0, 0, out, n, 1u); }, 64, blocks, it);
+        run("chain_rand<1> (toggling data)", [&](int g, int n) { hipLaunchKernelGGL(chain_rand<1>, dim3(g), dim3(256), 0, 0, out, n, 7u); }, 64, blocks, it);
+        run("chain_rand<8> (toggling data)", [&](int g, int n) { hipLaunchKernelGGL(chain_rand<8>, dim3(g), dim3(256), 0, 0, out, n, 7u); }, 64, blocks, it);
+        run("chain_rand<8> x4 longer", [&](int g, int n) { hipLaunchKernelGGL(chain_rand<8>, dim3(g), dim3(256), 0, 0, out, n * 4, 7u); }, 64 * 4, blocks, it);
+        if (argc > 2) continue;
         run("mixed<8> (dep, every 2nd)", [&](int g, int n) { hipLaunchKernelGGL(mixed<8>, dim3(g), dim3(256), 0, 0, out, n, 1u); }, 48, blocks, it);
         M2(0, 2); M2(0, 4); M2(0, 6);
         M2(1, 2); M2(1, 4); M2(1, 6); M2(1, 8); M2(1, 10);
