@@ -325,7 +325,8 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         peak = BF16_MFMA_PEAK_TFLOPS if args.precision == "bf16" else F32_MFMA_PEAK_TFLOPS
         if args.precision == "bf16":
-            kernel_name = "sdpa::fused_bf16_kernel"
+            kernel_name = ("sdpa::fused_bf16_wide_kernel<%d,0> (+ its redo pass)" % (512 if d > 256 else 256 if d > 128 else 128 if d > 64 else 64)
+                           if d > 256 else "sdpa::fused_bf16_pipe_kernel")
         elif d in (64, 128):
             kernel_name = "sdpa::fused_pipelined_kernel<%d,%d,0>" % (d, d)
         else:

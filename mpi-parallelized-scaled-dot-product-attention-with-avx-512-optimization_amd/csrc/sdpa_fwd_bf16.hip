@@ -30,6 +30,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <type_traits>
 
 namespace sdpa {
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
     const int qrow = qblock * kQRowsPerBlock + wave * 32 + li;
     const int dv0 = chunk * DVC;
     // second pass behind the wide kernel: only the blocks it flagged
-    if (a.redo != nullptr && a.redo[split * n_qblocks + qblock] == 0) return;
+    if (a.redo != nullptr && a.redo[split * n_qblocks + qblock] != a.redo_gen) return;
 
     const int kv_begin = split * kv_per_split;
     const int kv_end = min(a.n_local, kv_begin + kv_per_split);
@@ -692,7 +693,8 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
 //     to those 256 registers in or around the loop -- a rescale on a never-taken branch, an early
 //     exit -- makes hipcc copy and spill accumulator tiles on the hot path.  So the kernel has NO
 //     rescale: the reference exponent is fixed by the first tile, a wave whose later row max
-//     exceeds it by more than 2^32 flags its (q block, split), and the launcher runs the general
+//     exceeds it by more than 2^32 stamps its (q block, split) flag with the launch's generation number
+//     (nothing to clear beforehand), and the launcher runs the general
 //     kernel (256-column chunks, in-loop rescale) behind this one over the flagged blocks only.
 //   * K (three buffers) and Vt (two) arrive by LDS-DMA issued piece by piece between MFMAs, one
 //     barrier per tile in the middle of the step; no staging registers.  Vt rows are 64 bytes
@@ -1070,7 +1072,7 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
         } else {
             step(std::false_type(), std::true_type(), pA, pB, t);
         }
-        if (redo && lane == 0) a.redo[split * n_qblocks + qblock] = 1;
+        if (redo && lane == 0) a.redo[split * n_qblocks + qblock] = a.redo_gen;
     }
 
     // ---- epilogue: fold the true row max back in, write this chunk's columns
@@ -1251,7 +1253,10 @@ static hipError_t launch_bf16(const Bf16Args &a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_shard_partial_bf16(const Bf16Args &a, hipStream_t s) {
+hipError_t launch_shard_partial_bf16(const Bf16Args &args, hipStream_t s) {
+    static std::atomic<int> generation{0x5d9a0000};
+    Bf16Args a = args;
+    a.redo_gen = generation.fetch_add(1) + 1;
     const int kp = bf16_pad_dk(a.dk), vc = bf16_chunk_dv(a.dv);
     if (a.dk > 512 || a.ldq != kp || a.ldk != kp) return hipErrorInvalidValue;
     hipError_t e = hipErrorInvalidValue;
@@ -1279,9 +1284,6 @@ hipError_t launch_shard_partial_bf16(const Bf16Args &a, hipStream_t s) {
     if (vc == 512) {
         if ((reinterpret_cast<uintptr_t>(a.K) & 15) || (reinterpret_cast<uintptr_t>(a.Vt) & 15) || !a.redo)
             return hipErrorInvalidValue;
-        const int nqb = (a.m + kQRowsPerBlock - 1) / kQRowsPerBlock;
-        e = hipMemsetAsync(a.redo, 0, (size_t)nqb * a.kv_splits * sizeof(int), s);
-        if (e != hipSuccess) return e;
         if (kp == 512 && ((tune >> 8) & 15)) {                // timing-only ablations
             switch ((tune >> 8) & 15) {
                 case 1: e = launch_bf16_wide<512, 1>(a, s); break;    // no DMA

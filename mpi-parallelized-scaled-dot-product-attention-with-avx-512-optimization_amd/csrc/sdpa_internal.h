@@ -44,6 +44,9 @@ struct Bf16Args {
     float *ws_lmax;
     float *ws_lsum;
     int *redo;                     // [kv_splits x q blocks] flags, dv > 256 only (bf16_carve_workspace)
+    int redo_gen;                  // a flag counts when it equals this launch's generation (set by the
+                                   // launcher): nothing has to be cleared, stale or uninitialised
+                                   // values at worst cause a harmless extra redo
 };
 
 int  bf16_pad_dk(int dk);
