@@ -99,6 +99,14 @@ SDPA_API int sdpa_last_timing(struct sdpa_timing *out);
  * :504); sdpa_attention_f64 works without it, the first call is just slower.               */
 SDPA_API int sdpa_prepare(int m, int n, int dk, int dv, int flags);
 
+/* Optional: page-locked host memory for the caller's Q/K/V/result arrays -- what the reference's
+ * read_matrix() mallocs (attention.c:84-90) and main() frees (:191-194).  Arrays allocated here
+ * need no per-call registration inside sdpa_attention_f64 and move at the full PCIe rate from the
+ * first touch.  Returns NULL when there is no usable device or the allocation fails (the host then
+ * uses malloc; sdpa_attention_f64 accepts any host pointer).  SURVEY.md 8(f)-2.                 */
+SDPA_API void *sdpa_host_alloc(size_t bytes);
+SDPA_API void  sdpa_host_free(void *p);
+
 /* K/V row partition, attention-mpi.c:19-27. */
 SDPA_API int sdpa_owner_count(int n, int size, int rank);
 SDPA_API int sdpa_owner_disp(int n, int size, int rank);

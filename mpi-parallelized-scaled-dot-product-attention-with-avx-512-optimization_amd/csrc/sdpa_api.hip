@@ -618,6 +618,20 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
     return SDPA_OK;
 }
 
+void *sdpa_host_alloc(size_t bytes) {
+    if (bytes == 0 || require_device() != SDPA_OK) return nullptr;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+void sdpa_host_free(void *p) {
+    if (p && hipHostFree(p) != hipSuccess) (void)hipGetLastError();
+}
+
 int sdpa_prepare(int m, int n, int dk, int dv, int flags) {
     if (m <= 0 || n <= 0 || dk <= 0 || dv <= 0) return SDPA_EINVAL;
     if (dv > 1024) return SDPA_EUNSUP;

@@ -37,6 +37,37 @@ def test_owner_partition_matches_oracle(n, size, pkg, orc):
         assert pkg.owner_disp(n, size, r) == orc.owner_disp(n, size, r)
 
 
+def test_bf16_image_geometry_helpers(pkg):
+    """host-side layout contract of the bf16 operand images (include/sdpa_hip.h): padded leading
+    dimensions, the key order of a Vt row, the workspace of the wide (dv > 256) kernel"""
+    lib = pkg.load()
+    assert [lib.sdpa_dev_bf16_ld(d) for d in (1, 64, 65, 128, 200, 256, 300, 512)] == [64, 64, 128, 128, 256, 256, 512, 512]
+    assert [lib.sdpa_dev_bf16_dvp(d) for d in (1, 64, 100, 128, 200, 256, 257, 512, 700, 1024)] == \
+        [64, 64, 128, 128, 256, 256, 512, 512, 1024, 1024]
+    assert [lib.sdpa_dev_bf16_ldn(n) for n in (0, 1, 32, 33, 65536)] == [0, 32, 32, 64, 65536]
+    pos = [lib.sdpa_dev_bf16_kvpos(j) for j in range(64)]
+    assert pos[:16] == [0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15]       # group order 0-3, 8-11, 4-7, 12-15
+    assert all(pos[16 * g + i] == 16 * g + pos[i] for g in range(4) for i in range(16))
+    assert [pos[p] for p in pos] == list(range(64))                                   # an involution
+    # the eight keys one MFMA lane multiplies -- rows crow(8h+j, hi) of the score tile's C layout --
+    # are positions 16h + 8hi .. +7 of the row, i.e. 16 contiguous bytes
+    crow = lambda r, hi: (r & 3) + 8 * (r >> 2) + 4 * hi
+    for h in range(2):
+        for hi in range(2):
+            assert [pos[crow(8 * h + j, hi)] for j in range(8)] == list(range(16 * h + 8 * hi, 16 * h + 8 * hi + 8))
+    assert lib.sdpa_dev_bf16_kvpos(-1) < 0
+    # split buffers ([splits x m x (ld(dv) + 2)] floats) when the shard is split in-GPU, and for
+    # dv > 256 one redo flag per (split, 128-row q block)
+    s1 = lib.sdpa_dev_kv_splits_bf16(32768, 65536, 128, 128)
+    assert lib.sdpa_dev_workspace_bytes_bf16(32768, 65536, 128, 128) == (s1 * 32768 * (128 + 2) * 4 if s1 > 1 else 0)
+    assert lib.sdpa_dev_kv_splits_bf16(70000, 4096, 64, 64) == 1 and lib.sdpa_dev_workspace_bytes_bf16(70000, 4096, 64, 64) == 0
+    splits = lib.sdpa_dev_kv_splits_bf16(32768, 65536, 512, 512)
+    assert splits == 1 and lib.sdpa_dev_workspace_bytes_bf16(32768, 65536, 512, 512) == 256 * 4
+    s2 = lib.sdpa_dev_kv_splits_bf16(256, 8192, 512, 512)
+    assert s2 > 1
+    assert lib.sdpa_dev_workspace_bytes_bf16(256, 8192, 512, 512) == s2 * 256 * (512 + 2) * 4 + 2 * s2 * 4
+
+
 def test_argument_validation_precedes_device_use(pkg):
     lib = pkg.load()
     a = np.zeros((4, 4))

@@ -263,6 +263,36 @@ def test_cli_bf16_env_and_qbatch(tmp_path, O):
             assert "q_batches=3" in r.stderr
 
 
+def test_cli_io_modes_and_pinned_host_arrays(tmp_path, pkg, orc, O):
+    """the CLI reads into page-locked memory by default, into malloc'd memory with
+    SDPA_PINNED_IO=0, and creates the engine inside the timed call with SDPA_TIME_INIT=1 -- same
+    verdict each way; sdpa_host_alloc memory works as caller arrays of the boundary call"""
+    case = os.path.join(GOLD, "cfg1_small_D1.bin")
+    for env in ({}, {"SDPA_PINNED_IO": "0"}, {"SDPA_TIME_INIT": "1"}):
+        r = subprocess.run([CLI, case], capture_output=True, text=True, env=dict(os.environ, **env))
+        assert r.returncode == 0 and r.stdout.startswith("Correct!\nElapsed time: "), (env, r.stderr)
+    import ctypes
+    lib = pkg.load()
+    Q, K, V = O.make_inputs(64, 2048, 128, 128, "D2", seed=77)       # K, V: 2 MiB each
+    bufs = []
+    def pinned_copy(a):
+        p = lib.sdpa_host_alloc(a.nbytes)
+        assert p, "sdpa_host_alloc returned NULL on a GPU box"
+        bufs.append(p)
+        out = np.ctypeslib.as_array((ctypes.c_double * a.size).from_address(p)).reshape(a.shape)
+        out[...] = a
+        return out
+    try:
+        Kp, Vp = pinned_copy(K), pinned_copy(V)
+        got = pkg.attention(Q, Kp, Vp)
+        assert np.abs(got - orc.attention_f64(Q, K, V)).max() <= fp32_tol(V)
+    finally:
+        for p in bufs:
+            lib.sdpa_host_free(p)
+    lib.sdpa_host_free(None)
+    assert lib.sdpa_host_alloc(0) is None
+
+
 def test_random_shape_sweep_f32(pkg, be, orc, O):
     """40 seeded random shapes (ragged everything, dims on both sides of every kernel's tile and
     dispatch boundaries) through the device-level path"""

@@ -11,5 +11,7 @@ for name,(m,n,d) in {"headline":(32768,65536,128),"config2":(8192,8192,128)}.ite
         f.write(np.zeros((m,d)).tobytes())
 PY
 CLI=mpi-parallelized-scaled-dot-product-attention-with-avx-512-optimization_amd/bin/attention-hip
-for f in headline config2; do for reg in 1 0; do
-  echo "== $f SDPA_HOST_REGISTER=$reg"; SDPA_HOST_REGISTER=$reg SDPA_VERBOSE=1 $CLI /tmp/$f.bin 2>&1 | grep -E "total|Elapsed" ; done; done
+for f in headline config2; do
+  echo "== $f pinned reader (default)"; SDPA_VERBOSE=1 $CLI /tmp/$f.bin 2>&1 | grep -E "total|Elapsed"
+  for reg in 1 0; do
+  echo "== $f SDPA_PINNED_IO=0 SDPA_HOST_REGISTER=$reg"; SDPA_PINNED_IO=0 SDPA_HOST_REGISTER=$reg SDPA_VERBOSE=1 $CLI /tmp/$f.bin 2>&1 | grep -E "total|Elapsed" ; done; done
