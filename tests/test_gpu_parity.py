@@ -103,7 +103,15 @@ SHAPES = [
     (200,  333, 128,  64, "D1"),
     (40,   300, 100, 200, "D2"),      # dv > 128 -> any-shape kernel
     (24,   200, 256, 256, "D1"),      # dk, dv > 128
-    (16,   130, 512, 512, "D1"),      # BASELINE config 5 dims (fp32 any-shape path)
+    (16,   130, 512, 512, "D1"),      # BASELINE config 5 dims in fp32: dk-split kernel, 128-col slices
+    (70,   333, 300,  40, "D2"),      # 256 < dk <= 512: dk-split kernel, 32-col slices, ragged everything
+    (129,  700, 512, 300, "D1"),      # dk-split, three q blocks of 64 (last ragged), waves past dv idle
+    (64,  2048, 384, 128, "D3"),      # dk-split, peaky, one wave's dk slice all padding
+    (200,    5, 512,  64, "D2"),      # dk-split, n < tile
+    (33,    64, 257, 257, "D1"),      # one past both MFMA-kernel limits: 64-col slices
+    (300, 4096, 512, 200, "D2"),      # dk-split with in-GPU K/V splits
+    (130, 1000, 400, 700, "D4"),      # dk-split, dv > 512 -> two chunks, late spike key
+    (20,    70, 600,  48, "D2"),      # dk > 512: VALU any-shape kernel
 ]
 
 

@@ -5,15 +5,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("mpi-parallelized-scaled-dot-product-attention-with-avx-512-optimization_amd")
 shapes = {"headline": (32768, 65536, 128), "config2": (8192, 8192, 128), "config1": (512, 512, 64),
-          "config4": (131072, 65536, 128)}
+          "config4": (131072, 65536, 128), "config5": (32768, 65536, 512)}
 pkg.init(0)
 for name in sys.argv[1:] or ["headline", "config2", "config1"]:
-    m, n, d = shapes[name]
+    prec = "bf16" if name.endswith(":bf16") else None     # e.g. config5:bf16
+    m, n, d = shapes[name.split(":")[0]]
     rng = np.random.default_rng(0)
     Q, K, V = (rng.uniform(-1, 1, s) for s in ((m, d), (n, d), (n, d)))
     best = None
     for it in range(4):
-        t0 = time.perf_counter(); pkg.attention(Q, K, V); dt = time.perf_counter() - t0
+        t0 = time.perf_counter(); pkg.attention(Q, K, V, precision=prec); dt = time.perf_counter() - t0
         t = pkg.last_timing(); t["wall_s"] = dt
         if it and (best is None or t["total_us"] < best["total_us"]): best = t
     print(name, json.dumps(best))
