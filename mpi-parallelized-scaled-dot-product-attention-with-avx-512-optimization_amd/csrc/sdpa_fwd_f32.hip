@@ -34,8 +34,9 @@
 //                                   config; 142 TFLOP/s = 90.5 % of peak at the metric shape)
 //   fused_partial_kernel<DKP,DVP>   any dk <= 256 (padded to 32/64/128/256), any dv (chunks of <= 128
 //                                   columns): register-staged
-//   fused_dksplit_kernel<DVS>       256 < dk <= 512: the four waves split dk (scores) and dv (accumulate),
-//                                   partial score tiles exchanged through LDS, K/V straight from global
+//   fused_dksplit_kernel<DKS,DVS>   256 < dk <= 512, and 128 < dk <= 256 with dv > 128: the four waves split dk
+//                                   (scores) and dv (accumulate), partial score tiles exchanged through LDS,
+//                                   K/V straight from global memory
 //   generic_partial_kernel          dk > 512: VALU-only correctness path
 //   split_merge_kernel              merge of the in-GPU K/V splits
 //
@@ -709,10 +710,11 @@ __global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, 
 }
 
 // ---------------------------------------------------------------------------
-// 256 < dk <= 512 in fp32.  A 32 x 512 fp32 Q fragment alone is 256 registers, so here the four
-// waves of a workgroup SPLIT the contraction dimensions between them instead of the query rows:
-//   * workgroup = 64 query rows (two 32-row MFMA blocks).  Wave w holds Q[:, 128w .. 128w+127]
-//     (128 VGPRs) and the O^T slice of V columns [DVS*w, DVS*(w+1)) of the chunk (<= 128 regs);
+// 256 < dk <= 512 in fp32 (and 128 < dk <= 256 when dv > 128, where it saves the per-chunk score
+// recompute).  A 32 x 512 fp32 Q fragment alone is 256 registers, so here the four waves of a
+// workgroup SPLIT the contraction dimensions between them instead of the query rows:
+//   * workgroup = 64 query rows (two 32-row MFMA blocks).  Wave w holds Q[:, DKS*w .. DKS*(w+1))
+//     (128 registers at DKS = 128) and the O^T slice of V columns [DVS*w, DVS*(w+1)) of the chunk (<= 128 regs);
 //   * per 32-key tile a wave computes the PARTIAL score tile over its dk slice -- K fragments come
 //     straight from global memory, nobody else needs them -- the four partials go through LDS and
 //     every wave sums them in the same fixed order (bitwise the same S^T in all four, so the
@@ -722,10 +724,10 @@ __global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, 
 // 256 MFMAs of 64 cycles per wave and tile against 32 KiB of global reads: matrix-pipe bound.
 // Same outputs and the same online-softmax arithmetic as fused_partial_kernel.
 // ---------------------------------------------------------------------------
-template <int DVS>
+template <int DKS, int DVS>
 __global__ __launch_bounds__(256, 1) void fused_dksplit_kernel(
     PartialArgs a, int kv_per_split, int n_qblocks, int n_chunks, float scale) {
-    constexpr int DKS = 128;            // dk slice of one wave (dk is treated as padded to 512)
+    // DKS: dk slice of one wave (dk is treated as padded to 4*DKS = 256 or 512)
     constexpr int NU = DKS / 8;         // 16-byte K reads (4 MFMA k-steps each) per tile per lane
     constexpr int NT = DVS / 32;        // 32-row O^T blocks per wave; also floats per V read
     constexpr int XLD = 20;             // floats per lane in the exchange buffer: 16 + pad, b128 conflict-free
@@ -1065,10 +1067,17 @@ static inline int dv_chunks(int dv) { return (dv + dv_chunk(dv) - 1) / dv_chunk(
 static inline int dksplit_slice(int dv) { return dv <= 128 ? 32 : (dv <= 256 ? 64 : 128); }
 static inline int dksplit_chunks(int dv) { return (dv + 4 * dksplit_slice(dv) - 1) / (4 * dksplit_slice(dv)); }
 
+// the dk-split kernel takes 256 < dk <= 512, and 128 < dk <= 256 when dv needs more than one
+// 128-column chunk of fused_partial_kernel (measured: 102 vs 86 TFLOP/s at dk = dv = 256, but
+// 74 vs 118 at dk = 256, dv = 64, where its per-tile exchange is not amortised)
+static inline bool uses_dksplit(int dk, int dv) {
+    return dk <= kMaxDkSplit && (dk > kMaxMfmaDk || (dk > kMaxFastDim && dv > kMaxFastDim));
+}
+
 int pick_kv_splits(int m, int n_local, int dk, int dv) {
     if (dk > kMaxDkSplit) return 1;              // VALU-only fallback kernel: no splits
     if (m <= 0 || n_local <= 0) return 1;
-    if (dk > kMaxMfmaDk) {                       // dk-split kernel: 64-row workgroups, one per CU
+    if (uses_dksplit(dk, dv)) {                  // 64-row workgroups, one per CU
         const int nb = ((m + 63) / 64) * dksplit_chunks(dv);
         const int ntiles = (n_local + kKvTile - 1) / kKvTile;
         int want = (256 + nb - 1) / nb, cap = ntiles / 4;
@@ -1132,7 +1141,7 @@ static hipError_t launch_fast(const PartialArgs &a, hipStream_t s) {
     return e;
 }
 
-template <int DVS>
+template <int DKS, int DVS>
 static hipError_t launch_dksplit(const PartialArgs &a, hipStream_t s) {
     const int nqb = (a.m + 63) / 64;
     const int ntiles = (a.n_local + kKvTile - 1) / kKvTile;
@@ -1144,13 +1153,13 @@ static hipError_t launch_dksplit(const PartialArgs &a, hipStream_t s) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_dksplit_kernel<DVS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_dksplit_kernel<DKS, DVS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done[dev] = true;
     }
     const float scale = 1.0f / sqrtf((float)a.dk);   // attention-mpi.c:208
-    hipLaunchKernelGGL((fused_dksplit_kernel<DVS>), dim3(nqb * chunks * a.kv_splits), dim3(256), lds, s,
+    hipLaunchKernelGGL((fused_dksplit_kernel<DKS, DVS>), dim3(nqb * chunks * a.kv_splits), dim3(256), lds, s,
                        a, kv_per_split, nqb, chunks, scale);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -1192,11 +1201,17 @@ hipError_t launch_shard_partial(const PartialArgs &a_in, hipStream_t s) {
     PartialArgs a = a_in;
     static const int tune_env = getenv("SDPA_TUNE") ? atoi(getenv("SDPA_TUNE")) : 0;
     a.tune = tune_env;
-    if (a.dk > kMaxMfmaDk && a.dk <= kMaxDkSplit && !(a.tune & 8)) {   // $SDPA_TUNE&8: any-shape kernel
+    if (uses_dksplit(a.dk, a.dv) && !(a.tune & 8)) {   // $SDPA_TUNE&8: the kernels it replaced
+        if (a.dk > kMaxMfmaDk) {
+            switch (dksplit_slice(a.dv)) {
+                case 32: return launch_dksplit<128, 32>(a, s);
+                case 64: return launch_dksplit<128, 64>(a, s);
+                default: return launch_dksplit<128, 128>(a, s);
+            }
+        }
         switch (dksplit_slice(a.dv)) {
-            case 32: return launch_dksplit<32>(a, s);
-            case 64: return launch_dksplit<64>(a, s);
-            default: return launch_dksplit<128>(a, s);
+            case 64: return launch_dksplit<64, 64>(a, s);
+            default: return launch_dksplit<64, 128>(a, s);
         }
     }
     if (a.dk > kMaxMfmaDk) {
