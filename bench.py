@@ -329,6 +329,8 @@ def main():
                            if d > 256 else "sdpa::fused_bf16_pipe_kernel")
         elif d in (64, 128):
             kernel_name = "sdpa::fused_pipelined_kernel<%d,%d,0>" % (d, d)
+        elif 128 < d <= 512:
+            kernel_name = "sdpa::fused_dksplit_kernel<%d,%d>" % (128 if d > 256 else 64, 128 if d > 256 else 64)
         else:
             kernel_name = "sdpa::fused_partial_kernel / generic_partial_kernel"
         total_flop = 4.0 * m * n * d
