@@ -112,6 +112,8 @@ SHAPES = [
     (300, 4096, 512, 200, "D2"),      # dk-split with in-GPU K/V splits
     (130, 1000, 400, 700, "D4"),      # dk-split, dv > 512 -> two chunks, late spike key
     (20,    70, 600,  48, "D2"),      # dk > 512: VALU any-shape kernel
+    (1,      1, 400,   1, "D2"),      # dk-split, smallest possible
+    (65,    33, 260, 130, "D3"),      # dk-split, one row past a 64-row workgroup, one key past a tile
 ]
 
 
