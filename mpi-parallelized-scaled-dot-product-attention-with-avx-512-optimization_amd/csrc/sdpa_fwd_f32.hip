@@ -456,13 +456,12 @@ __global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, 
         (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)smem);
     auto dma_piece = [&](const char *gbase, unsigned lane_off, unsigned lds_byte) __attribute__((always_inline)) {
         if constexpr (ABL & 1) return;
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\t"
-                     "s_mov_b32 m0, %2\n\t"
+        // M0 is written without save/restore: hipcc treats it as reserved and re-initialises it next
+        // to each of its own uses (the same choice as in the bf16 wide kernel)
+        asm volatile("s_mov_b32 m0, %1\n\t"
                      "s_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, %3\n\t"
-                     "s_mov_b32 m0, %0"
-                     : "=&s"(keep)
+                     "global_load_lds_dwordx4 %0, %2"
+                     :
                      : "v"(lane_off), "s"(lds_byte), "s"(gbase)
                      : "memory");
     };
@@ -580,14 +579,17 @@ __global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, 
                     if constexpr (ABL & 4) {
                         asm volatile("" : "+v"(su[r]));
                     } else {
-                        su[r] = pinned_exp2(su[r]);
-                        l_run += su[r];
+                        // exp2 of element r, then the row-sum add of element r-1: the transcendental's
+                        // result is never read by the next instruction, so it needs no wait state
+                        asm volatile("v_exp_f32 %0, %0" : "+v"(su[r]));
+                        if (r > 0) asm volatile("v_add_f32 %0, %0, %1" : "+v"(l_run) : "v"(su[r - 1]));
                     }
                 }
                 kf = kn;
                 kn = kn2;
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(ABL & 4)) l_run += su[15];
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
