@@ -563,8 +563,17 @@ __global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, 
             // exp2 is a volatile asm so that it stays inside its sched_barrier-fenced slot.
             float4 kf = kfrag(kbuf, 0);
             float4 kn = kfrag(kbuf, 1);
+            {   // accumulator = -m_ref in 8 packed moves instead of 16 (every VALU op beside an
+                // f32 MFMA costs matrix-pipe time)
+                const f32x2 negm = {-m_ref, -m_ref};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sm[r] = -m_ref;
+                for (int r = 0; r < 16; r += 2) {
+                    f32x2 t2;
+                    asm volatile("v_pk_mov_b32 %0, %1, %1" : "=v"(t2) : "v"(negm));
+                    sm[r] = t2.x;
+                    sm[r + 1] = t2.y;
+                }
+            }
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 float4 kn2 = kn;
