@@ -46,21 +46,41 @@ extern "C" {
 #define SDPA_ENOMEM   -5   /* device or pinned-host allocation failed                */
 #define SDPA_EUNSUP   -6   /* shape not supported by this build                      */
 
-/* flags for sdpa_attention_f64 */
-#define SDPA_F_DEFAULT     0
-#define SDPA_F_NO_PIPELINE 1   /* one Q batch, no copy/compute overlap (debug)     */
-#define SDPA_F_BF16        2   /* bf16-input MFMA path (fp32 accumulate/softmax);  */
-                               /* also selected by $SDPA_PRECISION=bf16            */
+/* flags for sdpa_attention_f64 / sdpa_prepare */
+#define SDPA_F_DEFAULT         0
+#define SDPA_F_NO_PIPELINE     1   /* one Q batch, one K/V chunk, no overlap (debug)            */
+#define SDPA_F_BF16            2   /* bf16-input MFMA path (fp32 accumulate/softmax);           */
+                                   /* also selected by $SDPA_PRECISION=bf16                     */
+#define SDPA_F_PLAN_QROWS      4   /* multi-GPU plan: shard the QUERY rows, replicate K/V, no   */
+                                   /* merge collective (rows are independent, attention.c:28);  */
+                                   /* also $SDPA_PLAN=qrows.  Default: K/V rows sharded         */
+                                   /* (attention-mpi.c:19-27) + the merge of :340-380           */
+#define SDPA_F_MERGE_ALLREDUCE 8   /* K/V plan: the reference's literal two-phase merge,        */
+                                   /* all-reduce(MAX) + all-reduce(SUM) (attention-mpi.c:342,   */
+                                   /* :354); also $SDPA_MERGE=allreduce.  Default: ONE          */
+                                   /* all-gather of the (lmax,lsum) pairs -- same algebra       */
 
-/* Per-call wall-clock breakdown of the last sdpa_attention_f64(), microseconds. */
+/* Breakdown of the last sdpa_attention_f64(), microseconds.  The call only ENQUEUES work and
+ * waits once at the end, so the stage figures are device-side intervals (HIP events on GPU 0)
+ * and they overlap each other; total_us is the host wall clock of the call.                    */
 struct sdpa_timing {
-    double total_us;      /* entry -> exit of sdpa_attention_f64                   */
-    double kv_stage_us;   /* K/V host->device copy + fp64->fp32 convert (all GPUs)  */
-    double pipeline_us;   /* Q batches: H2D, kernels, merge collectives, D2H        */
-    double kernel_us;     /* sum of fused-kernel time on GPU 0 (HIP events)         */
-    int    n_gpus;        /* GPUs the call used                                     */
-    int    q_batches;     /* Q batches the pipeline ran                             */
-    int    kv_splits;     /* in-GPU K/V splits the fused kernel used                */
+    double total_us;      /* entry -> exit of sdpa_attention_f64 (host clock)                   */
+    double kv_stage_us;   /* first H2D -> last K/V chunk converted (runs UNDER the kernels)     */
+    double pipeline_us;   /* first fused kernel start -> last result byte on the host           */
+    double kernel_us;     /* sum of fused-kernel launch durations on GPU 0                      */
+    int    n_gpus;        /* ranks the call used (GPUs, or virtual ranks)                       */
+    int    q_batches;     /* Q batches the pipeline ran                                         */
+    int    kv_splits;     /* in-GPU K/V splits of the last fused launch                         */
+    /* -- fields added in 0.2 (appended: older readers of the struct stay valid) -------------- */
+    double register_us;   /* page-locking the caller's arrays (host clock, inside total_us)     */
+    double head_us;       /* entry -> first fused kernel starts (what is NOT overlapped at the  */
+                          /* front: registration, Q batch 0 and K/V chunk 0 over PCIe)          */
+    double tail_us;       /* last fused kernel ends -> exit (merge, collectives, last D2H)      */
+    int    kv_chunks;     /* K/V chunks the first Q batch streamed through (1 = not streamed)   */
+    int    fused_launches;/* fused-kernel launches on GPU 0                                     */
+    int    plan;          /* 0 = K/V rows sharded, 1 = query rows sharded                       */
+    int    merge;         /* 0 = none (one rank), 1 = all-gather, 2 = two all-reduces           */
+    int    virtual_ranks; /* 1 = the ranks are loopback ranks on one device                     */
 };
 
 /* ---- lifecycle ---------------------------------------------------------- */
@@ -68,8 +88,19 @@ struct sdpa_timing {
 /* Create the engine on `n_gpus` devices (0 = every visible device).  Separate
  * from the compute call so a bench can keep one-time HIP/RCCL start-up out of
  * the timed region (the reference's timer brackets attention() itself,
- * attention.c:179-182).  sdpa_attention_f64() calls it lazily with
- * $SDPA_GPUS (default 0) when it has not been called.                        */
+ * attention.c:179-182).  sdpa_attention_f64() calls it lazily with $SDPA_GPUS
+ * when it has not been called; WITHOUT $SDPA_GPUS the lazy default is ONE GPU:
+ * driving several GPUs from this process is opt-in ($SDPA_GPUS=8, or =0 / =all
+ * for every visible device).
+ * $SDPA_VIRTUAL_GPUS=P makes the engine P logical ranks that all live on
+ * device 0 (own streams and buffers each, loopback collectives): the P > 1
+ * pipeline on a one-GPU machine.  $SDPA_FORCE_COLLECTIVES=1 runs the merge
+ * collectives even with one rank (a one-rank RCCL communicator).
+ *
+ * Threading: the engine is one process-wide object; the host-level entry
+ * points are NOT thread-safe and not re-entrant (the reference's caller is
+ * single-threaded, attention.c:179-182).  They restore the calling thread's
+ * current HIP device before returning.                                        */
 SDPA_API int sdpa_init(int n_gpus);
 SDPA_API void sdpa_shutdown(void);
 SDPA_API int sdpa_device_count(void);          /* visible HIP devices, <0 on error */
@@ -85,8 +116,14 @@ SDPA_API const char *sdpa_version(void);
  * Compute is fp32 (fp64 inputs rounded to nearest-even as cvt_d2f_avx512,
  * attention-mpi.c:31-64; scale = 1/sqrtf((float)dk), :208), output widened to
  * fp64 (:373,:396).  K/V rows are sharded over the engine's GPUs with
- * owner_count/owner_disp (:19-27) and merged with all-reduce(MAX),
- * all-reduce(SUM) and reduce(SUM) as :340-380.                               */
+ * owner_count/owner_disp (:19-27) and merged with the algebra of :340-380
+ * (flags choose the collective schedule).  The first Q batch streams the K/V
+ * shard host->device in chunks and starts computing on chunk 0.
+ * Numerical range: the kernels rescale their accumulators lazily (only when a
+ * row maximum rises by more than 2^24 in the fp32 kernels, 2^32 in the bf16
+ * wide kernel), which spends that much of fp32's exponent headroom: the
+ * un-normalised contrib of a row overflows for |V|*n above ~2^104 (fp32) /
+ * ~2^96 (bf16 wide), where the reference's eager rescale would not.          */
 SDPA_API int sdpa_attention_f64(const double *Q, const double *K, const double *V,
                                 double *result, int m, int n, int dk, int dv,
                                 int flags);

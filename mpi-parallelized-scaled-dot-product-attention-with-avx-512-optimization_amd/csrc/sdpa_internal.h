@@ -25,8 +25,12 @@ struct PartialArgs {
     int ws_ld;                     // row stride of ws_contrib = dv rounded up to 4
     float *ws_lmax;                // [kv_splits x m]
     float *ws_lsum;                // [kv_splits x m]
-    int tune;                      // $SDPA_TUNE: 4 = register-staged kernel instead of the pipelined one,
-                                   // 16/32/64 (+combinations) = timing-only ablations; 0 = shipped default
+    long ws_rows;                  // rows between two slots of the ws arrays (0 = m): lets a launch over a
+                                   // sub-range of rows write into the slots of a larger batch
+    int defer_merge;               // 1 = leave the kv_splits partial triples in the ws slots (the host
+                                   // pipeline merges the slots of all its K/V chunks in one pass)
+    int tune;                      // -DSDPA_ABLATIONS builds only ($SDPA_TUNE): 4 = register-staged kernel
+                                   // instead of the pipelined one, 16/32/64 = timing-only ablations
 };
 
 // bf16 variant: Q,K row-major bf16 (ld = dk padded to 64/128/256/512, pad columns zero),
@@ -44,6 +48,8 @@ struct Bf16Args {
     float *ws_contrib;  int ws_ld;
     float *ws_lmax;
     float *ws_lsum;
+    long ws_rows;                  // as PartialArgs::ws_rows
+    int defer_merge;               // as PartialArgs::defer_merge
     int *redo;                     // [kv_splits x q blocks] flags, dv > 256 only (bf16_carve_workspace)
     int redo_gen;                  // a flag counts when it equals this launch's generation (set by the
                                    // launcher): nothing has to be cleared, stale or uninitialised
@@ -66,6 +72,10 @@ hipError_t launch_shard_partial_bf16(const Bf16Args &a, hipStream_t s);
 hipError_t launch_cvt_d2bf(const double *src, unsigned short *dst, long rows, int cols, int ld, hipStream_t s);
 hipError_t launch_cvt_d2bf_t(const double *src, unsigned short *dst, long rows, int cols, int cols_pad,
                              long ldt, hipStream_t s);
+// the same for `rows` keys that land at dst (a column offset into a larger Vt image of row stride
+// ldt): zero-fills key positions [rows, rows_pad) only
+hipError_t launch_cvt_d2bf_t_part(const double *src, unsigned short *dst, long rows, long rows_pad, int cols,
+                                  int cols_pad, long ldt, hipStream_t s);
 hipError_t launch_split_merge(const PartialArgs &a, hipStream_t s);
 
 int  pick_kv_splits(int m, int n_local, int dk, int dv);

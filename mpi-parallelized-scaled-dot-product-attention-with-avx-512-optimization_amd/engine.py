@@ -55,12 +55,18 @@ def shutdown():
     _lib.load().sdpa_shutdown()
 
 
-def attention(Q, K, V, flags=0, precision=None):
+def attention(Q, K, V, flags=0, precision=None, plan=None, merge=None):
     """result = softmax(Q K^T / sqrt(dk)) V; numpy fp64 [m,dk],[n,dk],[n,dv] -> [m,dv].
-    precision="bf16" selects the bf16-input MFMA path (flag SDPA_F_BF16)."""
+    precision="bf16" selects the bf16-input MFMA path (flag SDPA_F_BF16); plan="qrows" shards the
+    query rows over the engine's ranks instead of the K/V rows; merge="allreduce" is the
+    reference's literal two-phase merge (default: one all-gather of the (lmax, lsum) pairs)."""
     lib = _lib.load()
     if precision == "bf16":
         flags |= _lib.SDPA_F_BF16
+    if plan == "qrows":
+        flags |= _lib.SDPA_F_PLAN_QROWS
+    if merge == "allreduce":
+        flags |= _lib.SDPA_F_MERGE_ALLREDUCE
     Q = np.ascontiguousarray(Q, dtype=np.float64)
     K = np.ascontiguousarray(K, dtype=np.float64)
     V = np.ascontiguousarray(V, dtype=np.float64)

@@ -11,6 +11,11 @@
  * /root/reference/attention.c into oracle/_ref/, see oracle/Makefile) on every
  * fixture in tests/golden/ (tests/test_oracle.py), and the fixtures themselves
  * were produced by that reference build (oracle/make_golden.py).
+ * oracle_attention_sharded_f32() -- the fp32 K/V-sharded pipeline -- is checked
+ * bit-for-bit against raw outputs of the reference's own MPI program
+ * (attention-mpi.c unmodified, documented build flags, mpiexec -n 1/2/8,
+ * oracle/ref_mpi_dump.c + oracle/make_ref_mpi_fp32.py ->
+ * tests/golden/ref_mpi_fp32/).
  *
  * Every function cites the reference lines it restates; paths are relative to
  * /root/reference.
@@ -94,14 +99,44 @@ void oracle_cvt_f2d(double *dst, const float *src, size_t count)
 }
 
 /* ------------------------------------------------------------------------- */
+/* dot_avx512, attention-mpi.c:103-121, lane for lane in plain C: four         */
+/* accumulators of 16 fp32 lanes fed by FMAs over 64-element strides, a        */
+/* 16-wide clean-up loop and a masked tail into accumulator 0 (:109-119),      */
+/* (acc0+acc1)+(acc2+acc3) per lane, then _mm512_reduce_add_ps -- gcc's        */
+/* avx512fintrin.h reduces 16 -> 8 -> 4 -> 2 -> 1 by adding the upper half to  */
+/* the lower half each time.  fmaf() is the one-rounding FMA of                */
+/* _mm512_fmadd_ps, so the result is bit-identical to the reference's.         */
+/* ------------------------------------------------------------------------- */
+static float oracle_dot_lanes(const float *a, const float *b, int n)
+{
+    float acc[4][16];
+    for (int g = 0; g < 4; ++g)
+        for (int l = 0; l < 16; ++l) acc[g][l] = 0.0f;
+    int i = 0;
+    for (; i + 63 < n; i += 64)
+        for (int g = 0; g < 4; ++g)
+            for (int l = 0; l < 16; ++l)
+                acc[g][l] = fmaf(a[i + 16 * g + l], b[i + 16 * g + l], acc[g][l]);
+    for (; i + 15 < n; i += 16)
+        for (int l = 0; l < 16; ++l) acc[0][l] = fmaf(a[i + l], b[i + l], acc[0][l]);
+    for (int l = 0; l < n - i; ++l) acc[0][l] = fmaf(a[i + l], b[i + l], acc[0][l]);
+    float v[16];
+    for (int l = 0; l < 16; ++l) v[l] = (acc[0][l] + acc[1][l]) + (acc[2][l] + acc[3][l]);
+    for (int l = 0; l < 8; ++l) v[l] = v[l + 8] + v[l];
+    for (int l = 0; l < 4; ++l) v[l] = v[l + 4] + v[l];
+    for (int l = 0; l < 2; ++l) v[l] = v[l] + v[l + 2];
+    return v[0] + v[1];
+}
+
+/* ------------------------------------------------------------------------- */
 /* One query row against one K/V shard, streaming online softmax:             */
 /* attention-mpi.c:168-189.  Returns the UN-normalised contribution and the   */
 /* shard-local (max, sum).  rmax starts at -inf (:172), contrib is zeroed     */
-/* (:173), the running rescale is applied for every j>0 (:181).               */
-/* The dot product is a plain t-ascending fp32 FMA-free loop; the reference   */
-/* splits it over 64 AVX-512 partial sums (:103-121), which is not            */
-/* reproducible off AVX-512 hardware, so fp32 parity is tolerance based       */
-/* (SURVEY.md section 8c).                                                    */
+/* (:173), the running rescale is applied for every j>0 (:181, a plain        */
+/* multiply, memset_zero_scale :142-166), the accumulate is one FMA per        */
+/* element (axpy_avx512 :123-140).  Operation for operation the reference's:  */
+/* tests/test_oracle.py checks it BIT FOR BIT against outputs of the          */
+/* reference's own MPI program (tests/golden/ref_mpi_fp32/).                  */
 /* ------------------------------------------------------------------------- */
 void oracle_online_row_f32(float *contrib, float *lmax, float *lsum,
                            const float *q, const float *Kloc, const float *Vloc,
@@ -110,18 +145,15 @@ void oracle_online_row_f32(float *contrib, float *lmax, float *lsum,
     float run_max = -INFINITY, run_sum = 0.0f;
     for (int d = 0; d < dv; ++d) contrib[d] = 0.0f;
     for (int j = 0; j < n_local; ++j) {
-        const float *k = Kloc + (size_t)j * dk;
-        float acc = 0.0f;
-        for (int t = 0; t < dk; ++t) acc += q[t] * k[t];
-        float s = acc * scale;                             /* :176 */
+        float s = oracle_dot_lanes(q, Kloc + (size_t)j * dk, dk) * scale;   /* :176 */
         float prev = run_max;
         if (s > run_max) run_max = s;                      /* :178 */
         float fix = expf(prev - run_max);                  /* :179 */
         float p = expf(s - run_max);
         run_sum = run_sum * fix + p;                       /* :180 */
         const float *v = Vloc + (size_t)j * dv;
-        if (j > 0) for (int d = 0; d < dv; ++d) contrib[d] *= fix;   /* :181 */
-        for (int d = 0; d < dv; ++d) contrib[d] += p * v[d];        /* :182 */
+        if (j > 0) for (int d = 0; d < dv; ++d) contrib[d] *= fix;          /* :181 */
+        for (int d = 0; d < dv; ++d) contrib[d] = fmaf(p, v[d], contrib[d]); /* :182 */
     }
     *lmax = run_max;
     *lsum = run_sum;
@@ -136,10 +168,20 @@ void oracle_online_row_f32(float *contrib, float *lmax, float *lsum,
 /*     corr = expf(lmax-gmax), lsum*=corr, contrib*=corr (:346-351);          */
 /*     gsum = sum_r lsum (:354); inv = gsum==0 ? 0 : 1/gsum, contrib*=inv     */
 /*     (:358-362); result = sum_r contrib (:380), widened to fp64 (:373,:396) */
-/* The MPI reduction order is implementation defined; here it is rank         */
-/* ascending.                                                                 */
+/* The MPI reduction order is implementation defined; both sums here use the  */
+/* pairwise tree of MPICH's recursive doubling / binomial reduce              */
+/* (((0+1)+(2+3))+((4+5)+(6+7)) for 8 ranks), which is what the fixtures of   */
+/* tests/golden/ref_mpi_fp32/ were produced with (MPICH 3.3.2).               */
 /* scale = 1/sqrtf((float)dk) (:208).                                         */
 /* ------------------------------------------------------------------------- */
+static float tree_sum(const float *x, int stride, int lo, int hi)   /* ranks [lo, hi) */
+{
+    if (hi - lo == 1) return x[(size_t)lo * stride];
+    int half = 1;
+    while (half * 2 < hi - lo) half *= 2;
+    return tree_sum(x, stride, lo, lo + half) + tree_sum(x, stride, lo + half, hi);
+}
+
 void oracle_attention_sharded_f32(const double *Q, const double *K, const double *V,
                                   double *result, int m, int n, int dk, int dv,
                                   int parts)
@@ -168,17 +210,16 @@ void oracle_attention_sharded_f32(const double *Q, const double *K, const double
             }
             float gmax = pmax[0];
             for (int r = 1; r < parts; ++r) if (pmax[r] > gmax) gmax = pmax[r];
-            float gsum = 0.0f;
             for (int r = 0; r < parts; ++r) {
-                float fix = expf(pmax[r] - gmax);
+                float fix = expf(pmax[r] - gmax);          /* :347 */
                 psum[r] *= fix;
                 for (int d = 0; d < dv; ++d) part[(size_t)r * dv + d] *= fix;
-                gsum += psum[r];
             }
+            float gsum = tree_sum(psum, 1, 0, parts);      /* :354 */
             float inv = (gsum == 0.0f) ? 0.0f : 1.0f / gsum;
-            for (int d = 0; d < dv; ++d) tot[d] = 0.0f;
             for (int r = 0; r < parts; ++r)
-                for (int d = 0; d < dv; ++d) tot[d] += part[(size_t)r * dv + d] * inv;
+                for (int d = 0; d < dv; ++d) part[(size_t)r * dv + d] *= inv;   /* :358-362 */
+            for (int d = 0; d < dv; ++d) tot[d] = tree_sum(part + d, dv, 0, parts);   /* :380 */
             oracle_cvt_f2d(result + (size_t)i * dv, tot, (size_t)dv);
         }
         free(qf); free(part); free(pmax); free(psum); free(tot);

@@ -1,0 +1,196 @@
+"""GPU (-m gpu): the host-level pipeline of sdpa_attention_f64 (csrc/sdpa_host.hip) -- K/V chunk
+streaming, the pieces of the last batch, and the P > 1 choreography of attention-mpi.c:340-399 run
+on ONE device through loopback ranks (SDPA_VIRTUAL_GPUS=P), plus the real RCCL calls on a one-rank
+communicator (SDPA_FORCE_COLLECTIVES=1).
+
+Tolerance: max|got - fp64 oracle| <= 5e-5 * max(1, max|V|) for fp32
+compute, 1e-2 * max(1, max|V|) for the bf16 path; NaN/Inf anywhere fails."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import fp32_tol
+
+pytestmark = pytest.mark.gpu
+
+
+def check(got, want, V, what="", tol=None):
+    tol = fp32_tol(V) if tol is None else tol
+    assert got.shape == want.shape
+    assert np.isfinite(got).all(), what + ": non-finite values"
+    err = np.abs(got - want).max()
+    assert err <= tol, "%s: max|err| %.3e > %.3e" % (what, err, tol)
+    return err
+
+
+@pytest.fixture
+def engine(pkg, monkeypatch):
+    """re-creates the engine with the environment a test asks for, and puts the default
+    one-GPU engine back afterwards"""
+    assert torch.cuda.is_available(), "the -m gpu tests need a real MI355X"
+
+    def make(**env):
+        pkg.shutdown()
+        for k in ("SDPA_VIRTUAL_GPUS", "SDPA_FORCE_COLLECTIVES", "SDPA_QBATCH", "SDPA_KV_CHUNK_MIN",
+                  "SDPA_KV_CHUNK_MAX", "SDPA_TAIL_SPLIT", "SDPA_PLAN", "SDPA_MERGE", "SDPA_PRECISION"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, str(v))
+        pkg.init(1)
+        return pkg
+
+    yield make
+    pkg.shutdown()
+    for k in ("SDPA_VIRTUAL_GPUS", "SDPA_FORCE_COLLECTIVES"):
+        monkeypatch.delenv(k, raising=False)
+    pkg.init(1)
+
+
+# ---------------------------------------------------------------- K/V chunk streaming ---------
+@pytest.mark.parametrize("m,n,dk,dv,dist,prec", [
+    (700, 9000, 128, 128, "D2", None),      # pipelined kernel, ragged rows and last chunk
+    (513, 7000, 64, 64, "D4", None),        # late spike key sits in the last chunk
+    (300, 5000, 72, 40, "D3", None),        # register-staged kernel (padded dims), peaky
+    (200, 6000, 300, 96, "D2", None),       # dk-split kernel
+    (700, 9000, 128, 128, "D2", "bf16"),    # bf16 pipe kernel: chunks of the transposed Vt image
+    (260, 5000, 512, 512, "D1", "bf16"),    # bf16 wide kernel (redo flags live beside the slots)
+])
+def test_kv_chunk_streaming_matches_oracle(m, n, dk, dv, dist, prec, engine, orc, O):
+    """the first Q batch starts on K/V chunk 0 while the later chunks are still crossing PCIe; the
+    partial triples of all chunks and in-launch splits are merged in one pass; the last chunk runs
+    in pieces whose finish + D2H overlap the next piece's kernel"""
+    pkg = engine(SDPA_KV_CHUNK_MIN=1024, SDPA_KV_CHUNK_MAX=2048)
+    Q, K, V = O.make_inputs(m, n, dk, dv, dist, seed=m + n)
+    want = orc.attention_f64(Q, K, V)
+    tol = 1e-2 * max(1.0, float(np.abs(V).max())) if prec == "bf16" else None
+    got = pkg.attention(Q, K, V, precision=prec)
+    t = pkg.last_timing()
+    assert t["kv_chunks"] >= 3 and t["q_batches"] == 1, t
+    assert t["fused_launches"] >= t["kv_chunks"], t            # last chunk in >= 1 pieces
+    check(got, want, V, "streamed", tol)
+    # same problem, nothing streamed and nothing cut in pieces: must agree to rounding
+    got1 = pkg.attention(Q, K, V, flags=1, precision=prec)      # SDPA_F_NO_PIPELINE
+    t1 = pkg.last_timing()
+    assert t1["kv_chunks"] == 1 and t1["fused_launches"] == 1, t1
+    check(got1, want, V, "unstreamed", tol)
+    assert np.abs(got - got1).max() <= (tol if tol else 2 * fp32_tol(V))
+    # several Q batches on top: batch 0 streams, the later ones run on the resident shard
+    pkg = engine(SDPA_KV_CHUNK_MIN=1024, SDPA_KV_CHUNK_MAX=2048, SDPA_QBATCH=256)
+    got2 = pkg.attention(Q, K, V, precision=prec)
+    t2 = pkg.last_timing()
+    assert t2["q_batches"] == (m + 255) // 256 and t2["kv_chunks"] >= 3
+    check(got2, want, V, "streamed + batches", tol)
+
+
+def test_streaming_is_deterministic(engine, O):
+    pkg = engine(SDPA_KV_CHUNK_MIN=1024, SDPA_KV_CHUNK_MAX=4096)
+    Q, K, V = O.make_inputs(1024, 12000, 128, 128, "D2", seed=4)
+    a = pkg.attention(Q, K, V)
+    for _ in range(5):
+        assert np.array_equal(pkg.attention(Q, K, V), a), "same inputs must give bit-identical results"
+
+
+def test_tail_pieces_cover_ragged_rows(engine, orc, O):
+    """pieces of the last batch are whole query blocks; the last piece is ragged"""
+    for m in (129, 1000, 1025):
+        for pieces in (1, 4, 8):
+            pkg = engine(SDPA_TAIL_SPLIT=pieces, SDPA_KV_CHUNK_MIN=1024, SDPA_KV_CHUNK_MAX=1024)
+            Q, K, V = O.make_inputs(m, 3000, 64, 64, "D2", seed=m)
+            check(pkg.attention(Q, K, V), orc.attention_f64(Q, K, V), V, "m=%d pieces=%d" % (m, pieces))
+
+
+# ---------------------------------------------------------------- P > 1 on one device ---------
+CASES_P = [
+    # m,   n,    dk,  dv, dist, qbatch
+    (96,  1000,  64,  64, "D4", 0),       # late spike key: the running max jumps in the LAST shard
+    (64,     5,  16,  16, "D2", 0),       # n < P: empty shards (attention-mpi.c:172-173)
+    (1000, 600,  64,  64, "D2", 192),     # 6 batches, ragged last one
+    (300, 4100, 128, 128, "D3", 128),     # peaky, pipelined kernel, 3 batches
+    (130,  700, 300,  72, "D2", 0),       # dk-split kernel
+]
+
+
+@pytest.mark.parametrize("P", [2, 3, 8])
+@pytest.mark.parametrize("merge", ["gather", "allreduce"])
+def test_virtual_ranks_kv_sharded(P, merge, engine, orc, O):
+    """the C host's P > 1 branch (attention-mpi.c:340-399): owner_count/owner_disp shards, per-rank
+    fused launches, all-gather or all-reduce(MAX)+all-reduce(SUM), reduce(SUM) to rank 0 -- vs the
+    fp64 oracle and vs the restated fp32 pipeline of the reference at the same P"""
+    for (m, n, dk, dv, dist, qb) in CASES_P:
+        env = dict(SDPA_VIRTUAL_GPUS=P, SDPA_KV_CHUNK_MIN=1024, SDPA_KV_CHUNK_MAX=1024)
+        if qb:
+            env["SDPA_QBATCH"] = qb
+        pkg = engine(**env)
+        Q, K, V = O.make_inputs(m, n, dk, dv, dist, seed=P + m)
+        want = orc.attention_f64(Q, K, V)
+        got = pkg.attention(Q, K, V, merge=merge)
+        t = pkg.last_timing()
+        assert t["n_gpus"] == P and t["virtual_ranks"] == 1 and t["plan"] == 0
+        assert t["merge"] == (1 if merge == "gather" else 2)
+        if qb:
+            assert t["q_batches"] == (m + qb - 1) // qb
+        check(got, want, V, "P=%d %s %s" % (P, merge, (m, n, dk, dv, dist)))
+        ref32 = orc.attention_sharded_f32(Q, K, V, P)
+        assert np.abs(got - ref32).max() <= 2 * fp32_tol(V), "vs the reference's fp32 pipeline at P=%d" % P
+
+
+@pytest.mark.parametrize("P", [2, 3, 8])
+def test_virtual_ranks_qrow_sharded(P, engine, orc, O):
+    """SDPA_PLAN=qrows in the C host (attention-mpi.c:307-338 rows are independent): every rank
+    holds all of K/V and finishes its own slice of the query rows; no collective"""
+    for (m, n, dk, dv, dist, qb) in [(100, 900, 64, 64, "D2", 0), (5, 300, 32, 32, "D1", 0),
+                                      (1000, 2500, 128, 128, "D3", 96)]:
+        env = dict(SDPA_VIRTUAL_GPUS=P, SDPA_KV_CHUNK_MIN=1024, SDPA_KV_CHUNK_MAX=1024)
+        if qb:
+            env["SDPA_QBATCH"] = qb
+        pkg = engine(**env)
+        Q, K, V = O.make_inputs(m, n, dk, dv, dist, seed=3 * P + m)
+        got = pkg.attention(Q, K, V, plan="qrows")
+        t = pkg.last_timing()
+        assert t["plan"] == 1 and t["merge"] == 0 and t["n_gpus"] == P
+        check(got, orc.attention_f64(Q, K, V), V, "qrows P=%d m=%d" % (P, m))
+
+
+def test_virtual_ranks_bf16(engine, orc, O):
+    pkg = engine(SDPA_VIRTUAL_GPUS=3, SDPA_KV_CHUNK_MIN=1024, SDPA_KV_CHUNK_MAX=1024, SDPA_QBATCH=256)
+    for (m, n, d) in [(600, 5000, 128), (130, 4, 64), (260, 3100, 512)]:
+        Q, K, V = O.make_inputs(m, n, d, d, "D2", seed=m)
+        got = pkg.attention(Q, K, V, precision="bf16")
+        check(got, orc.attention_f64(Q, K, V), V, "bf16 P=3 %s" % ((m, n, d),), 1e-2 * max(1.0, float(np.abs(V).max())))
+
+
+def test_rccl_calls_on_a_one_rank_communicator(engine, orc, O):
+    """SDPA_FORCE_COLLECTIVES=1: the merge branch with the REAL RCCL entry points (dlopen'd
+    ncclCommInitAll / ncclAllGather / ncclAllReduce / ncclReduce, grouped) on a communicator of
+    one rank -- argument order, datatypes and stream ordering of sdpa_coll.hip's RCCL side"""
+    pkg = engine(SDPA_FORCE_COLLECTIVES=1, SDPA_QBATCH=300)
+    Q, K, V = O.make_inputs(1000, 3000, 128, 128, "D2", seed=21)
+    want = orc.attention_f64(Q, K, V)
+    for merge, code in (("gather", 1), ("allreduce", 2)):
+        got = pkg.attention(Q, K, V, merge=merge)
+        t = pkg.last_timing()
+        assert t["merge"] == code and t["n_gpus"] == 1 and t["virtual_ranks"] == 0 and t["q_batches"] == 4
+        check(got, want, V, "rccl one rank, " + merge)
+
+
+def test_engine_restores_the_callers_device_and_survives_reinit(engine, O, orc):
+    pkg = engine()
+    torch.cuda.set_device(0)
+    Q, K, V = O.make_inputs(64, 256, 32, 32, "D1", seed=1)
+    want = orc.attention_f64(Q, K, V)
+    for env in ({"SDPA_VIRTUAL_GPUS": 2}, {}, {"SDPA_VIRTUAL_GPUS": 5}, {}):
+        pkg = engine(**env)
+        check(pkg.attention(Q, K, V), want, V, str(env))
+        assert torch.cuda.current_device() == 0
+        assert pkg.last_timing()["n_gpus"] == int(env.get("SDPA_VIRTUAL_GPUS", 1))
+
+
+def test_tune_env_cannot_change_the_shipped_library(engine, O, orc, monkeypatch):
+    """$SDPA_TUNE selected timing-only ablation kernels in round 1; the shipped build must ignore it"""
+    monkeypatch.setenv("SDPA_TUNE", "112")
+    pkg = engine()
+    Q, K, V = O.make_inputs(300, 2000, 128, 128, "D2", seed=2)
+    check(pkg.attention(Q, K, V), orc.attention_f64(Q, K, V), V, "SDPA_TUNE=112")
+    Q, K, V = O.make_inputs(130, 1000, 512, 512, "D1", seed=2)
+    monkeypatch.setenv("SDPA_TUNE", str(15 << 8))
+    check(pkg.attention(Q, K, V, precision="bf16"), orc.attention_f64(Q, K, V), V, "SDPA_TUNE bf16", 1e-2 * max(1.0, float(np.abs(V).max())))

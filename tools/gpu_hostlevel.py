@@ -1,20 +1,70 @@
-"""Boundary (host fp64 in / out) timing of sdpa_attention_f64 at a named shape."""
-import importlib, os, sys, time, json
+"""Boundary (host fp64 in / out) timing of sdpa_attention_f64 at named shapes, optionally swept
+over the pipeline's environment knobs (read per call):
+    python tools/gpu_hostlevel.py headline config2 --sweep
+Each line: shape, knobs, then the stage breakdown of the best of 5 warm calls."""
+import importlib, os, sys, time, json, ctypes
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("mpi-parallelized-scaled-dot-product-attention-with-avx-512-optimization_amd")
 shapes = {"headline": (32768, 65536, 128), "config2": (8192, 8192, 128), "config1": (512, 512, 64),
-          "config4": (131072, 65536, 128), "config5": (32768, 65536, 512)}
-pkg.init(0)
-for name in sys.argv[1:] or ["headline", "config2", "config1"]:
+          "config3": (32768, 262144, 128), "config4": (131072, 65536, 128), "config5": (32768, 65536, 512)}
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+sweep = "--sweep" in sys.argv
+pinned = "--pinned" in sys.argv
+lib = pkg.load()
+pkg.init(1)
+KNOBS = ("SDPA_QBATCH", "SDPA_KV_CHUNK_MIN", "SDPA_KV_CHUNK_MAX", "SDPA_TAIL_SPLIT", "SDPA_HOST_REGISTER")
+SWEEP = [{},
+         {"SDPA_TAIL_SPLIT": 1},
+         {"SDPA_TAIL_SPLIT": 8},
+         {"SDPA_KV_CHUNK_MIN": 2048},
+         {"SDPA_KV_CHUNK_MIN": 8192},
+         {"SDPA_KV_CHUNK_MAX": 8192},
+         {"SDPA_KV_CHUNK_MAX": 32768},
+         {"SDPA_KV_CHUNK_MAX": 65536},
+         {"SDPA_QBATCH": 16384},
+         {"SDPA_QBATCH": 8192},
+         {"SDPA_KV_CHUNK_MIN": 1 << 20, "SDPA_TAIL_SPLIT": 1},     # round-1 structure: nothing streamed
+         ]
+
+
+def hostbuf(a):
+    if not pinned:
+        return a, None
+    ptr = lib.sdpa_host_alloc(a.nbytes)
+    v = np.ctypeslib.as_array((ctypes.c_double * a.size).from_address(ptr)).reshape(a.shape)
+    v[...] = a
+    return v, ptr
+
+
+for name in args or ["headline", "config2", "config1"]:
     prec = "bf16" if name.endswith(":bf16") else None     # e.g. config5:bf16
     m, n, d = shapes[name.split(":")[0]]
     rng = np.random.default_rng(0)
     Q, K, V = (rng.uniform(-1, 1, s) for s in ((m, d), (n, d), (n, d)))
-    best = None
-    for it in range(4):
-        t0 = time.perf_counter(); pkg.attention(Q, K, V, precision=prec); dt = time.perf_counter() - t0
-        t = pkg.last_timing(); t["wall_s"] = dt
-        if it and (best is None or t["total_us"] < best["total_us"]): best = t
-    print(name, json.dumps(best))
+    (Q, pq), (K, pk), (V, pv) = hostbuf(Q), hostbuf(K), hostbuf(V)
+    R, pr = hostbuf(np.zeros((m, d)))
+    flags = 2 if prec else 0
+    for knobs in (SWEEP if sweep else [{}]):
+        for k in KNOBS:
+            os.environ.pop(k, None)
+        for k, v in knobs.items():
+            os.environ[k] = str(v)
+        best = None
+        for it in range(6):
+            t0 = time.perf_counter()
+            rc = lib.sdpa_attention_f64(Q.ctypes.data, K.ctypes.data, V.ctypes.data, R.ctypes.data, m, n, d, d, flags)
+            dt = time.perf_counter() - t0
+            assert rc == 0, rc
+            t = pkg.last_timing(); t["wall_ms"] = dt * 1e3
+            if it and (best is None or t["total_us"] < best["total_us"]): best = t
+        row = {"shape": name, "pinned": pinned, "knobs": knobs}
+        for k in ("total_us", "head_us", "tail_us", "register_us", "kv_stage_us", "pipeline_us", "kernel_us"):
+            row[k.replace("_us", "_ms")] = round(best[k] / 1e3, 3)
+        for k in ("q_batches", "kv_chunks", "fused_launches", "kv_splits"):
+            row[k] = best[k]
+        row["kernel_tflops"] = round(4.0 * m * n * d / (best["kernel_us"] * 1e-6) / 1e12, 1)
+        print(json.dumps(row), flush=True)
+    for p in (pq, pk, pv, pr):
+        if p: lib.sdpa_host_free(p)
