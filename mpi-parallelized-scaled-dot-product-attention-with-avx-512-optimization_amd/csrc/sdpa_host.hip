@@ -6,7 +6,8 @@
 //                                                            straight from the caller's arrays over
 //                                                            its own PCIe link, in chunks, and
 //                                                            converts on device; the first Q batch
-//                                                            starts computing on chunk 0
+//                                                            starts computing on chunk 0, itself
+//                                                            in row pieces as Q arrives
 //   attention-mpi.c:268-330  Q ping-pong + MPI_Ibcast      -> two Q slots per rank, copy stream one
 //                                                            batch ahead of the compute stream
 //                                                            (every rank reads the batch from host
@@ -42,7 +43,7 @@ using sdpa::PartialArgs;
 using sdpa::RedOp;
 using sdpa::round4;
 
-constexpr int kMaxSub = 8;        // pieces the last batch's finish + D2H is cut into
+constexpr int kMaxSub = 8;        // row pieces a batch is cut into at the front and at the back of a call
 
 struct DevBuf {
     void *p = nullptr;
@@ -62,15 +63,20 @@ int ensure(DevBuf &b, size_t bytes) {
 
 struct Rank {
     int dev = 0;                         // HIP device ordinal (loopback ranks share one)
-    hipStream_t s_in = nullptr, s_run = nullptr, s_out = nullptr;
-    DevBuf k64, v64;                     // fp64 staging of ONE K/V chunk
+    // s_cp: host->device copies only (never waits for a kernel: PCIe stays busy while the fused
+    // kernel holds every CU); s_in: the fp64->operand converts (high priority: they slip into the
+    // gap between two fused launches); s_run: fused kernels, merges, collectives; s_out: D2H
+    hipStream_t s_cp = nullptr, s_in = nullptr, s_run = nullptr, s_out = nullptr;
+    DevBuf k64, v64;                     // fp64 staging of the WHOLE shard (a copy never waits for a convert)
     DevBuf kf, vf;                       // operand image of the whole shard
     DevBuf ws;                           // the fused kernel's own scratch (splits of a direct launch, redo flags)
     DevBuf slots;                        // partial triples of the streamed batch: [slot][row][ldo] + 2 x [slot][row]
     DevBuf q64[2], qf[2], contrib[2], stat[2], gstat[2], red[2], out64[2];
     hipEvent_t ev_q[2] = {}, ev_run[2] = {}, ev_out[2] = {};
     hipEvent_t ev_sub[2][kMaxSub] = {};
-    std::vector<hipEvent_t> ev_kv;       // K/V chunk c is on the device and converted
+    hipEvent_t ev_qh[kMaxSub] = {}, ev_qp[kMaxSub] = {};   // Q piece j: copied / converted
+    std::vector<hipEvent_t> ev_h2d;      // K/V chunk c has crossed PCIe
+    std::vector<hipEvent_t> ev_kv;       // K/V chunk c is converted into the operand image
     std::vector<hipEvent_t> ev_k;        // fused-kernel timing brackets (rank 0)
     hipEvent_t ev_t0 = nullptr, ev_kv_done = nullptr, ev_end = nullptr;
 };
@@ -169,11 +175,19 @@ struct Plan {
     bool bf16, qrows, collectives, merge_allreduce;
     int P;
     int B, nb;                        // rows per Q batch, batches (over the largest row range)
-    int tail_split;                   // pieces of the last batch (1 = off)
+    int row_pieces, piece_min_rows;   // row pieces of the first / last batch (1 = off)
     int ldq, ldk, ldv, ldo;           // leading dimensions of the operand images (elements)
     size_t q_elem, kv_elem;
     std::vector<RankPlan> r;
 };
+
+int piece_rows_of(const Plan &pl, int bs) {
+    if (pl.row_pieces <= 1 || bs <= 0) return bs > 0 ? bs : 1;
+    int pr = (bs + pl.row_pieces - 1) / pl.row_pieces;
+    if (pr < pl.piece_min_rows) pr = pl.piece_min_rows;
+    pr = (pr + 127) / 128 * 128;
+    return pr >= bs ? bs : pr;
+}
 
 int pick_splits(const Plan &pl, int rows, int keys) {
     return pl.bf16 ? sdpa::pick_kv_splits_bf16(rows, keys, pl.dk, pl.dv)
@@ -206,12 +220,11 @@ std::vector<int> chunk_sizes(int cnt, int cmin, int cmax) {
     return out;
 }
 
-// rows per piece when the last batch (bs rows) is finished in `pieces` pieces: whole query blocks
-int piece_rows_of(int bs, int pieces) {
-    int pr = (bs + pieces - 1) / pieces;
-    pr = (pr + 127) / 128 * 128;
-    return pr < 128 ? 128 : pr;
-}
+// Row pieces.  The first batch's Q crosses PCIe in pieces and its FIRST K/V chunk is launched
+// piece by piece as they land; the last batch's LAST chunk is launched piece by piece so that the
+// merge, finish and D2H of piece j run under the kernel of piece j+1.  Everything in between runs
+// full-row launches (the fused kernel's best shape).  A piece is whole query blocks (128 rows).
+int piece_rows_of(const struct Plan &pl, int bs);
 
 bool want_bf16(int flags) {
     bool bf16 = (flags & SDPA_F_BF16) != 0;
@@ -249,7 +262,9 @@ void make_plan(Plan &pl, int m, int n, int dk, int dv, int flags) {
     int cmin = env_int("SDPA_KV_CHUNK_MIN", 4096), cmax = env_int("SDPA_KV_CHUNK_MAX", 16384);
     cmin = std::max(1024, cmin / 1024 * 1024);
     cmax = std::max(cmin, cmax / 1024 * 1024);
-    pl.tail_split = std::min(kMaxSub, env_int("SDPA_TAIL_SPLIT", 4));
+    pl.row_pieces = std::min(kMaxSub, env_int("SDPA_ROW_PIECES", 4));
+    // a piece narrower than 4096 rows runs the fused kernel below ~100 TFLOP/s (tools/gpu_kernel_grid.py)
+    pl.piece_min_rows = env_int("SDPA_PIECE_MIN_ROWS", 4096);
 
     pl.r.assign(pl.P, RankPlan());
     int max_rows = 0;
@@ -269,22 +284,24 @@ void make_plan(Plan &pl, int m, int n, int dk, int dv, int flags) {
     pl.B = B;
     pl.nb = (max_rows + B - 1) / B;
     if (pl.nb < 1) pl.nb = 1;
-    if (no_pipe || pl.collectives) pl.tail_split = 1;    // collectives run once per batch
+    if (no_pipe) pl.row_pieces = 1;
 
     for (int g = 0; g < pl.P; ++g) {
         RankPlan &rp = pl.r[g];
         const int rows0 = std::min(B, rp.row_cnt);          // rows of this rank's first batch
         std::vector<int> sizes = no_pipe ? std::vector<int>(rp.key_cnt > 0 ? 1 : 0, rp.key_cnt)
                                          : chunk_sizes(rp.key_cnt, cmin, cmax);
-        // the last chunk of a batch that is both first and last is launched piece by piece
+        // the first chunk is launched in row pieces, and so is the last one when the first batch is
+        // also the last and finishes its rows itself (collectives run once per batch)
         const bool first_is_last = rp.row_cnt <= B;
-        const int rows_piece0 = (first_is_last && pl.tail_split > 1) ? std::min(rows0, piece_rows_of(rows0, pl.tail_split)) : rows0;
+        const int rows_piece0 = piece_rows_of(pl, rows0);
         int k0 = 0, slot = 0;
         for (size_t ci = 0; ci < sizes.size(); ++ci) {
             const int sz = sizes[ci];
             Chunk c;
             c.k0 = k0; c.keys = sz;
-            const int launch_rows = ci + 1 == sizes.size() ? rows_piece0 : rows0;
+            const bool in_pieces = ci == 0 || (ci + 1 == sizes.size() && first_is_last && !pl.collectives);
+            const int launch_rows = in_pieces ? rows_piece0 : rows0;
             c.splits = launch_rows > 0 ? pick_splits(pl, launch_rows, sz) : 1;
             c.slot0 = slot;
             slot += c.splits;
@@ -298,8 +315,9 @@ void make_plan(Plan &pl, int m, int n, int dk, int dv, int flags) {
         size_t ws = 0;
         const int nb_g = rp.row_cnt > 0 ? (rp.row_cnt + B - 1) / B : 0;
         const int rows_last = rp.row_cnt - (nb_g - 1) * B;                  // rows of this rank's last batch
-        const int pr = piece_rows_of(rows_last, pl.tail_split);
-        const int shapes[4] = {rows0, rows_last, std::min(rows_last, pr), rows_last % pr};
+        const int pr = piece_rows_of(pl, rows_last);
+        const int shapes[6] = {rows0, rows_last, pr, pr > 0 ? rows_last % pr : 0, rows_piece0,
+                               rows_piece0 > 0 ? rows0 % rows_piece0 : 0};
         for (int rows : shapes)
             if (rows > 0 && rp.key_cnt > 0) {
                 ws = std::max(ws, launch_ws_bytes(pl, rows, rp.key_cnt));
@@ -314,8 +332,8 @@ int ensure_buffers(const Plan &pl) {
         Rank &rk = E.r[g];
         const RankPlan &rp = pl.r[g];
         HIP_TRY(hipSetDevice(rk.dev));
-        SDPA_TRY(ensure(rk.k64, (size_t)rp.max_chunk * pl.dk * sizeof(double)));
-        SDPA_TRY(ensure(rk.v64, (size_t)rp.max_chunk * pl.dv * sizeof(double)));
+        SDPA_TRY(ensure(rk.k64, (size_t)rp.key_cnt * pl.dk * sizeof(double)));
+        SDPA_TRY(ensure(rk.v64, (size_t)rp.key_cnt * pl.dv * sizeof(double)));
         SDPA_TRY(ensure(rk.kf, (size_t)rp.key_cnt * pl.ldk * pl.kv_elem));
         if (pl.bf16)
             SDPA_TRY(ensure(rk.vf, (size_t)sdpa::bf16_pad_dv(pl.dv) * sdpa::bf16_pad_n(rp.key_cnt) * sizeof(unsigned short)));
@@ -340,6 +358,8 @@ int ensure_buffers(const Plan &pl) {
             hipEvent_t e;
             HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             rk.ev_kv.push_back(e);
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            rk.ev_h2d.push_back(e);
         }
     }
     return SDPA_OK;
@@ -432,32 +452,49 @@ int merge_slots(const Plan &pl, Rank &rk, const RankPlan &rp, int s, int bs, int
     return SDPA_OK;
 }
 
-// K/V chunk c of the rank's shard: host -> device staging, convert into the operand image
-// (attention-mpi.c:224-225 / :248-249 and the Scatterv of :258-264), all on the copy stream.
+// K/V chunk c of the rank's shard: host -> device into the fp64 staging image on the copy stream,
+// then the convert into the operand image (attention-mpi.c:224-225 / :248-249 and the Scatterv of
+// :258-264) on the convert stream.
 int stage_chunk(const Plan &pl, Rank &rk, const RankPlan &rp, const double *K, const double *V, int c) {
     const Chunk &ch = rp.chunks[c];
     const size_t row0 = (size_t)rp.key_off + ch.k0;
-    HIP_TRY(hipMemcpyAsync(rk.k64.p, K + row0 * pl.dk, (size_t)ch.keys * pl.dk * sizeof(double),
-                           hipMemcpyHostToDevice, rk.s_in));
-    if (pl.bf16)
-        HIP_TRY(sdpa::launch_cvt_d2bf((const double *)rk.k64.p, (unsigned short *)rk.kf.p + (size_t)ch.k0 * pl.ldk,
-                                      ch.keys, pl.dk, pl.ldk, rk.s_in));
-    else
-        HIP_TRY(sdpa::launch_cvt_d2f((const double *)rk.k64.p, (float *)rk.kf.p + (size_t)ch.k0 * pl.ldk,
-                                     ch.keys, pl.dk, pl.ldk, rk.s_in));
-    HIP_TRY(hipMemcpyAsync(rk.v64.p, V + row0 * pl.dv, (size_t)ch.keys * pl.dv * sizeof(double),
-                           hipMemcpyHostToDevice, rk.s_in));
+    double *k64 = (double *)rk.k64.p + (size_t)ch.k0 * pl.dk;
+    double *v64 = (double *)rk.v64.p + (size_t)ch.k0 * pl.dv;
+    HIP_TRY(hipMemcpyAsync(k64, K + row0 * pl.dk, (size_t)ch.keys * pl.dk * sizeof(double), hipMemcpyHostToDevice,
+                           rk.s_cp));
+    HIP_TRY(hipMemcpyAsync(v64, V + row0 * pl.dv, (size_t)ch.keys * pl.dv * sizeof(double), hipMemcpyHostToDevice,
+                           rk.s_cp));
+    HIP_TRY(hipEventRecord(rk.ev_h2d[c], rk.s_cp));
+    HIP_TRY(hipStreamWaitEvent(rk.s_in, rk.ev_h2d[c], 0));
     if (pl.bf16) {
+        HIP_TRY(sdpa::launch_cvt_d2bf(k64, (unsigned short *)rk.kf.p + (size_t)ch.k0 * pl.ldk, ch.keys, pl.dk, pl.ldk,
+                                      rk.s_in));
         const long ldn = sdpa::bf16_pad_n(rp.key_cnt);
         const bool last = c + 1 == (int)rp.chunks.size();
         const long pad = last ? ldn - ch.k0 : ch.keys;       // the image's zero tail belongs to the last chunk
-        HIP_TRY(sdpa::launch_cvt_d2bf_t_part((const double *)rk.v64.p, (unsigned short *)rk.vf.p + ch.k0, ch.keys,
-                                             pad, pl.dv, sdpa::bf16_pad_dv(pl.dv), ldn, rk.s_in));
+        HIP_TRY(sdpa::launch_cvt_d2bf_t_part(v64, (unsigned short *)rk.vf.p + ch.k0, ch.keys, pad, pl.dv,
+                                             sdpa::bf16_pad_dv(pl.dv), ldn, rk.s_in));
     } else {
-        HIP_TRY(sdpa::launch_cvt_d2f((const double *)rk.v64.p, (float *)rk.vf.p + (size_t)ch.k0 * pl.ldv,
-                                     ch.keys, pl.dv, pl.ldv, rk.s_in));
+        HIP_TRY(sdpa::launch_cvt_d2f(k64, (float *)rk.kf.p + (size_t)ch.k0 * pl.ldk, ch.keys, pl.dk, pl.ldk, rk.s_in));
+        HIP_TRY(sdpa::launch_cvt_d2f(v64, (float *)rk.vf.p + (size_t)ch.k0 * pl.ldv, ch.keys, pl.dv, pl.ldv, rk.s_in));
     }
     HIP_TRY(hipEventRecord(rk.ev_kv[c], rk.s_in));
+    return SDPA_OK;
+}
+
+// Rows [j0, j0+jr) of a Q batch: copy, convert into slot s of qf (attention-mpi.c:303,:325).
+int stage_q_rows(const Plan &pl, Rank &rk, const double *Q, int s, size_t i0, int j0, int jr, hipEvent_t copied,
+                 hipEvent_t converted) {
+    double *q64 = (double *)rk.q64[s].p + (size_t)j0 * pl.dk;
+    HIP_TRY(hipMemcpyAsync(q64, Q + (i0 + j0) * pl.dk, (size_t)jr * pl.dk * sizeof(double), hipMemcpyHostToDevice,
+                           rk.s_cp));
+    HIP_TRY(hipEventRecord(copied, rk.s_cp));
+    HIP_TRY(hipStreamWaitEvent(rk.s_in, copied, 0));
+    if (pl.bf16)
+        HIP_TRY(sdpa::launch_cvt_d2bf(q64, (unsigned short *)rk.qf[s].p + (size_t)j0 * pl.ldq, jr, pl.dk, pl.ldq, rk.s_in));
+    else
+        HIP_TRY(sdpa::launch_cvt_d2f(q64, (float *)rk.qf[s].p + (size_t)j0 * pl.ldq, jr, pl.dk, pl.ldq, rk.s_in));
+    HIP_TRY(hipEventRecord(converted, rk.s_in));
     return SDPA_OK;
 }
 
@@ -496,9 +533,13 @@ void destroy_rank(Rank &g) {
         for (hipEvent_t e : g.ev_sub[s]) if (e) (void)hipEventDestroy(e);
     }
     for (hipEvent_t e : g.ev_kv) (void)hipEventDestroy(e);
+    for (hipEvent_t e : g.ev_h2d) (void)hipEventDestroy(e);
+    for (hipEvent_t e : g.ev_qh) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : g.ev_qp) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : g.ev_k) (void)hipEventDestroy(e);
     hipEvent_t evs[] = {g.ev_t0, g.ev_kv_done, g.ev_end};
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+    if (g.s_cp) (void)hipStreamDestroy(g.s_cp);
     if (g.s_in) (void)hipStreamDestroy(g.s_in);
     if (g.s_run) (void)hipStreamDestroy(g.s_run);
     if (g.s_out) (void)hipStreamDestroy(g.s_out);
@@ -508,9 +549,10 @@ void destroy_rank(Rank &g) {
 int create_rank(Rank &g, int dev) {
     g.dev = dev;
     HIP_TRY(hipSetDevice(dev));
-    // copies and converts go first when a slot frees up: they feed the next fused launch
+    // converts go first when a fused launch retires: they feed the next one
     int lo = 0, hi = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIP_TRY(hipStreamCreateWithFlags(&g.s_cp, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithPriority(&g.s_in, hipStreamNonBlocking, hi));
     HIP_TRY(hipStreamCreateWithFlags(&g.s_run, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithPriority(&g.s_out, hipStreamNonBlocking, hi));
@@ -519,6 +561,10 @@ int create_rank(Rank &g, int dev) {
         HIP_TRY(hipEventCreateWithFlags(&g.ev_run[s], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&g.ev_out[s], hipEventDisableTiming));
         for (int j = 0; j < kMaxSub; ++j) HIP_TRY(hipEventCreateWithFlags(&g.ev_sub[s][j], hipEventDisableTiming));
+    }
+    for (int j = 0; j < kMaxSub; ++j) {
+        HIP_TRY(hipEventCreateWithFlags(&g.ev_qh[j], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&g.ev_qp[j], hipEventDisableTiming));
     }
     HIP_TRY(hipEventCreate(&g.ev_t0));
     HIP_TRY(hipEventCreate(&g.ev_kv_done));
@@ -651,7 +697,7 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
 
     Rank &root = E.r[0];
     HIP_TRY(hipSetDevice(root.dev));
-    HIP_TRY(hipEventRecord(root.ev_t0, root.s_in));
+    HIP_TRY(hipEventRecord(root.ev_t0, root.s_cp));
     int n_brackets = 0, last_splits = 1;
     auto bracket = [&](Rank &rk) -> int {      // timing event on rank 0's compute stream
         if (&rk != &root) return SDPA_OK;
@@ -678,74 +724,88 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
             const int j_lo = b * pl.B;
             if (j_lo >= rp.row_cnt) continue;                    // this rank has no rows left
             const int bs = std::min(pl.B, rp.row_cnt - j_lo);
-            const int i0 = rp.row_off + j_lo;                    // first global query row
+            const size_t i0 = (size_t)rp.row_off + j_lo;         // first global query row
             const int C = (int)rp.chunks.size();
             HIP_TRY(hipSetDevice(rk.dev));
 
-            // copy stream: K/V chunk 0, the Q batch, the remaining chunks.  Slot s of qf was last
-            // read by the compute of batch b-2 (ev_run[s]).
+            const bool finisher = !pl.collectives;               // finishes its own rows on this rank
+            const bool last_batch = j_lo + pl.B >= rp.row_cnt;   // of this rank
+            const bool head_pieces = b == 0;                     // Q arrives in row pieces
+            const bool tail_pieces = last_batch && finisher;     // rows leave in row pieces
+            const int pr = (head_pieces || tail_pieces) ? piece_rows_of(pl, bs) : bs;
+            const int pieces = (bs + pr - 1) / pr;
+
+            // copy + convert streams: K/V chunk 0, the Q batch (in pieces for batch 0), the remaining
+            // chunks.  q64[s] was last read by the convert of batch b-2 (ev_q[s]); qf[s] by its
+            // kernels (ev_run[s]).
             if (b == 0 && C > 0) SDPA_TRY(stage_chunk(pl, rk, rp, K, V, 0));
-            if (b >= 2) HIP_TRY(hipStreamWaitEvent(rk.s_in, rk.ev_run[s], 0));
-            HIP_TRY(hipMemcpyAsync(rk.q64[s].p, Q + (size_t)i0 * dk, (size_t)bs * dk * sizeof(double),
-                                   hipMemcpyHostToDevice, rk.s_in));
-            if (pl.bf16)
-                HIP_TRY(sdpa::launch_cvt_d2bf((const double *)rk.q64[s].p, (unsigned short *)rk.qf[s].p, bs, dk,
-                                              pl.ldq, rk.s_in));
-            else
-                HIP_TRY(sdpa::launch_cvt_d2f((const double *)rk.q64[s].p, (float *)rk.qf[s].p, bs, dk, pl.ldq,
-                                             rk.s_in));
-            HIP_TRY(hipEventRecord(rk.ev_q[s], rk.s_in));
+            if (b >= 2) {
+                HIP_TRY(hipStreamWaitEvent(rk.s_cp, rk.ev_q[s], 0));
+                HIP_TRY(hipStreamWaitEvent(rk.s_in, rk.ev_run[s], 0));
+            }
+            if (head_pieces) {
+                for (int j = 0; j < pieces; ++j)
+                    SDPA_TRY(stage_q_rows(pl, rk, Q, s, i0, j * pr, std::min(pr, bs - j * pr), rk.ev_qh[j], rk.ev_qp[j]));
+                HIP_TRY(hipEventRecord(rk.ev_q[s], rk.s_in));
+            } else {
+                SDPA_TRY(stage_q_rows(pl, rk, Q, s, i0, 0, bs, rk.ev_qh[0], rk.ev_q[s]));
+            }
             if (b == 0) {
                 for (int c = 1; c < C; ++c) SDPA_TRY(stage_chunk(pl, rk, rp, K, V, c));
                 if (g == 0) HIP_TRY(hipEventRecord(rk.ev_kv_done, rk.s_in));
             }
 
             // compute stream
-            HIP_TRY(hipStreamWaitEvent(rk.s_run, rk.ev_q[s], 0));
             if (b >= 2) HIP_TRY(hipStreamWaitEvent(rk.s_run, rk.ev_out[s], 0));   // out64[s] still leaving
-            const bool finisher = !pl.collectives;               // finishes its own rows on this rank
             const bool streamed = b == 0 && rp.n_slots > 1;
-            // pieces of the last batch: finish + D2H of piece j run under the fused launch of j+1
-            const bool last_batch = j_lo + pl.B >= rp.row_cnt;   // of this rank
-            const int piece_rows = (last_batch && finisher && pl.tail_split > 1) ? piece_rows_of(bs, pl.tail_split) : bs;
-            const int pieces = (bs + piece_rows - 1) / piece_rows;
+            bool have_all_q = false;
+            auto need_all_q = [&]() -> int {
+                if (!have_all_q) HIP_TRY(hipStreamWaitEvent(rk.s_run, rk.ev_q[s], 0));
+                have_all_q = true;
+                return SDPA_OK;
+            };
+            // rows [j0, j0+jr) are complete in contrib[s]/stat[s]: step 5 with gsum = lsum fused with
+            // the fp64 writeback (attention-mpi.c:358-362, :373), then they go home
+            auto finish_rows = [&](int ev, int j0, int jr) -> int {
+                HIP_TRY(sdpa::launch_finish_f64((const float *)rk.contrib[s].p + (size_t)j0 * pl.ldo, pl.ldo,
+                                                (const float *)rk.stat[s].p + bs + j0,
+                                                (double *)rk.out64[s].p + (size_t)j0 * dv, jr, dv, rk.s_run));
+                HIP_TRY(hipEventRecord(rk.ev_sub[s][ev], rk.s_run));
+                HIP_TRY(hipStreamWaitEvent(rk.s_out, rk.ev_sub[s][ev], 0));
+                HIP_TRY(hipMemcpyAsync(result + (i0 + j0) * dv, (double *)rk.out64[s].p + (size_t)j0 * dv,
+                                       (size_t)jr * dv * sizeof(double), hipMemcpyDeviceToHost, rk.s_out));
+                return SDPA_OK;
+            };
 
-            if (streamed) {
-                for (int c = 0; c + 1 < C; ++c) {
-                    const Chunk &ch = rp.chunks[c];
-                    HIP_TRY(hipStreamWaitEvent(rk.s_run, rk.ev_kv[c], 0));
+            const int n_launch_chunks = streamed ? C : 1;
+            for (int c = 0; c < n_launch_chunks; ++c) {
+                const bool first = c == 0, last = c + 1 == n_launch_chunks;
+                const bool in_pieces = pieces > 1 && ((first && head_pieces) || (last && tail_pieces));
+                const int k0 = streamed ? rp.chunks[c].k0 : 0;
+                const int keys = streamed ? rp.chunks[c].keys : rp.key_cnt;
+                if (b == 0 && C > 0) HIP_TRY(hipStreamWaitEvent(rk.s_run, rk.ev_kv[streamed ? c : C - 1], 0));
+                const int np = in_pieces ? pieces : 1;
+                for (int j = 0; j < np; ++j) {
+                    const int j0 = in_pieces ? j * pr : 0, jr = in_pieces ? std::min(pr, bs - j0) : bs;
+                    if (first && head_pieces && in_pieces)
+                        HIP_TRY(hipStreamWaitEvent(rk.s_run, rk.ev_qp[j], 0));
+                    else
+                        SDPA_TRY(need_all_q());
+                    int sp, slot0 = -1;
+                    if (streamed) {
+                        sp = rp.chunks[c].splits;                 // the slot count was planned for this launch shape
+                        slot0 = rp.chunks[c].slot0;
+                    } else {
+                        sp = keys > 0 ? pick_splits(pl, jr, keys) : 1;
+                    }
                     SDPA_TRY(bracket(rk));
-                    SDPA_TRY(launch_fused(pl, rk, rp, s, bs, 0, bs, ch.k0, ch.keys, ch.splits, ch.slot0));
+                    SDPA_TRY(launch_fused(pl, rk, rp, s, bs, j0, jr, k0, keys, sp, slot0));
                     SDPA_TRY(bracket(rk));
-                }
-                HIP_TRY(hipStreamWaitEvent(rk.s_run, rk.ev_kv[C - 1], 0));
-            } else if (b == 0 && C > 0) {
-                HIP_TRY(hipStreamWaitEvent(rk.s_run, rk.ev_kv[0], 0));
-            }
-            for (int j = 0; j < pieces; ++j) {
-                const int j0 = j * piece_rows, jr = std::min(piece_rows, bs - j0);
-                SDPA_TRY(bracket(rk));
-                if (streamed) {
-                    const Chunk &ch = rp.chunks[C - 1];          // the slot count is the full-row launch's
-                    SDPA_TRY(launch_fused(pl, rk, rp, s, bs, j0, jr, ch.k0, ch.keys, ch.splits, ch.slot0));
-                    if (g == 0) last_splits = ch.splits;
-                } else {
-                    const int sp = rp.key_cnt > 0 ? pick_splits(pl, jr, rp.key_cnt) : 1;
-                    SDPA_TRY(launch_fused(pl, rk, rp, s, bs, j0, jr, 0, rp.key_cnt, sp, -1));
                     if (g == 0) last_splits = sp;
-                }
-                SDPA_TRY(bracket(rk));
-                if (streamed) SDPA_TRY(merge_slots(pl, rk, rp, s, bs, j0, jr));
-                if (finisher) {
-                    // single rank (or the q-row plan): step 5 with gsum = lsum fused with the fp64
-                    // writeback (attention-mpi.c:358-362, :373), then the piece goes home
-                    HIP_TRY(sdpa::launch_finish_f64((const float *)rk.contrib[s].p + (size_t)j0 * pl.ldo, pl.ldo,
-                                                    (const float *)rk.stat[s].p + bs + j0,
-                                                    (double *)rk.out64[s].p + (size_t)j0 * dv, jr, dv, rk.s_run));
-                    HIP_TRY(hipEventRecord(rk.ev_sub[s][j], rk.s_run));
-                    HIP_TRY(hipStreamWaitEvent(rk.s_out, rk.ev_sub[s][j], 0));
-                    HIP_TRY(hipMemcpyAsync(result + ((size_t)i0 + j0) * dv, (double *)rk.out64[s].p + (size_t)j0 * dv,
-                                           (size_t)jr * dv * sizeof(double), hipMemcpyDeviceToHost, rk.s_out));
+                    if (last) {
+                        if (streamed) SDPA_TRY(merge_slots(pl, rk, rp, s, bs, j0, jr));
+                        if (finisher) SDPA_TRY(finish_rows(in_pieces ? j : 0, j0, jr));
+                    }
                 }
             }
             if (finisher) {
@@ -823,6 +883,7 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
         HIP_TRY(hipStreamSynchronize(E.r[g].s_run));
         HIP_TRY(hipStreamSynchronize(E.r[g].s_out));
         HIP_TRY(hipStreamSynchronize(E.r[g].s_in));
+        HIP_TRY(hipStreamSynchronize(E.r[g].s_cp));
     }
     drain.armed = false;
     const double t_exit = now_us();

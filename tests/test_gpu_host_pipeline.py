@@ -23,6 +23,15 @@ def check(got, want, V, what="", tol=None):
     return err
 
 
+def n_pieces(rows, row_pieces=4, min_rows=128):
+    """row pieces of a batch as csrc/sdpa_host.hip plans them (whole query blocks of 128 rows)"""
+    if row_pieces <= 1:
+        return 1
+    pr = max(-(-rows // row_pieces), min_rows)
+    pr = -(-pr // 128) * 128
+    return 1 if pr >= rows else -(-rows // pr)
+
+
 @pytest.fixture
 def engine(pkg, monkeypatch):
     """re-creates the engine with the environment a test asks for, and puts the default
@@ -32,7 +41,7 @@ def engine(pkg, monkeypatch):
     def make(**env):
         pkg.shutdown()
         for k in ("SDPA_VIRTUAL_GPUS", "SDPA_FORCE_COLLECTIVES", "SDPA_QBATCH", "SDPA_KV_CHUNK_MIN",
-                  "SDPA_KV_CHUNK_MAX", "SDPA_TAIL_SPLIT", "SDPA_PLAN", "SDPA_MERGE", "SDPA_PRECISION"):
+                  "SDPA_KV_CHUNK_MAX", "SDPA_ROW_PIECES", "SDPA_PIECE_MIN_ROWS", "SDPA_PLAN", "SDPA_MERGE", "SDPA_PRECISION"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, str(v))
@@ -59,14 +68,14 @@ def test_kv_chunk_streaming_matches_oracle(m, n, dk, dv, dist, prec, engine, orc
     """the first Q batch starts on K/V chunk 0 while the later chunks are still crossing PCIe; the
     partial triples of all chunks and in-launch splits are merged in one pass; the last chunk runs
     in pieces whose finish + D2H overlap the next piece's kernel"""
-    pkg = engine(SDPA_KV_CHUNK_MIN=1024, SDPA_KV_CHUNK_MAX=2048)
+    pkg = engine(SDPA_KV_CHUNK_MIN=1024, SDPA_KV_CHUNK_MAX=2048, SDPA_PIECE_MIN_ROWS=128)
     Q, K, V = O.make_inputs(m, n, dk, dv, dist, seed=m + n)
     want = orc.attention_f64(Q, K, V)
     tol = 1e-2 * max(1.0, float(np.abs(V).max())) if prec == "bf16" else None
     got = pkg.attention(Q, K, V, precision=prec)
     t = pkg.last_timing()
     assert t["kv_chunks"] >= 3 and t["q_batches"] == 1, t
-    assert t["fused_launches"] >= t["kv_chunks"], t            # last chunk in >= 1 pieces
+    assert t["fused_launches"] == t["kv_chunks"] - 2 + 2 * n_pieces(m), t      # first and last chunk in row pieces
     check(got, want, V, "streamed", tol)
     # same problem, nothing streamed and nothing cut in pieces: must agree to rounding
     got1 = pkg.attention(Q, K, V, flags=1, precision=prec)      # SDPA_F_NO_PIPELINE
@@ -75,7 +84,7 @@ def test_kv_chunk_streaming_matches_oracle(m, n, dk, dv, dist, prec, engine, orc
     check(got1, want, V, "unstreamed", tol)
     assert np.abs(got - got1).max() <= (tol if tol else 2 * fp32_tol(V))
     # several Q batches on top: batch 0 streams, the later ones run on the resident shard
-    pkg = engine(SDPA_KV_CHUNK_MIN=1024, SDPA_KV_CHUNK_MAX=2048, SDPA_QBATCH=256)
+    pkg = engine(SDPA_KV_CHUNK_MIN=1024, SDPA_KV_CHUNK_MAX=2048, SDPA_QBATCH=256, SDPA_PIECE_MIN_ROWS=128)
     got2 = pkg.attention(Q, K, V, precision=prec)
     t2 = pkg.last_timing()
     assert t2["q_batches"] == (m + 255) // 256 and t2["kv_chunks"] >= 3
@@ -90,13 +99,19 @@ def test_streaming_is_deterministic(engine, O):
         assert np.array_equal(pkg.attention(Q, K, V), a), "same inputs must give bit-identical results"
 
 
-def test_tail_pieces_cover_ragged_rows(engine, orc, O):
-    """pieces of the last batch are whole query blocks; the last piece is ragged"""
+def test_row_pieces_cover_ragged_rows(engine, orc, O):
+    """row pieces (Q arriving / rows leaving) are whole query blocks; the last piece is ragged;
+    with one K/V chunk the same launches serve as head and tail pieces"""
     for m in (129, 1000, 1025):
         for pieces in (1, 4, 8):
-            pkg = engine(SDPA_TAIL_SPLIT=pieces, SDPA_KV_CHUNK_MIN=1024, SDPA_KV_CHUNK_MAX=1024)
-            Q, K, V = O.make_inputs(m, 3000, 64, 64, "D2", seed=m)
-            check(pkg.attention(Q, K, V), orc.attention_f64(Q, K, V), V, "m=%d pieces=%d" % (m, pieces))
+            for n in (3000, 900):
+                pkg = engine(SDPA_ROW_PIECES=pieces, SDPA_PIECE_MIN_ROWS=128, SDPA_KV_CHUNK_MIN=1024,
+                             SDPA_KV_CHUNK_MAX=1024)
+                Q, K, V = O.make_inputs(m, n, 64, 64, "D2", seed=m)
+                check(pkg.attention(Q, K, V), orc.attention_f64(Q, K, V), V, "m=%d n=%d pieces=%d" % (m, n, pieces))
+                t = pkg.last_timing()
+                want_pieces = n_pieces(m, pieces)
+                assert t["fused_launches"] == (t["kv_chunks"] - 2 + 2 * want_pieces if t["kv_chunks"] > 1 else want_pieces), t
 
 
 # ---------------------------------------------------------------- P > 1 on one device ---------
@@ -117,7 +132,7 @@ def test_virtual_ranks_kv_sharded(P, merge, engine, orc, O):
     fused launches, all-gather or all-reduce(MAX)+all-reduce(SUM), reduce(SUM) to rank 0 -- vs the
     fp64 oracle and vs the restated fp32 pipeline of the reference at the same P"""
     for (m, n, dk, dv, dist, qb) in CASES_P:
-        env = dict(SDPA_VIRTUAL_GPUS=P, SDPA_KV_CHUNK_MIN=1024, SDPA_KV_CHUNK_MAX=1024)
+        env = dict(SDPA_VIRTUAL_GPUS=P, SDPA_KV_CHUNK_MIN=1024, SDPA_KV_CHUNK_MAX=1024, SDPA_PIECE_MIN_ROWS=128)
         if qb:
             env["SDPA_QBATCH"] = qb
         pkg = engine(**env)
@@ -140,7 +155,7 @@ def test_virtual_ranks_qrow_sharded(P, engine, orc, O):
     holds all of K/V and finishes its own slice of the query rows; no collective"""
     for (m, n, dk, dv, dist, qb) in [(100, 900, 64, 64, "D2", 0), (5, 300, 32, 32, "D1", 0),
                                       (1000, 2500, 128, 128, "D3", 96)]:
-        env = dict(SDPA_VIRTUAL_GPUS=P, SDPA_KV_CHUNK_MIN=1024, SDPA_KV_CHUNK_MAX=1024)
+        env = dict(SDPA_VIRTUAL_GPUS=P, SDPA_KV_CHUNK_MIN=1024, SDPA_KV_CHUNK_MAX=1024, SDPA_PIECE_MIN_ROWS=128)
         if qb:
             env["SDPA_QBATCH"] = qb
         pkg = engine(**env)
@@ -152,7 +167,7 @@ def test_virtual_ranks_qrow_sharded(P, engine, orc, O):
 
 
 def test_virtual_ranks_bf16(engine, orc, O):
-    pkg = engine(SDPA_VIRTUAL_GPUS=3, SDPA_KV_CHUNK_MIN=1024, SDPA_KV_CHUNK_MAX=1024, SDPA_QBATCH=256)
+    pkg = engine(SDPA_VIRTUAL_GPUS=3, SDPA_KV_CHUNK_MIN=1024, SDPA_KV_CHUNK_MAX=1024, SDPA_QBATCH=256, SDPA_PIECE_MIN_ROWS=128)
     for (m, n, d) in [(600, 5000, 128), (130, 4, 64), (260, 3100, 512)]:
         Q, K, V = O.make_inputs(m, n, d, d, "D2", seed=m)
         got = pkg.attention(Q, K, V, precision="bf16")

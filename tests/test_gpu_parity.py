@@ -73,6 +73,37 @@ def test_golden_cli_prints_correct(case):
     assert "non-finite" not in r.stderr
 
 
+CLI_MPI = os.path.join(ROOT, PKG, "bin", "attention-mpi-hip")
+MPIEXEC = "/opt/conda/bin/mpiexec"
+
+
+@pytest.mark.parametrize("ranks", [1, 4])
+@pytest.mark.parametrize("case", golden_cases(), ids=lambda c: c["name"])
+def test_golden_mpi_flavour_cli_prints_correct(case, ranks):
+    """the MPI-flavour drop-in (attention-mpi.c:497-541): same stdout under mpiexec -n 1 and -n 4;
+    only rank 0 touches the GPU"""
+    if not (os.path.exists(CLI_MPI) and os.path.exists(MPIEXEC)):
+        pytest.skip("no MPI in this image")
+    r = subprocess.run([MPIEXEC, "-n", str(ranks), CLI_MPI, os.path.join(GOLD, case["file"])],
+                       capture_output=True, text=True, env=dict(os.environ, SDPA_VERBOSE="1"))
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.split("\n")
+    assert lines[0] == "Correct!" and lines[1].startswith("Elapsed time: ") and lines[1].endswith(" us")
+    assert lines[2] == "" and len(lines) == 3
+    assert "%d MPI ranks" % ranks in r.stderr and "non-finite" not in r.stderr
+
+
+def test_cli_virtual_ranks_and_plans(tmp_path, O):
+    """the CLI's multi-rank switches on one device: K/V-sharded with both merges, and q-row-sharded"""
+    case = os.path.join(GOLD, "adversarial_D4.bin")
+    for env, tag in (({"SDPA_VIRTUAL_GPUS": "4"}, "merge=all-gather"),
+                     ({"SDPA_VIRTUAL_GPUS": "4", "SDPA_MERGE": "allreduce"}, "merge=all-reduce x2"),
+                     ({"SDPA_VIRTUAL_GPUS": "3", "SDPA_PLAN": "qrows"}, "plan=qrows")):
+        r = subprocess.run([CLI, case], capture_output=True, text=True, env=dict(os.environ, SDPA_VERBOSE="1", **env))
+        assert r.returncode == 0 and r.stdout.startswith("Correct!\nElapsed time: "), (env, r.stderr)
+        assert tag in r.stderr and "(virtual)" in r.stderr, r.stderr
+
+
 def test_cli_reports_wrong_on_a_corrupted_answer(tmp_path, O):
     Q, K, V, ans = O.read_case(os.path.join(GOLD, "tiny_D1.bin"))
     bad = ans.copy()
@@ -250,7 +281,7 @@ def test_headline_shape_row_subset(pkg, O):
     check(got[rows], O.numpy_attention_f64(Q, K, V, rows), V, "headline rows")
     t = pkg.last_timing()
     assert t["n_gpus"] >= 1 and t["q_batches"] == 1      # default Q batch = 32768 rows
-    assert t["kv_chunks"] >= 4 and t["fused_launches"] > t["kv_chunks"]   # K/V streamed, last chunk in pieces
+    assert t["kv_chunks"] >= 4 and t["fused_launches"] == t["kv_chunks"] + 6   # K/V streamed, first and last chunk in 4 row pieces
     again = pkg.attention(Q, K, V)
     assert np.array_equal(again, got), "same inputs must give bit-identical results run to run"
 

@@ -14,10 +14,13 @@ sweep = "--sweep" in sys.argv
 pinned = "--pinned" in sys.argv
 lib = pkg.load()
 pkg.init(1)
-KNOBS = ("SDPA_QBATCH", "SDPA_KV_CHUNK_MIN", "SDPA_KV_CHUNK_MAX", "SDPA_TAIL_SPLIT", "SDPA_HOST_REGISTER")
+KNOBS = ("SDPA_QBATCH", "SDPA_KV_CHUNK_MIN", "SDPA_KV_CHUNK_MAX", "SDPA_ROW_PIECES", "SDPA_PIECE_MIN_ROWS", "SDPA_HOST_REGISTER")
 SWEEP = [{},
-         {"SDPA_TAIL_SPLIT": 1},
-         {"SDPA_TAIL_SPLIT": 8},
+         {"SDPA_ROW_PIECES": 1},
+         {"SDPA_ROW_PIECES": 2},
+         {"SDPA_ROW_PIECES": 8},
+         {"SDPA_ROW_PIECES": 8, "SDPA_KV_CHUNK_MIN": 2048},
+         {"SDPA_PIECE_MIN_ROWS": 2048},
          {"SDPA_KV_CHUNK_MIN": 2048},
          {"SDPA_KV_CHUNK_MIN": 8192},
          {"SDPA_KV_CHUNK_MAX": 8192},
@@ -25,7 +28,7 @@ SWEEP = [{},
          {"SDPA_KV_CHUNK_MAX": 65536},
          {"SDPA_QBATCH": 16384},
          {"SDPA_QBATCH": 8192},
-         {"SDPA_KV_CHUNK_MIN": 1 << 20, "SDPA_TAIL_SPLIT": 1},     # round-1 structure: nothing streamed
+         {"SDPA_KV_CHUNK_MIN": 1 << 20, "SDPA_ROW_PIECES": 1},     # round-1 structure: nothing streamed
          ]
 
 

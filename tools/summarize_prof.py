@@ -19,6 +19,13 @@ for p in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recurs
         print("%-90s calls=%s total_ns=%s avg_ns=%s pct=%s" % (r.get("Name", "")[:90], r.get("Calls"),
               r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage")))
 print()
+print("== fused kernel, per dispatch (kernel trace: End - Start, ns) ==")
+for p in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    for r in rows(p):
+        if "fused_" in r.get("Kernel_Name", ""):
+            print("%-70s dispatch=%s duration_ns=%d grid=%s" % (r["Kernel_Name"][:70], r.get("Dispatch_Id"),
+                  int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r.get("Grid_Size", r.get("Grid_Size_X"))))
+print()
 print("== PMC (per kernel name: mean counter value per dispatch) ==")
 for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
     if not os.path.isdir(d):
@@ -51,9 +58,15 @@ def fused_mean(d, counter):
 
 f, w = fused_mean("pmc_fetch", "FETCH_SIZE"), fused_mean("pmc_write", "WRITE_SIZE")
 if f is not None and w is not None:
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for fn in ("sdpa_fwd_f32.hip", "sdpa_fwd_bf16.hip", "sdpa_internal.h"):
+        h.update(open(os.path.join(root, "mpi-parallelized-scaled-dot-product-attention-with-avx-512-optimization_amd", "csrc", fn), "rb").read())
     t = {"per_launch_bytes": f * 1024 * 2 + w * 1024, "fetch_size_kib": f, "write_size_kib": w,
+         "kernel_src_sha16": h.hexdigest()[:16],      # bench.py quotes the figure only for this build
          "correction": "FETCH_SIZE KiB x1024 x2 (gfx950 wide-read under-count) + WRITE_SIZE KiB x1024",
-         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python bench.py --steps 2 --warmup 1"}
+         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python bench.py --steps 2 --warmup 1 --no-boundary"}
     json.dump(t, open(os.path.join(out, "traffic.json"), "w"), indent=1)
     print()
     print("== fused kernel HBM-side traffic per launch ==")
