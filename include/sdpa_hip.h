@@ -136,6 +136,19 @@ SDPA_API int sdpa_last_timing(struct sdpa_timing *out);
  * :504); sdpa_attention_f64 works without it, the first call is just slower.               */
 SDPA_API int sdpa_prepare(int m, int n, int dk, int dv, int flags);
 
+/* Optional: for hosts that produce or READ K and V incrementally (the CLI's file reader with
+ * SDPA_CLI_PREFETCH=1, attention.c:100-121).  Says that rows [0, k_rows_final) of K and
+ * [0, v_rows_final) of V are final in host memory; the engine starts moving every K/V chunk that
+ * is complete to the device(s) and converting it, while the host carries on reading.  The NEXT
+ * sdpa_attention_f64() with the same K, V, m, n, dk, dv, flags (and the same environment knobs)
+ * skips what is already staged; any other call voids the prefetch.  Call it again as more rows
+ * become final (counts only grow).  The rows announced must not change, and K / V must stay valid,
+ * until that compute call returns.  Note for benchmarks: a compute call that follows a prefetch
+ * does not contain the K/V transfer -- the reference's timed region does (attention-mpi.c:210-266).
+ * Call sdpa_prepare() BEFORE the first prefetch, not after (its warm-up call voids it).        */
+SDPA_API int sdpa_kv_prefetch(const double *K, const double *V, int m, int n, int dk, int dv,
+                              int flags, int k_rows_final, int v_rows_final);
+
 /* Optional: page-locked host memory for the caller's Q/K/V/result arrays -- what the reference's
  * read_matrix() mallocs (attention.c:84-90) and main() frees (:191-194).  Arrays allocated here
  * need no per-call registration inside sdpa_attention_f64 and move at the full PCIe rate from the

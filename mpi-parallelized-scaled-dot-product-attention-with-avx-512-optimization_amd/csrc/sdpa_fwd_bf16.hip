@@ -486,6 +486,13 @@ __device__ __forceinline__ void mfma_bf16_vgpr_first(f32x16 &d, const u32x4 &x, 
 __device__ __forceinline__ void mfma_bf16_vgpr(f32x16 &d, const u32x4 &x, const u32x4 &y) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(x), "v"(y));
 }
+// the same with the B operand read from the ACCUMULATOR file (wave-persistent Q fragments parked there)
+__device__ __forceinline__ void mfma_bf16_vgpr_first_qa(f32x16 &d, const u32x4 &x, const u32x4 &y) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(x), "a"(y));
+}
+__device__ __forceinline__ void mfma_bf16_vgpr_qa(f32x16 &d, const u32x4 &x, const u32x4 &y) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(x), "a"(y));
+}
 // 16 wait states: covers an 8-pass MFMA's result latency before a VALU read (needs 11)
 __device__ __forceinline__ void mfma_result_fence(f32x16 &d) {
     asm volatile("s_nop 7\n\ts_nop 7" : "+v"(d));
@@ -875,6 +882,438 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// Duo variant (dk, dv <= 256): one wave per SIMD, TWO 32-row query blocks per wave.
+// In the kernels above every K or Vt fragment read from LDS (1 KiB per wave instruction) feeds ONE
+// MFMA, and four SIMDs issuing one v_mfma_f32_32x32x16_bf16 per 32 cycles then ask for exactly the
+// 128 B/clk an LDS can deliver: the matrix pipe can never run ahead of the LDS.  Here a fragment is
+// read once and multiplied against both query blocks of the wave, which halves LDS bytes per flop:
+//   * workgroup = 4 waves x 64 query rows = 256 rows; per wave the two O^T tiles (2 x DV/32 x 16
+//     registers) live in the ACCUMULATOR file, and so do the Q fragments (2 x DK/16 x 4) when both
+//     fit its 256 registers (QA: 192 at d = 128), pinned there with "+a" constraints and read by the
+//     MFMAs straight from it; the architectural VGPRs hold the softmax;
+//   * SETS = 2 (d <= 128): two score-tile SETS are live (4 tiles, VGPR-form inline-asm MFMAs as in
+//     the wide kernel):
+//     [A] S^T(t+1) = K(t+1).Q^T for both blocks -- two independent chains interleaved, so a link
+//         never waits for its predecessor -- and  [B] O^T += Vt(t).P(t)^T for both blocks;
+//     the softmax of a tile (exp2, row sum, bf16 pack, row max: ~4 VALU per element pair) is cut
+//     into 32 slices (block 0's 16 registers, then block 1's) issued ONE PER MFMA GAP across
+//     [B] of step t-1 and [A] of step t, i.e. spread evenly under all 32 MFMAs of a step at d = 128;
+//     SETS = 1 (dk = dv = 256: O fills the accumulator file, Q takes half the VGPRs): one set, all
+//     32 slices under the 32 MFMAs of [B], the wide kernel's schedule;
+//   * K (three buffers) and Vt (two) by LDS-DMA, issued piece by piece between MFMAs, one barrier
+//     per step; the image layouts, swizzles and the fixed reference exponent + redo flag are the
+//     wide kernel's (a block whose row max outgrows 2^32 x the first tile's is redone by the general
+//     kernel right behind this one).
+// ---------------------------------------------------------------------------
+#ifndef SDPA_DUO_KD
+#define SDPA_DUO_KD 3
+#endif
+#ifndef SDPA_DUO_VD
+#define SDPA_DUO_VD 2
+#endif
+constexpr int kDuoRows = 256;          // query rows per workgroup of the duo kernel
+
+template <int DK, int DV>
+struct DuoCfg {
+    // Q fragments go to the accumulator file when they fit beside O with room to spare (a file filled
+    // to the last register makes hipcc shuttle tiles through VGPRs inside the loop)
+    static constexpr bool QA = DK / 2 + DV <= 192;
+    static constexpr int SETS = (QA || DK <= 128) ? 2 : 1;      // live score-tile sets
+    // LDS rings.  A tile is consumed in ~0.2-0.45 us at these head dims, far less than a trip to the
+    // L2 / Infinity Cache, so tiles are requested several steps ahead: K(t+NKB) is issued while
+    // K(t+1) is read, Vt(t+NVB-1) while Vt(t) is read.  Sized to ~64-128 KiB of the CU's 160 KiB.
+    static constexpr int NKB = DK + DV <= 256 ? 6 : (DK + DV <= 384 ? 5 : 4);
+    static constexpr int NVB = NKB - 1;
+    static constexpr size_t lds_bytes = ((size_t)NKB * 32 * DK + (size_t)NVB * DV * 32) * 2;
+};
+
+template <int DK, int DV>
+__global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
+    Bf16Args a, int kv_per_split, int n_qblocks, int n_qblocks128, float scale) {
+    constexpr int NKS = DK / 16;               // QK^T k-steps: MFMAs per score tile and block
+    constexpr int NT = DV / 32;                // 32-row blocks of O^T per query block
+    constexpr int KCH = DK / 8;                // 16-byte chunks per K row
+    constexpr int KTILE = kKvTile * DK;        // bf16 elements, unpadded (swizzled)
+    constexpr int VTILE = DV * kKvTile;        // bf16 elements: 64-byte rows, swizzled
+    constexpr int KPW = (kKvTile * KCH / 64) / 4;   // 1-KiB DMA pieces per wave per K tile
+    constexpr int RPP = 64 / KCH > 0 ? 64 / KCH : 1; // K rows per DMA piece
+    constexpr int VPW = (DV * 4 / 64) / 4;          // 1-KiB DMA pieces per wave per Vt tile (16 rows each)
+    constexpr int SWZ = KCH >= 16 ? 15 : KCH - 1;
+    constexpr int GA = 2 * NKS;                // MFMAs of phase [A]
+    constexpr int GB = 4 * NT;                 // MFMAs of phase [B]
+    constexpr int NSL = 32;                    // softmax slices per tile: 2 blocks x 16 accumulator registers
+    constexpr int NKB = DuoCfg<DK, DV>::NKB, NVB = DuoCfg<DK, DV>::NVB;
+    constexpr bool QA = DuoCfg<DK, DV>::QA;
+    constexpr int SETS = DuoCfg<DK, DV>::SETS;
+    // slices issued under [B]; the rest under the next step's [A] (none with one score set)
+    constexpr int NB_SL = SETS == 1 ? NSL : NSL * GB / (GA + GB);
+    static_assert(KCH >= 8 && KPW >= 1 && VPW >= 1, "DK, DV must be 64..256");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+    unsigned short *const Ks = smem16;                    // [NKB][KTILE]
+    unsigned short *const Vs = smem16 + NKB * KTILE;      // [NVB][VTILE]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31;
+    const int hi = lane >> 5;
+
+    const int work = xcd_remap_b(blockIdx.x, gridDim.x);
+    const int qblock = work % n_qblocks;
+    const int split = work / n_qblocks;
+    const int qrow0 = qblock * kDuoRows + wave * 64 + li;        // block b: qrow0 + 32 b
+
+    const int kv_begin = split * kv_per_split;
+    const int kv_end = min(a.n_local, kv_begin + kv_per_split);
+    const int T = kv_end > kv_begin ? (kv_end - kv_begin + kKvTile - 1) / kKvTile : 0;
+    const float c = scale * 1.44269504088896340736f;
+
+    u32x4 qf[2][NKS];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int qrow = qrow0 + 32 * b;
+            if (qrow < a.m)
+                qf[b][ks] = *reinterpret_cast<const u32x4 *>(a.Q + (size_t)qrow * DK + 16 * ks + 8 * hi);
+            else
+                qf[b][ks] = u32x4{0u, 0u, 0u, 0u};
+        }
+    // wave-persistent operands live in the accumulator file: an MFMA reads A/B from AGPRs as well
+    auto pin_q = [&]() __attribute__((always_inline)) {
+        if constexpr (QA) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+a"(qf[b][ks]));
+        }
+    };
+    // one link of a score chain: S^T += K fragment . Q fragment (ks-th k-step of block b)
+    auto score_link = [&](f32x16 &sx, const u32x4 &kf, int b, int ks) __attribute__((always_inline)) {
+        if constexpr (QA) {
+            if (ks == 0) mfma_bf16_vgpr_first_qa(sx, kf, qf[b][0]);
+            else mfma_bf16_vgpr_qa(sx, kf, qf[b][ks]);
+        } else {
+            if (ks == 0) mfma_bf16_vgpr_first(sx, kf, qf[b][0]);
+            else mfma_bf16_vgpr(sx, kf, qf[b][ks]);
+        }
+    };
+    pin_q();
+
+    f32x16 oacc[2][NT];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[b][t][r] = 0.f;
+    auto pin_o = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) asm volatile("" : "+a"(oacc[b][tt]));
+    };
+    pin_o();
+    constexpr float kDeferLog2 = 32.0f;                   // P <= 2^32; beyond that the block is redone
+    float m_ref[2] = {0.f, 0.f}, max_rel[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};   // exp2 domain
+
+    // ---- K and Vt staging by LDS-DMA (the wide kernel's scheme)
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane(
+        (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)smem16);
+    auto dma_piece = [&](const char *gbase, unsigned lane_off, unsigned lds_byte) __attribute__((always_inline)) {
+        asm volatile("s_mov_b32 m0, %1\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %0, %2"
+                     :
+                     : "v"(lane_off), "s"(lds_byte), "s"(gbase)
+                     : "memory");
+    };
+    const unsigned klane = (unsigned)((lane / KCH) * DK * 2 + (((lane % KCH) ^ ((lane / KCH) & SWZ)) << 4));
+    auto dma_k_piece = [&](int tile, int buf, int j) __attribute__((always_inline)) {
+        const int base = kv_begin + tile * kKvTile;
+        const int last = kv_end - 1 - base;
+        const char *kb = reinterpret_cast<const char *>(a.K + (size_t)base * DK);
+        const int row0 = (wave * KPW + j) * RPP;                  // wave-uniform, a multiple of RPP:
+        const unsigned swz = (unsigned)((row0 & SWZ) << 4);       // (row0 + x) & SWZ == (row0 & SWZ) ^ x
+        const unsigned dst = lds_base + (unsigned)(buf * KTILE * 2 + (wave * KPW + j) * 1024);
+        unsigned off;                                             // volatile: not hoisted into KPW live registers
+        asm volatile("v_xor_b32 %0, %1, %2" : "=v"(off) : "s"(swz), "v"(klane));
+        const unsigned row = (unsigned)min(row0 + (int)(lane / KCH), last);
+        dma_piece(kb, row * (DK * 2) + (off % (DK * 2)), dst);
+    };
+    const unsigned vlane = (unsigned)((size_t)(lane >> 2) * a.ldvt * 2u) + (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+    auto dma_v_piece = [&](int tile, int buf, int j) __attribute__((always_inline)) {
+        const char *vb = reinterpret_cast<const char *>(a.Vt + kv_begin + tile * kKvTile);
+        dma_piece(vb + (size_t)((wave * VPW + j) * 16) * a.ldvt * 2u, vlane,
+                  lds_base + (unsigned)(NKB * KTILE * 2 + buf * VTILE * 2 + (wave * VPW + j) * 1024));
+    };
+    auto stage_fence = [&](auto keep) __attribute__((always_inline)) {
+        constexpr int KEEP = decltype(keep)::value;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
+        __syncthreads();
+    };
+
+    constexpr int NKA = NKS < 8 ? NKS : 8;
+    unsigned kaddr[NKA];
+#pragma unroll
+    for (int u = 0; u < NKA; ++u) kaddr[u] = (unsigned)(li * DK * 2 + (((2 * u + hi) ^ (li & SWZ)) << 4));
+    auto kfrag = [&](int ks) __attribute__((always_inline)) -> u32x4 {
+        return *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(Ks) +
+                                                kaddr[ks % NKA] + (ks / NKA) * 256);
+    };
+    unsigned vaddr[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) vaddr[h] = (unsigned)(li * 64 + (((2 * h + hi) ^ ((li >> 2) & 3)) << 4));
+    // like kaddr[], vaddr[] carries the byte offset of the Vt buffer being read and is advanced in place
+    auto vfrag = [&](int slot) __attribute__((always_inline)) -> u32x4 {
+        const int h = slot / NT, tt = slot % NT;
+        return *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(Vs) + vaddr[h] + tt * 2048);
+    };
+    auto mask_ragged = [&](f32x16 (&sx)[2], int tile) __attribute__((always_inline)) {
+        const int valid = kv_end - (kv_begin + tile * kKvTile);
+        if (valid < kKvTile) {
+            const int vh = valid - 4 * hi;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (crow16(r, 0) >= vh) sx[b][r] = -INFINITY;
+        }
+    };
+
+    // ---- softmax slices.  Slice i = element r = i % 16 of block b = i / 16 of score set sx:
+    //   e = exp2(s*c - m_ref)  (issued now);  l += e, bf16 pack  (of the PREVIOUS slice: the
+    //   transcendental's latency is never waited on);  row max of the raw scores every other slice.
+    // State carried between slices of one tile: ecur/eprev (the two newest e values), pw (packed).
+    struct SliceState {
+        float e0, e1;              // e of element r-1 (pending add/pack) and r-2 (its pack partner)
+        float tmax[2];
+    };
+    bool redo = false;
+    auto slice = [&](int i, f32x16 (&sx)[2], SliceState &st, u32x4 (&pout)[2][2]) __attribute__((always_inline)) {
+        const int b = i / 16, r = i % 16;
+        float e;
+        asm volatile("v_exp_f32 %0, %1" : "=v"(e) : "v"(fmaf(sx[b][r], c, -m_ref[b])));
+        if (r > 0) {                                   // finish element r-1 of this block
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(l_run[b]) : "v"(st.e0));
+            if (((r - 1) & 1) == 1) pout[b][((r - 1) >> 1) / 4][((r - 1) >> 1) % 4] = bpin_pack(st.e1, st.e0);
+        }
+        if ((r & 1) == 0) st.tmax[b] = bpin_max3(st.tmax[b], sx[b][r], sx[b][r + 1]);
+        st.e1 = st.e0;
+        st.e0 = e;
+        if (r == 15) {                                 // close the block
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(l_run[b]) : "v"(st.e0));
+            pout[b][1][3] = bpin_pack(st.e1, st.e0);
+            const float tm = halfwave_max(fmaf(st.tmax[b], c, -m_ref[b]));
+            redo |= __any(tm > kDeferLog2);
+            max_rel[b] = fmaxf(max_rel[b], tm);
+            st.tmax[b] = -INFINITY;
+        }
+    };
+    // slices [lo, hi) spread over the gaps of a phase with G MFMAs: after MFMA j run those whose
+    // index is below lo + ceil((j+1) (hi-lo) / G)
+    auto slices_after = [&](int j, int G, int lo, int hi_, f32x16 (&sx)[2], SliceState &st,
+                            u32x4 (&pout)[2][2]) __attribute__((always_inline)) {
+        const int n = hi_ - lo;
+        const int from = lo + (j * n + G - 1) / G, to = lo + ((j + 1) * n + G - 1) / G;
+#pragma unroll
+        for (int i = from; i < to; ++i) slice(i, sx, st, pout);
+    };
+
+    // rotating ring positions (wave-uniform): K buffer read / written in [A], Vt buffer read / written in [B]
+    int kr = 1, kw = 0, vr = 0, vw = NVB - 1;
+    // One step t.  scur: scores of tile t (its slices [NB_SL, 32) still to do), snxt: receives
+    // S^T(t+1); pcur: P(t) (completed in [A]), pnxt: receives P(t+1) (slices [0, NB_SL) in [B]).
+    auto step = [&](auto has_next, f32x16 (&scur)[2], f32x16 (&snxt)[2], SliceState &stc, SliceState &stn,
+                    u32x4 (&pcur)[2][2], u32x4 (&pnxt)[2][2], int t) __attribute__((always_inline)) {
+        constexpr bool HAS_NEXT = decltype(has_next)::value;
+        pin_o();
+        pin_q();
+        // [A]
+        if constexpr (HAS_NEXT) {
+            const int tk = min(t + NKB, T - 1);            // past the end: a harmless reload into a free buffer
+            // K fragment ring: one less where Q already takes half the VGPRs (a fragment spilled to
+            // scratch is reloaded behind an s_waitcnt vmcnt(0) that also waits for the DMA in flight)
+            constexpr int KDW = SETS == 1 ? SDPA_DUO_KD - 1 : SDPA_DUO_KD;
+            constexpr int KD = NKS < KDW ? NKS : KDW;
+            u32x4 kq[KD];
+#pragma unroll
+            for (int i = 0; i < KD; ++i) kq[i] = kfrag(i);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const u32x4 kf = kq[ks % KD];
+                __builtin_amdgcn_sched_barrier(0);
+                score_link(snxt[0], kf, 0, ks);
+                slices_after(2 * ks, GA, NB_SL, NSL, scur, stc, pcur);
+                __builtin_amdgcn_sched_barrier(0);
+                score_link(snxt[1], kf, 1, ks);
+                if (ks + KD < NKS) kq[ks % KD] = kfrag(ks + KD);
+                if (ks % 4 == 0) dma_k_piece(tk, kw, ks / 4);      // NKS / KPW == 4 for every DK
+                slices_after(2 * ks + 1, GA, NB_SL, NSL, scur, stc, pcur);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_result_fence(snxt[0]);                            // the chains' last links have retired
+            asm volatile("" : "+v"(snxt[1]));
+            // everything older than Vt(t+1)'s request has landed: K(t+2) and Vt(t) with it
+            stage_fence(std::integral_constant<int, (NVB - 1) * KPW + (NVB - 2) * VPW>());
+        } else {
+#pragma unroll
+            for (int i = NB_SL; i < NSL; ++i) slice(i, scur, stc, pcur);
+            stage_fence(std::integral_constant<int, 0>());
+        }
+        pin_o();
+
+        // [B]
+        if constexpr (HAS_NEXT) mask_ragged(snxt, t + 1);
+        constexpr int SLOTS = 2 * NT;                      // Vt fragments of this step (2 MFMAs each)
+        constexpr int VD = SDPA_DUO_VD;
+        const int kr_next = kr == NKB - 1 ? 0 : kr + 1;
+        const unsigned kstep = (unsigned)((kr_next - kr) * KTILE * 2);
+        const int vr_next = vr == NVB - 1 ? 0 : vr + 1;
+        const unsigned vstep = (unsigned)((vr_next - vr) * VTILE * 2);
+        const int tv = min(t + NVB - 1, T - 1);            // past the end: a harmless reload
+        u32x4 vq[VD];
+#pragma unroll
+        for (int i = 0; i < VD; ++i) vq[i] = vfrag(i);
+#pragma unroll
+        for (int slot = 0; slot < SLOTS; ++slot) {
+            const int tt = slot % NT, h = slot / NT;
+            const u32x4 vf = vq[slot % VD];
+            __builtin_amdgcn_sched_barrier(0);
+            oacc[0][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
+                                                                  __builtin_bit_cast(bf16x8, pcur[0][h]),
+                                                                  oacc[0][tt], 0, 0, 0);
+            if constexpr (HAS_NEXT) slices_after(2 * slot, GB, 0, NB_SL, snxt, stn, pnxt);
+            __builtin_amdgcn_sched_barrier(0);
+            oacc[1][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
+                                                                  __builtin_bit_cast(bf16x8, pcur[1][h]),
+                                                                  oacc[1][tt], 0, 0, 0);
+            if (slot + VD < SLOTS) vq[slot % VD] = vfrag(slot + VD);
+            if constexpr (HAS_NEXT) {
+                if (slot % 4 == 1) dma_v_piece(tv, vw, slot / 4);               // SLOTS / VPW == 4 for every DV
+                slices_after(2 * slot + 1, GB, 0, NB_SL, snxt, stn, pnxt);
+                // next step reads the next K buffer: the NKA fragment addresses advance, spread over the slots
+#pragma unroll
+                for (int u = slot * NKA / SLOTS; u < (slot + 1) * NKA / SLOTS; ++u) kaddr[u] += kstep;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        pin_o();
+        if constexpr (HAS_NEXT) {
+            vaddr[0] += vstep;                              // all of this step's Vt reads are issued
+            vaddr[1] += vstep;
+            kr = kr_next;
+            kw = kw == NKB - 1 ? 0 : kw + 1;
+            vr = vr_next;
+            vw = vw == NVB - 1 ? 0 : vw + 1;
+        }
+    };
+
+    if (T > 0) {
+        // fill the rings: K(0..NKB-1), Vt(0..NVB-2)
+#pragma unroll
+        for (int i = 0; i < NKB; ++i) {
+#pragma unroll
+            for (int j = 0; j < KPW; ++j) dma_k_piece(min(i, T - 1), i, j);
+            if (i < NVB - 1) {
+#pragma unroll
+                for (int j = 0; j < VPW; ++j) dma_v_piece(min(i, T - 1), i, j);
+            }
+        }
+        stage_fence(std::integral_constant<int, 0>());
+        f32x16 sA[2], sB[2];
+        u32x4 pA[2][2], pB[2][2];
+        SliceState stA, stB;
+        stA.tmax[0] = stA.tmax[1] = stB.tmax[0] = stB.tmax[1] = -INFINITY;
+        stA.e0 = stA.e1 = stB.e0 = stB.e1 = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const u32x4 kf = kfrag(ks);
+            score_link(sA[0], kf, 0, ks);
+            score_link(sA[1], kf, 1, ks);
+        }
+        mfma_result_fence(sA[0]);
+        mfma_result_fence(sA[1]);
+        mask_ragged(sA, 0);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            float tmax = sA[b][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sA[b][r]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            m_ref[b] = tmax * c;                        // finite: every tile has a valid key row
+        }
+#pragma unroll
+        for (int i = 0; i < NB_SL; ++i) slice(i, sA, stA, pA);     // the part of P(0) a step's [B] would have done
+        __syncthreads();                                // K(0) fully consumed before K(NKB) lands on it
+#pragma unroll
+        for (int u = 0; u < NKA; ++u) kaddr[u] += (unsigned)(KTILE * 2);   // step 0 reads K(1) in buffer 1
+
+        int t = 0;
+        if constexpr (SETS == 2) {
+            for (; t + 2 < T; t += 2) {
+                step(std::true_type(), sA, sB, stA, stB, pA, pB, t);
+                step(std::true_type(), sB, sA, stB, stA, pB, pA, t + 1);
+            }
+            if (T - t == 2) {
+                step(std::true_type(), sA, sB, stA, stB, pA, pB, t);
+                step(std::false_type(), sB, sA, stB, stA, pB, pA, t + 1);
+            } else {
+                step(std::false_type(), sA, sB, stA, stB, pA, pB, t);
+            }
+        } else {            // one score set: it is dead once its slices ran under [B]
+            for (; t + 2 < T; t += 2) {
+                step(std::true_type(), sA, sA, stA, stA, pA, pB, t);
+                step(std::true_type(), sA, sA, stA, stA, pB, pA, t + 1);
+            }
+            if (T - t == 2) {
+                step(std::true_type(), sA, sA, stA, stA, pA, pB, t);
+                step(std::false_type(), sA, sA, stA, stA, pB, pA, t + 1);
+            } else {
+                step(std::false_type(), sA, sA, stA, stA, pA, pB, t);
+            }
+        }
+        if (redo && lane == 0) {                        // flags are per 128-row block of the redo kernel
+            const int q128 = 2 * qblock;
+            a.redo[split * n_qblocks128 + q128] = a.redo_gen;
+            if (q128 + 1 < n_qblocks128) a.redo[split * n_qblocks128 + q128 + 1] = a.redo_gen;
+        }
+    }
+
+    // ---- epilogue: fold the true row max back in
+    float *out = a.contrib;
+    float *omax = a.lmax, *osum = a.lsum;
+    int ldo = a.ldo;
+    if (a.kv_splits > 1) {
+        ldo = a.ws_ld;
+        out = a.ws_contrib + (size_t)split * a.ws_rows * ldo;
+        omax = a.ws_lmax + (size_t)split * a.ws_rows;
+        osum = a.ws_lsum + (size_t)split * a.ws_rows;
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int qrow = qrow0 + 32 * b;
+        const float fold = __builtin_amdgcn_exp2f(-max_rel[b]);
+        const float l_tot = (l_run[b] + __shfl_xor(l_run[b], 32)) * fold;
+        if (qrow < a.m) {
+            float *orow = out + (size_t)qrow * ldo;
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int col = 32 * tt + crow16(r, hi);
+                    if (col < a.dv) orow[col] = oacc[b][tt][r] * fold;
+                }
+            if (hi == 0) {
+                omax[qrow] = T > 0 ? (m_ref[b] + max_rel[b]) * 0.69314718055994530942f : -INFINITY;
+                osum[qrow] = l_tot;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // converts: fp64 -> bf16 (RNE), row-major with zero-padded columns, and the transposed V image
 // ---------------------------------------------------------------------------
 __global__ void cvt_d2bf_kernel(const double *__restrict__ src, unsigned short *__restrict__ dst,
@@ -919,6 +1358,16 @@ int bf16_chunk_dv(int dv) { return dv <= 64 ? 64 : dv <= 128 ? 128 : dv <= 256 ?
 int bf16_pad_dv(int dv) { const int ch = bf16_chunk_dv(dv); return (dv + ch - 1) / ch * ch; }
 long bf16_pad_n(long n) { return (n + 31) / 32 * 32; }
 
+// Which shapes take the two-query-blocks-per-wave kernel: dk and dv both within one 256-wide
+// operand (SDPA_BF16_DUO=0 keeps them on the general kernel -- both are exact paths; the switch
+// exists for A/B timing).
+bool bf16_uses_duo(int dk, int dv) {
+    static const int enabled = getenv("SDPA_BF16_DUO") ? atoi(getenv("SDPA_BF16_DUO")) : 1;
+    return enabled && dk <= 256 && dv <= 256;
+}
+// kernels with a fixed reference exponent flag blocks for a second pass: one int per (split, 128-row block)
+bool bf16_needs_redo(int dk, int dv) { return bf16_chunk_dv(dv) == 512 || bf16_uses_duo(dk, dv); }
+
 // workspace: [kv_splits x m x ws_ld] contrib, [kv_splits x m] lmax, [kv_splits x m] lsum when the
 // shard is split, then (dv > 256) one redo flag per (split, q block) for the wide kernel
 size_t bf16_workspace_bytes(int m, int n_local, int dk, int dv) {
@@ -926,7 +1375,7 @@ size_t bf16_workspace_bytes(int m, int n_local, int dk, int dv) {
     const int s = pick_kv_splits_bf16(m, n_local, dk, dv);
     const int ws_ld = (dv + 3) / 4 * 4;
     size_t bytes = s <= 1 ? 0 : (size_t)s * m * ((size_t)ws_ld + 2) * sizeof(float);
-    if (bf16_chunk_dv(dv) == 512) bytes += (size_t)((m + kQRowsPerBlock - 1) / kQRowsPerBlock) * s * sizeof(int);
+    if (bf16_needs_redo(dk, dv)) bytes += (size_t)((m + kQRowsPerBlock - 1) / kQRowsPerBlock) * s * sizeof(int);
     return bytes;
 }
 void bf16_carve_workspace(Bf16Args &a, void *ws, int ws_ld) {
@@ -938,11 +1387,20 @@ void bf16_carve_workspace(Bf16Args &a, void *ws, int ws_ld) {
         a.ws_lsum = a.ws_lmax + (size_t)a.kv_splits * a.m;
         p = reinterpret_cast<char *>(a.ws_lsum + (size_t)a.kv_splits * a.m);
     }
-    a.redo = bf16_chunk_dv(a.dv) == 512 ? reinterpret_cast<int *>(p) : nullptr;
+    a.redo = bf16_needs_redo(a.dk, a.dv) ? reinterpret_cast<int *>(p) : nullptr;
 }
 
 int pick_kv_splits_bf16(int m, int n_local, int dk, int dv) {
     if (m <= 0 || n_local <= 0) return 1;
+    if (bf16_uses_duo(dk, dv)) {            // 256-row workgroups, one per CU
+        const int nqb = (m + kDuoRows - 1) / kDuoRows;
+        const int ntiles = (n_local + kKvTile - 1) / kKvTile;
+        int want = (256 + nqb - 1) / nqb, cap = ntiles / 8;
+        if (cap < 1) cap = 1;
+        if (want > cap) want = cap;
+        if (want > 64) want = 64;
+        return want < 1 ? 1 : want;
+    }
     const int nqb = (m + kQRowsPerBlock - 1) / kQRowsPerBlock;
     const int chunks = bf16_pad_dv(dv) / bf16_chunk_dv(dv);
     const int ntiles = (n_local + kKvTile - 1) / kKvTile;
@@ -998,6 +1456,29 @@ static hipError_t launch_bf16_wide(const Bf16Args &a, hipStream_t s) {
     const float scale = 1.0f / sqrtf((float)a.dk);   // attention-mpi.c:208
     hipLaunchKernelGGL((fused_bf16_wide_kernel<DK, ABL>), dim3(nqb * chunks * a.kv_splits), dim3(256), lds, s,
                        a, kv_per_split, nqb, chunks, scale);
+    return hipGetLastError();
+}
+
+template <int DK, int DV>
+static hipError_t launch_bf16_duo(const Bf16Args &a, hipStream_t s) {
+    const int nqb = (a.m + kDuoRows - 1) / kDuoRows;
+    const int nqb128 = (a.m + kQRowsPerBlock - 1) / kQRowsPerBlock;
+    const int ntiles = (a.n_local + kKvTile - 1) / kKvTile;
+    const int tiles_per_split = (ntiles + a.kv_splits - 1) / a.kv_splits;
+    const int kv_per_split = tiles_per_split > 0 ? tiles_per_split * kKvTile : kKvTile;
+    const size_t lds = ((size_t)3 * kKvTile * DK + (size_t)2 * DV * kKvTile) * sizeof(unsigned short);
+    static bool attr_done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_bf16_duo_kernel<DK, DV>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done[dev] = true;
+    }
+    const float scale = 1.0f / sqrtf((float)a.dk);   // attention-mpi.c:208
+    hipLaunchKernelGGL((fused_bf16_duo_kernel<DK, DV>), dim3(nqb * a.kv_splits), dim3(256), lds, s, a,
+                       kv_per_split, nqb, nqb128, scale);
     return hipGetLastError();
 }
 
@@ -1058,6 +1539,16 @@ hipError_t launch_shard_partial_bf16(const Bf16Args &args, hipStream_t s) {
         }
     }
     if (reinterpret_cast<uintptr_t>(a.K) & 15) return hipErrorInvalidValue;   // LDS-DMA moves 16-byte chunks
+    if (bf16_uses_duo(a.dk, a.dv)) {
+        if ((reinterpret_cast<uintptr_t>(a.Vt) & 15) || !a.redo) return hipErrorInvalidValue;
+#define SDPA_DCASE(KP, VC) if (kp == KP && vc == VC) e = launch_bf16_duo<KP, VC>(a, s);
+        SDPA_DCASE(64, 64)  SDPA_DCASE(64, 128)  SDPA_DCASE(64, 256)
+        SDPA_DCASE(128, 64) SDPA_DCASE(128, 128) SDPA_DCASE(128, 256)
+        SDPA_DCASE(256, 64) SDPA_DCASE(256, 128) SDPA_DCASE(256, 256)
+#undef SDPA_DCASE
+        if (e != hipSuccess) return e;
+        // then the general kernel over the blocks the duo kernel flagged (in-loop rescale)
+    }
 #define SDPA_BCASE(KP, VC) \
     if (kp == KP && vc == VC) e = launch_bf16_pipe<KP, VC>(a, s);
     SDPA_BCASE(64, 64)  SDPA_BCASE(64, 128)  SDPA_BCASE(64, 256)

@@ -75,7 +75,7 @@ struct Rank {
     hipEvent_t ev_q[2] = {}, ev_run[2] = {}, ev_out[2] = {};
     hipEvent_t ev_sub[2][kMaxSub] = {};
     hipEvent_t ev_qh[kMaxSub] = {}, ev_qp[kMaxSub] = {};   // Q piece j: copied / converted
-    std::vector<hipEvent_t> ev_h2d;      // K/V chunk c has crossed PCIe
+    std::vector<hipEvent_t> ev_h2d;      // [2c] K rows, [2c+1] V rows of chunk c have crossed PCIe
     std::vector<hipEvent_t> ev_kv;       // K/V chunk c is converted into the operand image
     std::vector<hipEvent_t> ev_k;        // fused-kernel timing brackets (rank 0)
     hipEvent_t ev_t0 = nullptr, ev_kv_done = nullptr, ev_end = nullptr;
@@ -358,8 +358,10 @@ int ensure_buffers(const Plan &pl) {
             hipEvent_t e;
             HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             rk.ev_kv.push_back(e);
-            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            rk.ev_h2d.push_back(e);
+            for (int h = 0; h < 2; ++h) {
+                HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                rk.ev_h2d.push_back(e);
+            }
         }
     }
     return SDPA_OK;
@@ -426,7 +428,7 @@ int launch_fused(const Plan &pl, Rank &rk, const RankPlan &rp, int s, int bs, in
         a.contrib = contrib; a.ldo = pl.ldo; a.lmax = lmax; a.lsum = lsum;
         a.ws_contrib = sl_c; a.ws_lmax = sl_m; a.ws_lsum = sl_s;
         a.ws_ld = pl.ldo; a.ws_rows = bs; a.defer_merge = 1;
-        a.redo = sdpa::bf16_chunk_dv(pl.dv) == 512 ? (int *)rk.ws.p : nullptr;
+        a.redo = sdpa::bf16_needs_redo(pl.dk, pl.dv) ? (int *)rk.ws.p : nullptr;
     } else {
         a.contrib = contrib; a.ldo = pl.ldo; a.lmax = lmax; a.lsum = lsum;
         sdpa::bf16_carve_workspace(a, rk.ws.p, pl.ldo);
@@ -452,32 +454,57 @@ int merge_slots(const Plan &pl, Rank &rk, const RankPlan &rp, int s, int bs, int
     return SDPA_OK;
 }
 
-// K/V chunk c of the rank's shard: host -> device into the fp64 staging image on the copy stream,
-// then the convert into the operand image (attention-mpi.c:224-225 / :248-249 and the Scatterv of
-// :258-264) on the convert stream.
-int stage_chunk(const Plan &pl, Rank &rk, const RankPlan &rp, const double *K, const double *V, int c) {
+// K rows (is_v = false) or V rows (true) of chunk c of the rank's shard: host -> device into the
+// fp64 staging image on the copy stream, then the convert into the operand image
+// (attention-mpi.c:224-225 / :248-249 and the Scatterv of :258-264) on the convert stream.
+int stage_half(const Plan &pl, Rank &rk, const RankPlan &rp, const double *src, int c, bool is_v) {
     const Chunk &ch = rp.chunks[c];
     const size_t row0 = (size_t)rp.key_off + ch.k0;
-    double *k64 = (double *)rk.k64.p + (size_t)ch.k0 * pl.dk;
-    double *v64 = (double *)rk.v64.p + (size_t)ch.k0 * pl.dv;
-    HIP_TRY(hipMemcpyAsync(k64, K + row0 * pl.dk, (size_t)ch.keys * pl.dk * sizeof(double), hipMemcpyHostToDevice,
+    const int cols = is_v ? pl.dv : pl.dk;
+    double *stage = (double *)(is_v ? rk.v64.p : rk.k64.p) + (size_t)ch.k0 * cols;
+    hipEvent_t copied = rk.ev_h2d[2 * c + (is_v ? 1 : 0)];
+    HIP_TRY(hipMemcpyAsync(stage, src + row0 * cols, (size_t)ch.keys * cols * sizeof(double), hipMemcpyHostToDevice,
                            rk.s_cp));
-    HIP_TRY(hipMemcpyAsync(v64, V + row0 * pl.dv, (size_t)ch.keys * pl.dv * sizeof(double), hipMemcpyHostToDevice,
-                           rk.s_cp));
-    HIP_TRY(hipEventRecord(rk.ev_h2d[c], rk.s_cp));
-    HIP_TRY(hipStreamWaitEvent(rk.s_in, rk.ev_h2d[c], 0));
-    if (pl.bf16) {
-        HIP_TRY(sdpa::launch_cvt_d2bf(k64, (unsigned short *)rk.kf.p + (size_t)ch.k0 * pl.ldk, ch.keys, pl.dk, pl.ldk,
-                                      rk.s_in));
+    HIP_TRY(hipEventRecord(copied, rk.s_cp));
+    HIP_TRY(hipStreamWaitEvent(rk.s_in, copied, 0));
+    if (!is_v) {
+        if (pl.bf16)
+            HIP_TRY(sdpa::launch_cvt_d2bf(stage, (unsigned short *)rk.kf.p + (size_t)ch.k0 * pl.ldk, ch.keys, pl.dk,
+                                          pl.ldk, rk.s_in));
+        else
+            HIP_TRY(sdpa::launch_cvt_d2f(stage, (float *)rk.kf.p + (size_t)ch.k0 * pl.ldk, ch.keys, pl.dk, pl.ldk,
+                                         rk.s_in));
+    } else if (pl.bf16) {
         const long ldn = sdpa::bf16_pad_n(rp.key_cnt);
-        const bool last = c + 1 == (int)rp.chunks.size();
-        const long pad = last ? ldn - ch.k0 : ch.keys;       // the image's zero tail belongs to the last chunk
-        HIP_TRY(sdpa::launch_cvt_d2bf_t_part(v64, (unsigned short *)rk.vf.p + ch.k0, ch.keys, pad, pl.dv,
+        const bool last = ch.k0 + ch.keys == rp.key_cnt;
+        const long pad = last ? ldn - ch.k0 : ch.keys;       // the image's zero tail belongs to the last keys
+        HIP_TRY(sdpa::launch_cvt_d2bf_t_part(stage, (unsigned short *)rk.vf.p + ch.k0, ch.keys, pad, pl.dv,
                                              sdpa::bf16_pad_dv(pl.dv), ldn, rk.s_in));
     } else {
-        HIP_TRY(sdpa::launch_cvt_d2f(k64, (float *)rk.kf.p + (size_t)ch.k0 * pl.ldk, ch.keys, pl.dk, pl.ldk, rk.s_in));
-        HIP_TRY(sdpa::launch_cvt_d2f(v64, (float *)rk.vf.p + (size_t)ch.k0 * pl.ldv, ch.keys, pl.dv, pl.ldv, rk.s_in));
+        HIP_TRY(sdpa::launch_cvt_d2f(stage, (float *)rk.vf.p + (size_t)ch.k0 * pl.ldv, ch.keys, pl.dv, pl.ldv,
+                                     rk.s_in));
     }
+    return SDPA_OK;
+}
+
+// What sdpa_kv_prefetch() has already put on the devices for the NEXT compute call.
+struct Prefetched {
+    bool active = false;
+    const double *K = nullptr, *V = nullptr;
+    int m = 0, n = 0, dk = 0, dv = 0, flags = 0;
+    std::vector<std::vector<char>> k_done, v_done;     // [rank][chunk]
+    void reset() { *this = Prefetched(); }
+    bool matches(const double *k, const double *v, int m_, int n_, int dk_, int dv_, int flags_) const {
+        return active && K == k && V == v && m == m_ && n == n_ && dk == dk_ && dv == dv_ && flags == flags_;
+    }
+};
+Prefetched &PF = *new Prefetched;
+
+// Both halves of chunk c (skipping what a prefetch already moved), then the chunk's ready event.
+int stage_chunk(const Plan &pl, Rank &rk, const RankPlan &rp, int g, const double *K, const double *V, int c) {
+    const bool have_k = PF.active && PF.k_done[g][c], have_v = PF.active && PF.v_done[g][c];
+    if (!have_k) SDPA_TRY(stage_half(pl, rk, rp, K, c, false));
+    if (!have_v) SDPA_TRY(stage_half(pl, rk, rp, V, c, true));
     HIP_TRY(hipEventRecord(rk.ev_kv[c], rk.s_in));
     return SDPA_OK;
 }
@@ -632,6 +659,7 @@ extern "C" {
 
 void sdpa_shutdown(void) {
     DeviceRestore restore;
+    PF.reset();
     for (Rank &g : E.r) destroy_rank(g);
     E.r.clear();
     delete E.coll;
@@ -675,6 +703,15 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
     make_plan(pl, m, n, dk, dv, flags);
     SDPA_TRY(ensure_buffers(pl));
     const int P = pl.P;
+    // K/V rows a sdpa_kv_prefetch() of THIS problem already moved are not moved again; a prefetch
+    // of anything else is void (the staging images are about to be overwritten)
+    if (PF.active && !PF.matches(K, V, m, n, dk, dv, flags)) PF.reset();
+    if (PF.active) {          // and only if it was planned the way this call is (the knobs are environment)
+        bool same = (int)PF.k_done.size() == P;
+        for (int g = 0; same && g < P; ++g) same = PF.k_done[g].size() == pl.r[g].chunks.size();
+        if (!same) PF.reset();
+    }
+    struct ClearPrefetch { ~ClearPrefetch() { PF.reset(); } } clear_prefetch;   // one-shot, also on errors
 
     // Page-lock the caller's arrays for the duration of the call.  Copies from pages the driver
     // has never seen run at ~11 GB/s on this platform (measured, tools/probes/h2d_probe.cpp);
@@ -738,7 +775,7 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
             // copy + convert streams: K/V chunk 0, the Q batch (in pieces for batch 0), the remaining
             // chunks.  q64[s] was last read by the convert of batch b-2 (ev_q[s]); qf[s] by its
             // kernels (ev_run[s]).
-            if (b == 0 && C > 0) SDPA_TRY(stage_chunk(pl, rk, rp, K, V, 0));
+            if (b == 0 && C > 0) SDPA_TRY(stage_chunk(pl, rk, rp, g, K, V, 0));
             if (b >= 2) {
                 HIP_TRY(hipStreamWaitEvent(rk.s_cp, rk.ev_q[s], 0));
                 HIP_TRY(hipStreamWaitEvent(rk.s_in, rk.ev_run[s], 0));
@@ -751,7 +788,7 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
                 SDPA_TRY(stage_q_rows(pl, rk, Q, s, i0, 0, bs, rk.ev_qh[0], rk.ev_q[s]));
             }
             if (b == 0) {
-                for (int c = 1; c < C; ++c) SDPA_TRY(stage_chunk(pl, rk, rp, K, V, c));
+                for (int c = 1; c < C; ++c) SDPA_TRY(stage_chunk(pl, rk, rp, g, K, V, c));
                 if (g == 0) HIP_TRY(hipEventRecord(rk.ev_kv_done, rk.s_in));
             }
 
@@ -921,6 +958,45 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
     T.plan = pl.qrows ? 1 : 0;
     T.merge = !pl.collectives ? 0 : (pl.merge_allreduce ? 2 : 1);
     T.virtual_ranks = E.virtual_ranks ? 1 : 0;
+    return SDPA_OK;
+}
+
+int sdpa_kv_prefetch(const double *K, const double *V, int m, int n, int dk, int dv, int flags,
+                     int k_rows_final, int v_rows_final) {
+    SDPA_TRY(check_shape(K, K, V, V, m, n, dk, dv, flags, true));
+    if (k_rows_final < 0 || v_rows_final < 0 || k_rows_final > n || v_rows_final > n) return SDPA_EINVAL;
+    DeviceRestore restore;
+    SDPA_TRY(lazy_init());
+    Plan pl;
+    make_plan(pl, m, n, dk, dv, flags);
+    if (!PF.matches(K, V, m, n, dk, dv, flags)) {
+        SDPA_TRY(ensure_buffers(pl));
+        PF.reset();
+        PF.active = true;
+        PF.K = K; PF.V = V; PF.m = m; PF.n = n; PF.dk = dk; PF.dv = dv; PF.flags = flags;
+        PF.k_done.resize(pl.P);
+        PF.v_done.resize(pl.P);
+        for (int g = 0; g < pl.P; ++g) {
+            PF.k_done[g].assign(pl.r[g].chunks.size(), 0);
+            PF.v_done[g].assign(pl.r[g].chunks.size(), 0);
+        }
+    }
+    for (int g = 0; g < pl.P; ++g) {
+        Rank &rk = E.r[g];
+        const RankPlan &rp = pl.r[g];
+        HIP_TRY(hipSetDevice(rk.dev));
+        for (size_t c = 0; c < rp.chunks.size(); ++c) {
+            const int end = rp.key_off + rp.chunks[c].k0 + rp.chunks[c].keys;     // global row past the chunk
+            if (!PF.k_done[g][c] && end <= k_rows_final) {
+                SDPA_TRY(stage_half(pl, rk, rp, K, (int)c, false));
+                PF.k_done[g][c] = 1;
+            }
+            if (!PF.v_done[g][c] && end <= v_rows_final) {
+                SDPA_TRY(stage_half(pl, rk, rp, V, (int)c, true));
+                PF.v_done[g][c] = 1;
+            }
+        }
+    }
     return SDPA_OK;
 }
 

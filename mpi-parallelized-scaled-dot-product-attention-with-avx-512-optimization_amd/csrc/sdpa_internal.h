@@ -65,6 +65,7 @@ long bf16_pad_n(long n);
 __host__ __device__ inline constexpr long bf16_kvpos(long j) {
     return (j & ~12L) | ((j & 4) << 1) | ((j & 8) >> 1);
 }
+bool bf16_needs_redo(int dk, int dv);  // the shape's kernel flags blocks for a second pass (workspace holds the flags)
 int  pick_kv_splits_bf16(int m, int n_local, int dk, int dv);
 size_t bf16_workspace_bytes(int m, int n_local, int dk, int dv);
 void bf16_carve_workspace(Bf16Args &a, void *ws, int ws_ld);   // needs a.m, a.dv, a.kv_splits

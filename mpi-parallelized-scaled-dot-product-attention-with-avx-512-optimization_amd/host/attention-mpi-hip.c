@@ -47,6 +47,7 @@ int main(int argc, char **argv)
     MPI_Comm_rank(MPI_COMM_WORLD, &rank);
     MPI_Comm_size(MPI_COMM_WORLD, &size);
 
+    const double t_start = now_ms();
     const bool verbose = getenv("SDPA_VERBOSE") != NULL;
     const bool time_init = getenv("SDPA_TIME_INIT") != NULL;
 
@@ -88,7 +89,8 @@ int main(int argc, char **argv)
         fflush(stdout);
         if (nonfinite) fprintf(stderr, "%s: %ld non-finite result values\n", cli_name, nonfinite);
         if (verbose) {
-            fprintf(stderr, "%s: %d MPI ranks (rank 0 drives the GPUs)\n", cli_name, size);
+            fprintf(stderr, "%s: %d MPI ranks (rank 0 drives the GPUs); start -> result checked %.1f ms\n", cli_name,
+                    size, now_ms() - t_start);
             report_verbose(m, n, dk, dv, worst);
         }
         release_host_bufs();        /* before the engine goes away: pinned memory is the runtime's */

@@ -56,11 +56,14 @@ def test_bf16_image_geometry_helpers(pkg):
         for hi in range(2):
             assert [pos[crow(8 * h + j, hi)] for j in range(8)] == list(range(16 * h + 8 * hi, 16 * h + 8 * hi + 8))
     assert lib.sdpa_dev_bf16_kvpos(-1) < 0
-    # split buffers ([splits x m x (ld(dv) + 2)] floats) when the shard is split in-GPU, and for
-    # dv > 256 one redo flag per (split, 128-row q block)
+    # split buffers ([splits x m x (ld(dv) + 2)] floats) when the shard is split in-GPU, and one
+    # redo flag per (split, 128-row q block) for the kernels with a fixed reference exponent
+    # (dv > 256: wide kernel; dk, dv <= 128: duo kernel)
     s1 = lib.sdpa_dev_kv_splits_bf16(32768, 65536, 128, 128)
-    assert lib.sdpa_dev_workspace_bytes_bf16(32768, 65536, 128, 128) == (s1 * 32768 * (128 + 2) * 4 if s1 > 1 else 0)
-    assert lib.sdpa_dev_kv_splits_bf16(70000, 4096, 64, 64) == 1 and lib.sdpa_dev_workspace_bytes_bf16(70000, 4096, 64, 64) == 0
+    assert lib.sdpa_dev_workspace_bytes_bf16(32768, 65536, 128, 128) == (s1 * 32768 * (128 + 2) * 4 if s1 > 1 else 0) + 256 * s1 * 4
+    s0 = lib.sdpa_dev_kv_splits_bf16(32768, 65536, 256, 256)
+    assert lib.sdpa_dev_workspace_bytes_bf16(32768, 65536, 256, 256) == (s0 * 32768 * (256 + 2) * 4 if s0 > 1 else 0)
+    assert lib.sdpa_dev_kv_splits_bf16(70000, 4096, 64, 64) == 1 and lib.sdpa_dev_workspace_bytes_bf16(70000, 4096, 64, 64) == 547 * 4
     splits = lib.sdpa_dev_kv_splits_bf16(32768, 65536, 512, 512)
     assert splits == 1 and lib.sdpa_dev_workspace_bytes_bf16(32768, 65536, 512, 512) == 256 * 4
     s2 = lib.sdpa_dev_kv_splits_bf16(256, 8192, 512, 512)

@@ -122,6 +122,50 @@ def test_bf16_wide_steep_scores_take_the_redo_pass(pkg, be, O):
     assert np.isfinite(got2).all() and np.abs(got2 - want2).max() <= 4e-3 * max(1.0, np.abs(V2).max())
 
 
+@pytest.mark.parametrize("d", [64, 128, 256])
+def test_bf16_duo_steep_scores_take_the_redo_pass(d, pkg, be, O):
+    """dk, dv <= 256 run the duo kernel (two query blocks per wave, 256-row workgroups), which like
+    the wide kernel keeps the first tile's reference exponent: a workgroup in which some row's max
+    climbs more than 2^32 above it flags its two 128-row blocks and the general kernel redoes them.
+    Rows 0..127 climb 0.5 nat per key (workgroup 0 is redone, including its flat rows 128..255);
+    workgroup 1 (rows 256..511, flat scores) must stay on the duo kernel's own result."""
+    m, n = 512, 1024
+    rng = np.random.default_rng(17 + d)
+    Q = np.zeros((m, d)); K = np.zeros((n, d))
+    Q[:128, 0] = np.sqrt(d)                       # score_j = K[j, 0]
+    K[:, 0] = 0.5 * np.arange(n)
+    K[:, 1:] = rng.standard_normal((n, d - 1)) * 0.1
+    V = rng.standard_normal((n, d))
+    got = dev_attention_bf16(pkg, be, Q, K, V)
+    want = O.numpy_attention_f64(to_bf16_f64(Q), to_bf16_f64(K), to_bf16_f64(V))
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= 4e-3 * max(1.0, np.abs(V).max())
+    assert np.abs(got[128:] - to_bf16_f64(V).mean(axis=0)).max() <= 4e-3 * max(1.0, np.abs(V).max())
+    # with K/V splits on top, and a ragged last tile
+    n2 = 8192 + 13
+    K2 = np.zeros((n2, d)); K2[:, 0] = 0.25 * np.arange(n2); K2[:, 1:] = rng.standard_normal((n2, d - 1)) * 0.1
+    V2 = rng.standard_normal((n2, d))
+    assert pkg.load().sdpa_dev_kv_splits_bf16(m, n2, d, d) > 1
+    got2 = dev_attention_bf16(pkg, be, Q, K2, V2)
+    want2 = O.numpy_attention_f64(to_bf16_f64(Q), to_bf16_f64(K2), to_bf16_f64(V2))
+    assert np.isfinite(got2).all() and np.abs(got2 - want2).max() <= 4e-3 * max(1.0, np.abs(V2).max())
+
+
+@pytest.mark.parametrize("dk,dv", [(64, 64), (64, 128), (128, 64), (128, 128), (64, 256), (256, 64), (128, 256),
+                                   (256, 128), (256, 256), (72, 200), (200, 40)])
+def test_bf16_duo_every_instantiation(dk, dv, pkg, be, orc, O):
+    """each <DK, DV> instantiation of the duo kernel at a size with several 256-row workgroups,
+    in-GPU K/V splits and ragged rows / keys, vs the fp64 oracle, plus run-to-run bit identity
+    (its tiles move by LDS-DMA behind counted waits: a missing wait shows as rare wrong tiles)"""
+    m, n = 700, 5000 + dk
+    Q, K, V = O.make_inputs(m, n, dk, dv, "D2", seed=dk + dv)
+    got = dev_attention_bf16(pkg, be, Q, K, V)
+    assert np.isfinite(got).all()
+    assert np.abs(got - orc.attention_f64(Q, K, V)).max() <= bf16_tol(V)
+    for _ in range(5):
+        assert np.array_equal(dev_attention_bf16(pkg, be, Q, K, V), got)
+
+
 def test_bf16_kv_splits_and_triple(pkg, be, O):
     """long K/V with few query blocks: in-GPU splits; the triple's lmax is the fp32-exact row max of
     the bf16-rounded scores"""

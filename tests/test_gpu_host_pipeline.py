@@ -188,6 +188,40 @@ def test_rccl_calls_on_a_one_rank_communicator(engine, orc, O):
         check(got, want, V, "rccl one rank, " + merge)
 
 
+def test_kv_prefetch_then_compute(engine, orc, O):
+    """sdpa_kv_prefetch (reading K/V and moving them overlap): rows announced in
+    pieces, K first then V as the file stores them; the following compute call skips what is staged
+    and must give the same bits as a call without prefetch; a prefetch of other arrays is void"""
+    pkg = engine(SDPA_KV_CHUNK_MIN=1024, SDPA_KV_CHUNK_MAX=2048, SDPA_PIECE_MIN_ROWS=128)
+    lib = pkg.load()
+    m, n, dk, dv = 700, 9000, 128, 128
+    Q, K, V = O.make_inputs(m, n, dk, dv, "D2", seed=61)
+    want = orc.attention_f64(Q, K, V)
+    plain = pkg.attention(Q, K, V)
+    check(plain, want, V, "no prefetch")
+    Kc, Vc = np.ascontiguousarray(K), np.ascontiguousarray(V)
+    for r in range(0, n, 1500):
+        assert lib.sdpa_kv_prefetch(Kc.ctypes.data, Vc.ctypes.data, m, n, dk, dv, 0, min(n, r + 1500), 0) == 0
+    for r in range(0, n, 2100):
+        assert lib.sdpa_kv_prefetch(Kc.ctypes.data, Vc.ctypes.data, m, n, dk, dv, 0, n, min(n, r + 2100)) == 0
+    got = pkg.attention(Q, Kc, Vc)
+    assert np.array_equal(got, plain), "prefetched K/V must give the same bits"
+    # partial prefetch (K only, half of it), then compute
+    assert lib.sdpa_kv_prefetch(Kc.ctypes.data, Vc.ctypes.data, m, n, dk, dv, 0, n // 2, 0) == 0
+    assert np.array_equal(pkg.attention(Q, Kc, Vc), plain)
+    # a prefetch for different arrays / dims must not leak into this call
+    K2, V2 = K * 0.5, V + 1.0
+    assert lib.sdpa_kv_prefetch(K2.ctypes.data, V2.ctypes.data, m, n, dk, dv, 0, n, n) == 0
+    assert np.array_equal(pkg.attention(Q, Kc, Vc), plain)
+    assert lib.sdpa_kv_prefetch(Kc.ctypes.data, Vc.ctypes.data, m, n, dk, dv, 0, n + 1, 0) == pkg._lib.SDPA_EINVAL
+    # bf16 image and virtual ranks
+    pkg = engine(SDPA_VIRTUAL_GPUS=3, SDPA_KV_CHUNK_MIN=1024, SDPA_KV_CHUNK_MAX=1024, SDPA_PIECE_MIN_ROWS=128)
+    lib = pkg.load()
+    plain = pkg.attention(Q, Kc, Vc, precision="bf16")
+    assert lib.sdpa_kv_prefetch(Kc.ctypes.data, Vc.ctypes.data, m, n, dk, dv, 2, n, n - 1000) == 0
+    assert np.array_equal(pkg.attention(Q, Kc, Vc, precision="bf16"), plain)
+
+
 def test_engine_restores_the_callers_device_and_survives_reinit(engine, O, orc):
     pkg = engine()
     torch.cuda.set_device(0)

@@ -310,7 +310,8 @@ def test_cli_io_modes_and_pinned_host_arrays(tmp_path, pkg, orc, O):
     SDPA_PINNED_IO=0, and creates the engine inside the timed call with SDPA_TIME_INIT=1 -- same
     verdict each way; sdpa_host_alloc memory works as caller arrays of the boundary call"""
     case = os.path.join(GOLD, "cfg1_small_D1.bin")
-    for env in ({}, {"SDPA_PINNED_IO": "0"}, {"SDPA_TIME_INIT": "1"}):
+    for env in ({}, {"SDPA_PINNED_IO": "0"}, {"SDPA_TIME_INIT": "1"}, {"SDPA_CLI_PREFETCH": "1"},
+                {"SDPA_CLI_PREFETCH": "1", "SDPA_PINNED_IO": "0", "SDPA_VIRTUAL_GPUS": "2"}):
         r = subprocess.run([CLI, case], capture_output=True, text=True, env=dict(os.environ, **env))
         assert r.returncode == 0 and r.stdout.startswith("Correct!\nElapsed time: "), (env, r.stderr)
     import ctypes

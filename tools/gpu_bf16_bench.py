@@ -5,7 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("mpi-parallelized-scaled-dot-product-attention-with-avx-512-optimization_amd")
 be = pkg.HipBackend("cuda:0")
-for (m, n, d) in [(32768, 65536, 512), (32768, 65536, 384), (32768, 65536, 256), (32768, 65536, 128), (32768, 65536, 64), (8192, 8192, 128)]:
+dims = [int(x) for x in sys.argv[1:]] or [512, 384, 256, 128, 64]
+for (m, n, d) in [(32768, 65536, d) for d in dims] + [(8192, 8192, 128)]:
     g = torch.Generator(device="cuda"); g.manual_seed(1)
     Q = torch.rand((m, d), generator=g, device="cuda", dtype=torch.float64) * 2 - 1
     K = torch.rand((n, d), generator=g, device="cuda", dtype=torch.float64) * 2 - 1
@@ -17,7 +18,7 @@ for (m, n, d) in [(32768, 65536, 512), (32768, 65536, 384), (32768, 65536, 256),
     for _ in range(2): sa.batch_partial(qb)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 5
+    reps = 10
     e0.record()
     for _ in range(reps): out = sa.batch_partial(qb)
     e1.record(); torch.cuda.synchronize()
@@ -25,4 +26,5 @@ for (m, n, d) in [(32768, 65536, 512), (32768, 65536, 384), (32768, 65536, 256),
     flop = 4.0 * m * n * d
     print(json.dumps({"shape": [m, n, d], "kernel_ms": ms, "tflops": flop / ms / 1e9,
                       "frac_of_2.5PF": flop / ms / 1e9 / 2500.0,
-                      "kv_splits": pkg.load().sdpa_dev_kv_splits_bf16(m, n, d, d)}))
+                      "kv_splits": pkg.load().sdpa_dev_kv_splits_bf16(m, n, d, d),
+                      "duo": os.environ.get("SDPA_BF16_DUO", "1")}), flush=True)
