@@ -85,15 +85,25 @@ def cpu_baseline(m, n, d, budget_rows=8192):
             with tempfile.TemporaryDirectory(dir="/tmp") as td:
                 path = os.path.join(td, "sample.bin")
                 O.write_case(path, Q, K, V, ans)
-                best = None
-                for _ in range(2):
-                    out = subprocess.run([mpiexec, "-n", str(cores), exe, path], capture_output=True,
+                def run_ref(binary, file_path, ranks):
+                    out = subprocess.run([mpiexec, "-n", str(ranks), binary, file_path], capture_output=True,
                                          text=True, timeout=600).stdout
                     mt = re.search(r"Correct!\s*\nElapsed time: ([0-9.]+) us", out)
                     if not mt:
                         raise RuntimeError("reference run did not print Correct!: %r" % out[:200])
-                    us = float(mt.group(1))
-                    best = us if best is None else min(best, us)
+                    return float(mt.group(1))
+                # the reference shards K/V over its ranks, so at many ranks each holds few rows and the
+                # per-batch collectives dominate: probe a few rank counts on a quarter of the sample and
+                # time the best one on the whole sample (reported next to the all-cores number)
+                probe_rows = max(256, rows // 4)
+                probe_path = os.path.join(td, "probe.bin")
+                O.write_case(probe_path, Q[:probe_rows], K, V, ans[:probe_rows])
+                tried = {}
+                for r in sorted({cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8)}, reverse=True):
+                    tried[r] = probe_rows / (run_ref(exe, probe_path, r) * 1e-6)
+                best_ranks = max(tried, key=tried.get)
+                best = min(run_ref(exe, path, best_ranks) for _ in range(2))
+                all_cores_us = best if best_ranks == cores else run_ref(exe, path, cores)
                 # the documented build line has no -O flag (README.md:131): time that binary too,
                 # on a quarter of the sample
                 doc = None
@@ -102,16 +112,19 @@ def cpu_baseline(m, n, d, budget_rows=8192):
                     r0 = max(256, rows // 4)
                     path0 = os.path.join(td, "sample0.bin")
                     O.write_case(path0, Q[:r0], K, V, ans[:r0])
-                    out = subprocess.run([mpiexec, "-n", str(cores), exe0, path0], capture_output=True,
-                                         text=True, timeout=600).stdout
-                    mt = re.search(r"Correct!\s*\nElapsed time: ([0-9.]+) us", out)
-                    if mt:
-                        doc = dict(value=r0 / (float(mt.group(1)) * 1e-6), unit="Q-rows/s",
+                    try:
+                        doc = dict(value=r0 / (run_ref(exe0, path0, best_ranks) * 1e-6), unit="Q-rows/s", ranks=best_ranks,
                                    sample="%d rows" % r0, build="documented flags: no -O (README.md:131)")
-            return dict(value=rows / (best * 1e-6), unit="Q-rows/s", cores=cores, kind="reference",
+                    except RuntimeError:
+                        doc = None
+            return dict(value=rows / (best * 1e-6), unit="Q-rows/s", cores=best_ranks, kind="reference",
                         sample=sample, tflops=flop / (best * 1e-6) / 1e12, cpu=model,
                         build="attention-mpi.c unmodified, mpicc -O3 + AVX-512 flags, MPICH ch3:nemesis, "
-                              "its own Elapsed time (best of 2)", documented_flags=doc)
+                              "its own Elapsed time (best of 2) at the best of the probed rank counts",
+                        physical_cores=cores,
+                        all_physical_cores={"ranks": cores, "value": rows / (all_cores_us * 1e-6), "unit": "Q-rows/s"},
+                        rank_probe={"rows": probe_rows, "q_rows_per_s": {str(k): v for k, v in sorted(tried.items())}},
+                        documented_flags=doc)
         except Exception as e:  # noqa: BLE001
             sys.stderr.write("bench: reference CPU baseline unavailable (%s); using the oracle port\n" % e)
     orc = O.Oracle()
@@ -417,8 +430,9 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         peak = BF16_MFMA_PEAK_TFLOPS if args.precision == "bf16" else F32_MFMA_PEAK_TFLOPS
         if args.precision == "bf16":
-            kernel_name = ("sdpa::fused_bf16_wide_kernel<%d,0> (+ its redo pass)" % (512 if d > 256 else 256 if d > 128 else 128 if d > 64 else 64)
-                           if d > 256 else "sdpa::fused_bf16_pipe_kernel")
+            pad = 512 if d > 256 else 256 if d > 128 else 128 if d > 64 else 64
+            kernel_name = ("sdpa::fused_bf16_wide_kernel<%d,0> (+ its redo pass)" % pad if d > 256
+                           else "sdpa::fused_bf16_duo_kernel<%d,%d> (+ its redo pass)" % (pad, pad))
         elif d in (64, 128):
             kernel_name = "sdpa::fused_pipelined_kernel<%d,%d,0>" % (d, d)
         elif 128 < d <= 512:

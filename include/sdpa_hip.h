@@ -216,8 +216,13 @@ SDPA_API int sdpa_dev_finish_f64(const float *contrib, int ldo, const float *lsu
 /* ---- device level, bf16-input MFMA variant (BASELINE.json config 5) ---------- */
 /* Same stage as sdpa_dev_shard_partial_f32 with operands rounded to bf16 (RNE) and
  * fp32 accumulation; tolerance 1e-2*max(1,max|V|).  Operand images:
- *   Qb[m x ld], Kb[n_local x ld]   bf16 row-major, ld = sdpa_dev_bf16_ld(dk) (dk padded to
- *                                  64/128/256/512), pad columns zero;
+ *   Kb[n_local x ld]               bf16 row-major, ld = sdpa_dev_bf16_ld(dk) (dk padded to
+ *                                  64/128/256/512), pad columns zero (sdpa_dev_cvt_d2bf);
+ *   Qb[m x ld]                     the same layout, but holding bf16(Q * log2(e)/sqrtf(dk)): the
+ *                                  softmax scale (attention-mpi.c:208) and the change of base for
+ *                                  v_exp_f32 are folded into the operand BEFORE its one rounding
+ *                                  (sdpa_dev_cvt_d2bf_q) -- the kernels' score chains deliver
+ *                                  exp2-domain scores and a softmax weight costs one instruction;
  *   Vt[dvp x ldvt]                 bf16, V TRANSPOSED with the keys of a row permuted inside
  *                                  16-key groups: Vt[c*ldvt + sdpa_dev_bf16_kvpos(j)] = V[j][c],
  *                                  kvpos(j) = j with bits 2 and 3 swapped (group order 0-3, 8-11,
@@ -225,14 +230,17 @@ SDPA_API int sdpa_dev_finish_f64(const float *contrib, int ldo, const float *lsu
  *                                  16 contiguous bytes);
  *                                  dvp = sdpa_dev_bf16_dvp(dv), ldvt = sdpa_dev_bf16_ldn(n_local)
  *                                  (n_local padded to 32), pads zero.
- * sdpa_dev_cvt_d2bf / sdpa_dev_cvt_d2bf_t write these images from dense fp64.
- * dk <= 512, dv <= 1024.                                                          */
+ * sdpa_dev_cvt_d2bf_q (Q), sdpa_dev_cvt_d2bf (K) and sdpa_dev_cvt_d2bf_t (V) write these images
+ * from dense fp64.  dk <= 512, dv <= 1024.  lmax/lsum/contrib are those of the scores so computed
+ * (lmax in natural-log units, as in the fp32 variant).                              */
 SDPA_API int  sdpa_dev_bf16_ld(int dk);
 SDPA_API int  sdpa_dev_bf16_dvp(int dv);
 SDPA_API long sdpa_dev_bf16_ldn(long n_local);
 SDPA_API long sdpa_dev_bf16_kvpos(long j);
 SDPA_API int  sdpa_dev_cvt_d2bf(const double *src, void *dst, long rows, int cols, int ld,
                                 void *stream);
+SDPA_API int  sdpa_dev_cvt_d2bf_q(const double *src, void *dst, long rows, int dk, int ld,
+                                  void *stream);
 SDPA_API int  sdpa_dev_cvt_d2bf_t(const double *src, void *dst, long rows, int cols, int cols_pad,
                                   long ldt, void *stream);
 SDPA_API int    sdpa_dev_kv_splits_bf16(int m, int n_local, int dk, int dv);

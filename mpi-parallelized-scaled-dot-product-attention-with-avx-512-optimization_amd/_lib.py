@@ -11,7 +11,9 @@ import re
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
-LIB_PATH = os.path.join(PKG_DIR, "lib", "libsdpa_hip.so")
+# $SDPA_HIP_LIB: a differently built copy of the same library (tools/build_variant.sh builds tuning
+# variants into lib/variants/ for A/B timing); the product is lib/libsdpa_hip.so
+LIB_PATH = os.environ.get("SDPA_HIP_LIB") or os.path.join(PKG_DIR, "lib", "libsdpa_hip.so")
 HEADER_PATH = os.path.join(REPO_DIR, "include", "sdpa_hip.h")
 
 SDPA_F_NO_PIPELINE, SDPA_F_BF16, SDPA_F_PLAN_QROWS, SDPA_F_MERGE_ALLREDUCE = 1, 2, 4, 8
@@ -67,6 +69,7 @@ _PROTOS = {
     "sdpa_dev_bf16_ldn": (_c_long, [_c_long]),
     "sdpa_dev_bf16_kvpos": (_c_long, [_c_long]),
     "sdpa_dev_cvt_d2bf": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p]),
+    "sdpa_dev_cvt_d2bf_q": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p]),
     "sdpa_dev_cvt_d2bf_t": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_long, _c_void_p]),
     "sdpa_dev_kv_splits_bf16": (_c_int, [_c_int] * 4),
     "sdpa_dev_workspace_bytes_bf16": (_c_size_t, [_c_int] * 4),

@@ -168,6 +168,15 @@ int sdpa_dev_cvt_d2bf(const double *src, void *dst, long rows, int cols, int ld,
     return SDPA_OK;
 }
 
+int sdpa_dev_cvt_d2bf_q(const double *src, void *dst, long rows, int dk, int ld, void *stream) {
+    if (rows < 0 || dk <= 0 || dk > 512 || ld != sdpa::bf16_pad_dk(dk)) return SDPA_EINVAL;
+    if (rows == 0) return SDPA_OK;
+    if (!src || !dst) return SDPA_EINVAL;
+    SDPA_TRY(require_device());
+    HIP_TRY(sdpa::launch_cvt_d2bf_q(src, (unsigned short *)dst, rows, dk, ld, (hipStream_t)stream));
+    return SDPA_OK;
+}
+
 int sdpa_dev_cvt_d2bf_t(const double *src, void *dst, long rows, int cols, int cols_pad, long ldt,
                         void *stream) {
     if (rows < 0 || cols <= 0 || cols_pad < cols || ldt < rows) return SDPA_EINVAL;

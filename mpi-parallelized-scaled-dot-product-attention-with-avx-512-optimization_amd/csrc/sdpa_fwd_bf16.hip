@@ -141,7 +141,10 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
     const int kv_begin = split * kv_per_split;
     const int kv_end = min(a.n_local, kv_begin + kv_per_split);
     const int T = kv_end > kv_begin ? (kv_end - kv_begin + kKvTile - 1) / kKvTile : 0;
-    const float c = scale * 1.44269504088896340736f;
+    // the Q image is pre-multiplied by log2(e)/sqrtf(dk) by its converter (sdpa_dev_cvt_d2bf_q), so
+    // the MFMA chains deliver exp2-domain scores: the multiplier of the softmax argument is 1
+    (void)scale;
+    constexpr float c = 1.0f;
 
     // in the 512-register mode every MFMA result lands in the accumulator file, so one score
     // tile (16) sits there beside O: that many Q registers stay on the VGPR side
@@ -480,18 +483,30 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
 //     v_mfma_f32_32x32x16_bf16 with toggling operands at all (tools/probes/mfma_probe.hip:
 //     2.2 PFLOP/s with constant operands, 1.66-1.80 with random ones -- power, not issue).
 // ---------------------------------------------------------------------------
+// hipcc does not see an MFMA inside an asm statement, so its hazard recogniser inserts none of the
+// wait states an MFMA needs.  Two of them lead every statement: whatever VALU instruction the
+// register allocator puts right in front of it to set up an operand (a v_accvgpr_write of a Q
+// fragment, a v_mov of the accumulator) has then retired -- "VALU write VGPR/AGPR -> MFMA read"
+// needs 2 wait states on gfx90a+ (found the hard way: a build that copied Q fragments into AGPRs
+// in front of the tail steps' links read stale registers, nondeterministically).
+#ifndef SDPA_MFMA_LEAD
+#define SDPA_MFMA_LEAD "s_nop 1\n\t"
+#endif
+#ifndef SDPA_MFMA_ASM_TAIL      // tools/build_variant.sh: wait states BEHIND every asm MFMA (hazard hunting)
+#define SDPA_MFMA_ASM_TAIL ""
+#endif
 __device__ __forceinline__ void mfma_bf16_vgpr_first(f32x16 &d, const u32x4 &x, const u32x4 &y) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(x), "v"(y));
+    asm volatile(SDPA_MFMA_LEAD "v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" SDPA_MFMA_ASM_TAIL : "=&v"(d) : "v"(x), "v"(y));
 }
 __device__ __forceinline__ void mfma_bf16_vgpr(f32x16 &d, const u32x4 &x, const u32x4 &y) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(x), "v"(y));
+    asm volatile(SDPA_MFMA_LEAD "v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" SDPA_MFMA_ASM_TAIL : "+v"(d) : "v"(x), "v"(y));
 }
 // the same with the B operand read from the ACCUMULATOR file (wave-persistent Q fragments parked there)
 __device__ __forceinline__ void mfma_bf16_vgpr_first_qa(f32x16 &d, const u32x4 &x, const u32x4 &y) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(x), "a"(y));
+    asm volatile(SDPA_MFMA_LEAD "v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" SDPA_MFMA_ASM_TAIL : "=&v"(d) : "v"(x), "a"(y));
 }
 __device__ __forceinline__ void mfma_bf16_vgpr_qa(f32x16 &d, const u32x4 &x, const u32x4 &y) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(x), "a"(y));
+    asm volatile(SDPA_MFMA_LEAD "v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" SDPA_MFMA_ASM_TAIL : "+v"(d) : "v"(x), "a"(y));
 }
 // 16 wait states: covers an 8-pass MFMA's result latency before a VALU read (needs 11)
 __device__ __forceinline__ void mfma_result_fence(f32x16 &d) {
@@ -513,6 +528,11 @@ __device__ __forceinline__ float halfwave_max(float x) {
 #define SDPA_WIDE_VD 2
 #endif
 
+// experiment switch (tools/build_variant.sh): which of the in-loop O pins of the wide kernel are active
+#ifndef SDPA_WIDE_PINMASK
+#define SDPA_WIDE_PINMASK 0x0
+#endif
+#define PIN_O_IN_LOOP(n) do { if constexpr ((SDPA_WIDE_PINMASK >> (n)) & 1) pin_o(); } while (0)
 template <int DK, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
     Bf16Args a, int kv_per_split, int n_qblocks, int n_chunks, float scale) {
@@ -549,7 +569,10 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
     const int kv_begin = split * kv_per_split;
     const int kv_end = min(a.n_local, kv_begin + kv_per_split);
     const int T = kv_end > kv_begin ? (kv_end - kv_begin + kKvTile - 1) / kKvTile : 0;
-    const float c = scale * 1.44269504088896340736f;
+    // the Q image is pre-multiplied by log2(e)/sqrtf(dk) by its converter (sdpa_dev_cvt_d2bf_q), so
+    // the MFMA chains deliver exp2-domain scores: the multiplier of the softmax argument is 1
+    (void)scale;
+    constexpr float c = 1.0f;
 
     u32x4 qf[NKS];
 #pragma unroll
@@ -587,7 +610,7 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
                      "global_load_lds_dwordx4 %0, %2"
                      :
                      : "v"(lane_off), "s"(lds_byte), "s"(gbase)
-                     : "memory");
+                     : "memory" SDPA_M0_CLOBBER);
     };
     // same, lane offset = lane_part ^ swz computed in the wait slot
     auto dma_piece_xor = [&](const char *gbase, unsigned lane_part, unsigned swz, unsigned lds_byte) __attribute__((always_inline)) {
@@ -598,7 +621,7 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
                      "global_load_lds_dwordx4 %0, %4"
                      : "=&v"(off)
                      : "v"(lane_part), "s"(lds_byte), "s"(swz), "s"(gbase)
-                     : "memory");
+                     : "memory" SDPA_M0_CLOBBER);
     };
     // K tile: piece p (1 KiB of LDS) = RPP rows; lane -> row p*RPP + lane/KCH, LDS chunk position
     // lane%KCH, which holds global chunk (lane%KCH) ^ (row & SWZ).  Only the per-lane part of the
@@ -675,9 +698,6 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
                 if (crow16(r, 0) >= vh) sx[r] = -INFINITY;
         }
     };
-    constexpr int PPK = NKS >= 16 ? 1 : 16 / NKS;        // P values started per QK^T MFMA slot
-    constexpr int KPP = NKS >= 16 ? NKS / 16 : 1;        // QK^T MFMAs per P value
-
     // Pipeline of one step t (tile t is "current", t+1 "next"), one barrier per step:
     //   [A] S^T(t+1) = K(t+1).Q^T, a dependent chain of VGPR-form MFMAs, with nothing beside it
     //       but fragment reads and the DMA issue of K(t+3): VALU work next to a DEPENDENT MFMA
@@ -703,15 +723,16 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
     auto p_exp = [&](int r) __attribute__((always_inline)) {
         asm volatile("v_exp_f32 %0, %1" : "=v"(sx[r]) : "v"(fmaf(sx[r], c, -m_ref)));
     };
-    auto p_acc = [&](int r, unsigned (&pw)[8]) __attribute__((always_inline)) {
+    // (the packed pair goes straight into its word of the P operand: no staging array to keep alive)
+    auto p_acc = [&](int r, u32x4 (&pout)[2]) __attribute__((always_inline)) {
         asm volatile("v_add_f32 %0, %0, %1" : "+v"(l_run) : "v"(sx[r]));   // pinned: hipcc sinks the adds into one chain
-        if (r & 1) pw[r >> 1] = bpin_pack(sx[r - 1], sx[r]);
+        if (r & 1) pout[(r >> 1) / 4][(r >> 1) % 4] = bpin_pack(sx[r - 1], sx[r]);
     };
     auto step = [&](auto has_next, auto fenced, const u32x4 (&pb)[2], u32x4 (&pn)[2], int t) __attribute__((always_inline)) -> bool {
         constexpr bool HAS_NEXT = decltype(has_next)::value;
         constexpr bool FENCED = decltype(fenced)::value;
         const int vbuf = t & 1;
-        pin_o();
+        PIN_O_IN_LOOP(1);
         if constexpr (HAS_NEXT) {
             // [A]
             const int tk = min(t + 3, T - 1);              // past the end: a harmless reload into a free buffer
@@ -734,12 +755,11 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
         } else {
             stage_fence(std::integral_constant<int, 0>());
         }
-        pin_o();
+        PIN_O_IN_LOOP(2);
 
         // [B]
         if constexpr (HAS_NEXT) mask_ragged(sx, t + 1);
         float tmax = -INFINITY;
-        unsigned pw[8];
         constexpr int SLOTS = 2 * NT;                     // P.V MFMAs of this step
         constexpr int VD = SDPA_WIDE_VD;                   // V fragment prefetch depth
         // next step reads the next K buffer: advance the fragment addresses in place
@@ -767,22 +787,20 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
                     if (slot == 12) tmax = halfwave_max(fmaf(tmax, c, -m_ref));
                     if (slot >= 12 && slot < 28) {
                         p_exp(slot - 12);
-                        if (slot > 12) p_acc(slot - 13, pw);
+                        if (slot > 12) p_acc(slot - 13, pn);
                     }
-                    if (slot == 28) p_acc(15, pw);
+                    if (slot == 28) p_acc(15, pn);
                 } else if (slot == 4) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) pw[q] = __builtin_bit_cast(unsigned, sx[q]);
+                    for (int q = 0; q < 8; ++q) pn[q / 4][q % 4] = __builtin_bit_cast(unsigned, sx[q]);
                 }
                 if (slot >= 20 && slot < 20 + NKA) kaddr[slot - 20] += kstep;
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        pin_o();
+        PIN_O_IN_LOOP(3);
         bool pending = false;
         if constexpr (HAS_NEXT) {
-            pn[0] = u32x4{pw[0], pw[1], pw[2], pw[3]};
-            pn[1] = u32x4{pw[4], pw[5], pw[6], pw[7]};
             pending = __any(tmax > kDeferLog2);
             max_rel = fmaxf(max_rel, tmax);
             kr = kr_next;
@@ -816,17 +834,12 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
         m_ref = tmax * c;                               // finite: every tile has a valid key row
         // P(0)
         u32x4 pA[2], pB[2];
-        {
-            unsigned pw[8];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                p_exp(r);
-                if (r > 0) p_acc(r - 1, pw);
-            }
-            p_acc(15, pw);
-            pA[0] = u32x4{pw[0], pw[1], pw[2], pw[3]};
-            pA[1] = u32x4{pw[4], pw[5], pw[6], pw[7]};
+        for (int r = 0; r < 16; ++r) {
+            p_exp(r);
+            if (r > 0) p_acc(r - 1, pA);
         }
+        p_acc(15, pA);
         __syncthreads();                                // K(0) fully consumed before K(3) lands on it
 #pragma unroll
         for (int u = 0; u < NKA; ++u) kaddr[u] += (unsigned)(KTILE * 2);   // step 0 reads K(1) in buffer 1
@@ -900,10 +913,14 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
 //     [B] of step t-1 and [A] of step t, i.e. spread evenly under all 32 MFMAs of a step at d = 128;
 //     SETS = 1 (dk = dv = 256: O fills the accumulator file, Q takes half the VGPRs): one set, all
 //     32 slices under the 32 MFMAs of [B], the wide kernel's schedule;
+//   * the Q image carries log2e/sqrt(dk) (its converter multiplies before the ONE bf16 rounding), so
+//     the chains deliver exp2-domain scores and P = v_exp_f32(score): the reference exponent is
+//     ZERO, no fma, no per-tile state.  The raw
+//     row max is a running v_max3; after the last tile it is exchanged across the half-waves once,
+//     becomes lmax, and a workgroup with a row whose scores left +-100 (log2 domain) is flagged and
+//     redone by the general kernel right behind this one (in-loop rescale there);
 //   * K (three buffers) and Vt (two) by LDS-DMA, issued piece by piece between MFMAs, one barrier
-//     per step; the image layouts, swizzles and the fixed reference exponent + redo flag are the
-//     wide kernel's (a block whose row max outgrows 2^32 x the first tile's is redone by the general
-//     kernel right behind this one).
+//     per step; image layouts and swizzles are the wide kernel's.
 // ---------------------------------------------------------------------------
 #ifndef SDPA_DUO_KD
 #define SDPA_DUO_KD 3
@@ -912,6 +929,11 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
 #define SDPA_DUO_VD 2
 #endif
 constexpr int kDuoRows = 256;          // query rows per workgroup of the duo kernel
+// tools/build_variant.sh -DSDPA_DUO_ABL=bits: TIMING-ONLY ablations (results are wrong), never in
+// the shipped library: 1 = no softmax VALU, 2 = no LDS fragment reads, 4 = no DMA, 8 = no barrier
+#ifndef SDPA_DUO_ABL
+#define SDPA_DUO_ABL 0
+#endif
 
 template <int DK, int DV>
 struct DuoCfg {
@@ -919,14 +941,26 @@ struct DuoCfg {
     // to the last register makes hipcc shuttle tiles through VGPRs inside the loop)
     static constexpr bool QA = DK / 2 + DV <= 192;
     static constexpr int SETS = (QA || DK <= 128) ? 2 : 1;      // live score-tile sets
-    // LDS rings.  A tile is consumed in ~0.2-0.45 us at these head dims, far less than a trip to the
-    // L2 / Infinity Cache, so tiles are requested several steps ahead: K(t+NKB) is issued while
-    // K(t+1) is read, Vt(t+NVB-1) while Vt(t) is read.  Sized to ~64-128 KiB of the CU's 160 KiB.
-    static constexpr int NKB = DK + DV <= 256 ? 6 : (DK + DV <= 384 ? 5 : 4);
+    // LDS rings: K(t+NKB) is requested while K(t+1) is read, Vt(t+NVB-1) while Vt(t) is read.
+    // Deeper rings (4..6 K buffers) measured the same +-1 % at d = 64..256 (profiles/r02/
+    // bf16_duo_ring_depth_ab.log): the tiles come from L2 / Infinity Cache well inside one step.
+#ifdef SDPA_DUO_NKB          // tools/build_variant.sh: ring depth A/B
+    static constexpr int NKB = SDPA_DUO_NKB;
+#else
+    // (3, except at dk = dv = 256, where the VGPR file is exactly full and the 3- and 4-buffer
+    //  rotations tip hipcc into spilling a Q fragment inside the loop -- a scratch reload sits behind an
+    //  s_waitcnt vmcnt(0) that also waits for the DMA in flight: 1.92 ms against 1.75 ms with 5 buffers,
+    //  whose rotation happens to allocate cleanly; tests/test_kernel_isa.py guards the property)
+    static constexpr int NKB = DK + DV > 384 ? 5 : 3;
+#endif
     static constexpr int NVB = NKB - 1;
     static constexpr size_t lds_bytes = ((size_t)NKB * 32 * DK + (size_t)NVB * DV * 32) * 2;
 };
 
+#ifndef SDPA_DUO_PIN_IN_LOOP
+#define SDPA_DUO_PIN_IN_LOOP 1
+#endif
+#define DUO_PIN_O() do { if constexpr (SDPA_DUO_PIN_IN_LOOP) pin_o(); } while (0)
 template <int DK, int DV>
 __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
     Bf16Args a, int kv_per_split, int n_qblocks, int n_qblocks128, float scale) {
@@ -967,7 +1001,7 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
     const int kv_begin = split * kv_per_split;
     const int kv_end = min(a.n_local, kv_begin + kv_per_split);
     const int T = kv_end > kv_begin ? (kv_end - kv_begin + kKvTile - 1) / kKvTile : 0;
-    const float c = scale * 1.44269504088896340736f;
+    (void)scale;      // log2(e)/sqrtf(dk) lives in the Q image (sdpa_dev_cvt_d2bf_q): scores arrive in the exp2 domain
 
     u32x4 qf[2][NKS];
 #pragma unroll
@@ -1015,19 +1049,20 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
             for (int tt = 0; tt < NT; ++tt) asm volatile("" : "+a"(oacc[b][tt]));
     };
     pin_o();
-    constexpr float kDeferLog2 = 32.0f;                   // P <= 2^32; beyond that the block is redone
-    float m_ref[2] = {0.f, 0.f}, max_rel[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};   // exp2 domain
+    constexpr float kRangeLog2 = 100.0f;                  // |score * log2e / sqrt(dk)| <= 100, else the block is redone
+    float max_rel[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};  // exp2 domain
 
     // ---- K and Vt staging by LDS-DMA (the wide kernel's scheme)
     const unsigned lds_base = __builtin_amdgcn_readfirstlane(
         (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)smem16);
     auto dma_piece = [&](const char *gbase, unsigned lane_off, unsigned lds_byte) __attribute__((always_inline)) {
+        if constexpr (SDPA_DUO_ABL & 4) return;
         asm volatile("s_mov_b32 m0, %1\n\t"
                      "s_nop 0\n\t"
                      "global_load_lds_dwordx4 %0, %2"
                      :
                      : "v"(lane_off), "s"(lds_byte), "s"(gbase)
-                     : "memory");
+                     : "memory" SDPA_M0_CLOBBER);
     };
     const unsigned klane = (unsigned)((lane / KCH) * DK * 2 + (((lane % KCH) ^ ((lane / KCH) & SWZ)) << 4));
     auto dma_k_piece = [&](int tile, int buf, int j) __attribute__((always_inline)) {
@@ -1051,7 +1086,7 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
     auto stage_fence = [&](auto keep) __attribute__((always_inline)) {
         constexpr int KEEP = decltype(keep)::value;
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
-        __syncthreads();
+        if constexpr (!(SDPA_DUO_ABL & 8)) __syncthreads();
     };
 
     constexpr int NKA = NKS < 8 ? NKS : 8;
@@ -1059,6 +1094,7 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
 #pragma unroll
     for (int u = 0; u < NKA; ++u) kaddr[u] = (unsigned)(li * DK * 2 + (((2 * u + hi) ^ (li & SWZ)) << 4));
     auto kfrag = [&](int ks) __attribute__((always_inline)) -> u32x4 {
+        if constexpr (SDPA_DUO_ABL & 2) return u32x4{kaddr[ks % NKA], kaddr[0], kaddr[(ks + 1) % NKA], kaddr[ks % NKA]};
         return *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(Ks) +
                                                 kaddr[ks % NKA] + (ks / NKA) * 256);
     };
@@ -1068,6 +1104,7 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
     // like kaddr[], vaddr[] carries the byte offset of the Vt buffer being read and is advanced in place
     auto vfrag = [&](int slot) __attribute__((always_inline)) -> u32x4 {
         const int h = slot / NT, tt = slot % NT;
+        if constexpr (SDPA_DUO_ABL & 2) return u32x4{vaddr[h], kaddr[0], vaddr[0], (unsigned)tt};
         return *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(Vs) + vaddr[h] + tt * 2048);
     };
     auto mask_ragged = [&](f32x16 (&sx)[2], int tile) __attribute__((always_inline)) {
@@ -1083,32 +1120,37 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
     };
 
     // ---- softmax slices.  Slice i = element r = i % 16 of block b = i / 16 of score set sx:
-    //   e = exp2(s*c - m_ref)  (issued now);  l += e, bf16 pack  (of the PREVIOUS slice: the
+    //   e = exp2(s)  (issued now);  l += e, bf16 pack  (of the PREVIOUS slice: the
     //   transcendental's latency is never waited on);  row max of the raw scores every other slice.
     // State carried between slices of one tile: ecur/eprev (the two newest e values), pw (packed).
     struct SliceState {
         float e0, e1;              // e of element r-1 (pending add/pack) and r-2 (its pack partner)
-        float tmax[2];
     };
-    bool redo = false;
+    // running max of the RAW scores of the lane's query row, per block, over the whole K/V range:
+    // the reference exponent is fixed, so nothing in the loop depends on it -- the cross-half
+    // exchange, the redo test and max_rel are done once, after the last tile
+    float smax[2] = {-INFINITY, -INFINITY};
     auto slice = [&](int i, f32x16 (&sx)[2], SliceState &st, u32x4 (&pout)[2][2]) __attribute__((always_inline)) {
         const int b = i / 16, r = i % 16;
+        if constexpr (SDPA_DUO_ABL & 1) {
+            if (r == 15) {
+                pout[b][0] = u32x4{__float_as_uint(sx[b][0]), __float_as_uint(sx[b][1]), __float_as_uint(sx[b][2]), __float_as_uint(sx[b][3])};
+                pout[b][1] = u32x4{__float_as_uint(sx[b][4]), __float_as_uint(sx[b][5]), __float_as_uint(sx[b][6]), __float_as_uint(sx[b][7])};
+            }
+            return;
+        }
         float e;
-        asm volatile("v_exp_f32 %0, %1" : "=v"(e) : "v"(fmaf(sx[b][r], c, -m_ref[b])));
+        asm volatile("v_exp_f32 %0, %1" : "=v"(e) : "v"(sx[b][r]));
         if (r > 0) {                                   // finish element r-1 of this block
             asm volatile("v_add_f32 %0, %0, %1" : "+v"(l_run[b]) : "v"(st.e0));
             if (((r - 1) & 1) == 1) pout[b][((r - 1) >> 1) / 4][((r - 1) >> 1) % 4] = bpin_pack(st.e1, st.e0);
         }
-        if ((r & 1) == 0) st.tmax[b] = bpin_max3(st.tmax[b], sx[b][r], sx[b][r + 1]);
+        if ((r & 1) == 0) smax[b] = bpin_max3(smax[b], sx[b][r], sx[b][r + 1]);
         st.e1 = st.e0;
         st.e0 = e;
         if (r == 15) {                                 // close the block
             asm volatile("v_add_f32 %0, %0, %1" : "+v"(l_run[b]) : "v"(st.e0));
             pout[b][1][3] = bpin_pack(st.e1, st.e0);
-            const float tm = halfwave_max(fmaf(st.tmax[b], c, -m_ref[b]));
-            redo |= __any(tm > kDeferLog2);
-            max_rel[b] = fmaxf(max_rel[b], tm);
-            st.tmax[b] = -INFINITY;
         }
     };
     // slices [lo, hi) spread over the gaps of a phase with G MFMAs: after MFMA j run those whose
@@ -1128,8 +1170,10 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
     auto step = [&](auto has_next, f32x16 (&scur)[2], f32x16 (&snxt)[2], SliceState &stc, SliceState &stn,
                     u32x4 (&pcur)[2][2], u32x4 (&pnxt)[2][2], int t) __attribute__((always_inline)) {
         constexpr bool HAS_NEXT = decltype(has_next)::value;
-        pin_o();
+        DUO_PIN_O();
+#ifdef SDPA_DUO_PINQ
         pin_q();
+#endif
         // [A]
         if constexpr (HAS_NEXT) {
             const int tk = min(t + NKB, T - 1);            // past the end: a harmless reload into a free buffer
@@ -1156,13 +1200,17 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
             mfma_result_fence(snxt[0]);                            // the chains' last links have retired
             asm volatile("" : "+v"(snxt[1]));
             // everything older than Vt(t+1)'s request has landed: K(t+2) and Vt(t) with it
+#ifdef SDPA_DUO_WAIT_ALL     // tools/build_variant.sh: debugging aid, drains every request at every step
+            stage_fence(std::integral_constant<int, 0>());
+#else
             stage_fence(std::integral_constant<int, (NVB - 1) * KPW + (NVB - 2) * VPW>());
+#endif
         } else {
 #pragma unroll
             for (int i = NB_SL; i < NSL; ++i) slice(i, scur, stc, pcur);
             stage_fence(std::integral_constant<int, 0>());
         }
-        pin_o();
+        DUO_PIN_O();
 
         // [B]
         if constexpr (HAS_NEXT) mask_ragged(snxt, t + 1);
@@ -1199,7 +1247,7 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        pin_o();
+        DUO_PIN_O();
         if constexpr (HAS_NEXT) {
             vaddr[0] += vstep;                              // all of this step's Vt reads are issued
             vaddr[1] += vstep;
@@ -1225,7 +1273,6 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
         f32x16 sA[2], sB[2];
         u32x4 pA[2][2], pB[2][2];
         SliceState stA, stB;
-        stA.tmax[0] = stA.tmax[1] = stB.tmax[0] = stB.tmax[1] = -INFINITY;
         stA.e0 = stA.e1 = stB.e0 = stB.e1 = 0.f;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
@@ -1236,14 +1283,6 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
         mfma_result_fence(sA[0]);
         mfma_result_fence(sA[1]);
         mask_ragged(sA, 0);
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            float tmax = sA[b][0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sA[b][r]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-            m_ref[b] = tmax * c;                        // finite: every tile has a valid key row
-        }
 #pragma unroll
         for (int i = 0; i < NB_SL; ++i) slice(i, sA, stA, pA);     // the part of P(0) a step's [B] would have done
         __syncthreads();                                // K(0) fully consumed before K(NKB) lands on it
@@ -1273,6 +1312,15 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
             } else {
                 step(std::false_type(), sA, sA, stA, stA, pA, pB, t);
             }
+        }
+        bool redo = false;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            // reference exponent 0: P = 2^score is exact to fp32 rounding while the row's scores stay
+            // inside +-kRangeLog2 (|q.k/sqrt(dk)| < 69); a row that leaves that range on either side --
+            // overflow, or every P flushed to zero -- sends its workgroup to the redo pass
+            max_rel[b] = halfwave_max(smax[b]);
+            redo |= __any(!(fabsf(max_rel[b]) <= kRangeLog2));
         }
         if (redo && lane == 0) {                        // flags are per 128-row block of the redo kernel
             const int q128 = 2 * qblock;
@@ -1306,7 +1354,7 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
                     if (col < a.dv) orow[col] = oacc[b][tt][r] * fold;
                 }
             if (hi == 0) {
-                omax[qrow] = T > 0 ? (m_ref[b] + max_rel[b]) * 0.69314718055994530942f : -INFINITY;
+                omax[qrow] = T > 0 ? max_rel[b] * 0.69314718055994530942f : -INFINITY;
                 osum[qrow] = l_tot;
             }
         }
@@ -1317,13 +1365,13 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
 // converts: fp64 -> bf16 (RNE), row-major with zero-padded columns, and the transposed V image
 // ---------------------------------------------------------------------------
 __global__ void cvt_d2bf_kernel(const double *__restrict__ src, unsigned short *__restrict__ dst,
-                                long rows, int cols, int ld) {
+                                long rows, int cols, int ld, double mult) {
     const long total = rows * ld;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long)gridDim.x * blockDim.x) {
         const long r = idx / ld;
         const int cidx = (int)(idx - r * ld);
-        dst[idx] = cidx < cols ? (unsigned short)f32_to_bf16_rne(__double2float_rn(src[r * cols + cidx])) : 0;
+        dst[idx] = cidx < cols ? (unsigned short)f32_to_bf16_rne(__double2float_rn(src[r * cols + cidx] * mult)) : 0;
     }
 }
 
@@ -1430,7 +1478,7 @@ static hipError_t launch_bf16_pipe(const Bf16Args &a, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_done[dev] = true;
     }
-    const float scale = 1.0f / sqrtf((float)a.dk);   // attention-mpi.c:208
+    const float scale = 1.0f;   // attention-mpi.c:208's 1/sqrt(dk) (and log2 e) live in the Q image
     hipLaunchKernelGGL((fused_bf16_pipe_kernel<DK, DVC, ABL>), dim3(nqb * chunks * a.kv_splits), dim3(256), lds,
                        s, a, kv_per_split, nqb, chunks, scale);
     return hipGetLastError();
@@ -1453,7 +1501,7 @@ static hipError_t launch_bf16_wide(const Bf16Args &a, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_done[dev] = true;
     }
-    const float scale = 1.0f / sqrtf((float)a.dk);   // attention-mpi.c:208
+    const float scale = 1.0f;   // attention-mpi.c:208's 1/sqrt(dk) (and log2 e) live in the Q image
     hipLaunchKernelGGL((fused_bf16_wide_kernel<DK, ABL>), dim3(nqb * chunks * a.kv_splits), dim3(256), lds, s,
                        a, kv_per_split, nqb, chunks, scale);
     return hipGetLastError();
@@ -1466,7 +1514,7 @@ static hipError_t launch_bf16_duo(const Bf16Args &a, hipStream_t s) {
     const int ntiles = (a.n_local + kKvTile - 1) / kKvTile;
     const int tiles_per_split = (ntiles + a.kv_splits - 1) / a.kv_splits;
     const int kv_per_split = tiles_per_split > 0 ? tiles_per_split * kKvTile : kKvTile;
-    const size_t lds = ((size_t)3 * kKvTile * DK + (size_t)2 * DV * kKvTile) * sizeof(unsigned short);
+    const size_t lds = DuoCfg<DK, DV>::lds_bytes;
     static bool attr_done[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
@@ -1476,7 +1524,7 @@ static hipError_t launch_bf16_duo(const Bf16Args &a, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_done[dev] = true;
     }
-    const float scale = 1.0f / sqrtf((float)a.dk);   // attention-mpi.c:208
+    const float scale = 1.0f;   // attention-mpi.c:208's 1/sqrt(dk) (and log2 e) live in the Q image
     hipLaunchKernelGGL((fused_bf16_duo_kernel<DK, DV>), dim3(nqb * a.kv_splits), dim3(256), lds, s, a,
                        kv_per_split, nqb, nqb128, scale);
     return hipGetLastError();
@@ -1573,7 +1621,18 @@ hipError_t launch_cvt_d2bf(const double *src, unsigned short *dst, long rows, in
     if (rows <= 0) return hipSuccess;
     long g = (rows * ld + 255) / 256;
     if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(cvt_d2bf_kernel, dim3((unsigned)g), dim3(256), 0, s, src, dst, rows, cols, ld);
+    hipLaunchKernelGGL(cvt_d2bf_kernel, dim3((unsigned)g), dim3(256), 0, s, src, dst, rows, cols, ld, 1.0);
+    return hipGetLastError();
+}
+
+// the Q image of the bf16 kernels: bf16(Q * log2(e)/sqrtf(dk)), ONE rounding from fp64 -- the softmax
+// scale (attention-mpi.c:208) and the change of base for v_exp_f32 folded into the operand
+hipError_t launch_cvt_d2bf_q(const double *src, unsigned short *dst, long rows, int dk, int ld, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    long g = (rows * ld + 255) / 256;
+    if (g > 2048) g = 2048;
+    const float c = 1.44269504088896340736f * (1.0f / sqrtf((float)dk));
+    hipLaunchKernelGGL(cvt_d2bf_kernel, dim3((unsigned)g), dim3(256), 0, s, src, dst, rows, dk, ld, (double)c);
     return hipGetLastError();
 }
 

@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, 
                      "global_load_lds_dwordx4 %0, %2"
                      :
                      : "v"(lane_off), "s"(lds_byte), "s"(gbase)
-                     : "memory");
+                     : "memory" SDPA_M0_CLOBBER);
     };
     auto stage_fence = [&]() __attribute__((always_inline)) {
         if constexpr (ABL & 1) return;

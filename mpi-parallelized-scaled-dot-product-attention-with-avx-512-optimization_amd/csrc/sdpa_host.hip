@@ -518,7 +518,7 @@ int stage_q_rows(const Plan &pl, Rank &rk, const double *Q, int s, size_t i0, in
     HIP_TRY(hipEventRecord(copied, rk.s_cp));
     HIP_TRY(hipStreamWaitEvent(rk.s_in, copied, 0));
     if (pl.bf16)
-        HIP_TRY(sdpa::launch_cvt_d2bf(q64, (unsigned short *)rk.qf[s].p + (size_t)j0 * pl.ldq, jr, pl.dk, pl.ldq, rk.s_in));
+        HIP_TRY(sdpa::launch_cvt_d2bf_q(q64, (unsigned short *)rk.qf[s].p + (size_t)j0 * pl.ldq, jr, pl.dk, pl.ldq, rk.s_in));
     else
         HIP_TRY(sdpa::launch_cvt_d2f(q64, (float *)rk.qf[s].p + (size_t)j0 * pl.ldq, jr, pl.dk, pl.ldq, rk.s_in));
     HIP_TRY(hipEventRecord(converted, rk.s_in));

@@ -4,6 +4,14 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
+// The LDS-DMA asm statements write M0 (the DMA's LDS destination) without saving it.  Declaring
+// the clobber tells hipcc so: it cannot then keep a value of its own in M0 across such a statement
+// (LDS-direct, movrel, sendmsg users would otherwise silently read the DMA's address).
+// -DSDPA_M0_CLOBBER= (empty) builds the undeclared form for A/B timing (tools/build_variant.sh).
+#ifndef SDPA_M0_CLOBBER
+#define SDPA_M0_CLOBBER , "m0"
+#endif
+
 namespace sdpa {
 
 constexpr int kQRowsPerBlock = 128;   // 4 waves x 32 query rows
@@ -71,6 +79,7 @@ size_t bf16_workspace_bytes(int m, int n_local, int dk, int dv);
 void bf16_carve_workspace(Bf16Args &a, void *ws, int ws_ld);   // needs a.m, a.dv, a.kv_splits
 hipError_t launch_shard_partial_bf16(const Bf16Args &a, hipStream_t s);
 hipError_t launch_cvt_d2bf(const double *src, unsigned short *dst, long rows, int cols, int ld, hipStream_t s);
+hipError_t launch_cvt_d2bf_q(const double *src, unsigned short *dst, long rows, int dk, int ld, hipStream_t s);
 hipError_t launch_cvt_d2bf_t(const double *src, unsigned short *dst, long rows, int cols, int cols_pad,
                              long ldt, hipStream_t s);
 // the same for `rows` keys that land at dst (a column offset into a larger Vt image of row stride

@@ -171,6 +171,20 @@ class HipBackend:
                       "sdpa_dev_cvt_d2bf")
         return out
 
+    def cvt_d2bf_q(self, q64):
+        """fp64 Q [rows, dk] -> the bf16 Q image [rows, ld]: bf16(Q * log2(e)/sqrtf(dk)), one rounding
+        (the softmax scale and the exp2 change of base live in the operand)."""
+        rows, dk = q64.shape
+        ld = self.lib.sdpa_dev_bf16_ld(dk)
+        check(min(ld, 0), "sdpa_dev_bf16_ld")
+        out = self.empty((rows, ld), torch.bfloat16)
+        if rows:
+            assert q64.is_contiguous() and q64.dtype == torch.float64
+            with torch.cuda.device(self.device):
+                check(self.lib.sdpa_dev_cvt_d2bf_q(q64.data_ptr(), out.data_ptr(), rows, dk, ld, self._stream()),
+                      "sdpa_dev_cvt_d2bf_q")
+        return out
+
     def cvt_d2bf_t(self, v64):
         """fp64 V[n, dv] -> the transposed bf16 image Vt[dv_pad, n_pad] the bf16 kernel reads."""
         n, dv = v64.shape
@@ -302,7 +316,7 @@ class ShardedAttention:
 
     def convert_q(self, Q64):
         """Q batch fp64 -> operand image (attention-mpi.c:303,:325)."""
-        return self.be.cvt_d2bf(Q64) if self.precision == "bf16" else self.be.cvt_d2f(Q64)
+        return self.be.cvt_d2bf_q(Q64) if self.precision == "bf16" else self.be.cvt_d2f(Q64)
 
     def load_kv_shard(self, Kf_local, Vf_local, n, dk, dv):
         """The shard is already on this rank's device as padded fp32 (bench: resident inputs)."""

@@ -58,11 +58,11 @@ def test_bf16_image_geometry_helpers(pkg):
     assert lib.sdpa_dev_bf16_kvpos(-1) < 0
     # split buffers ([splits x m x (ld(dv) + 2)] floats) when the shard is split in-GPU, and one
     # redo flag per (split, 128-row q block) for the kernels with a fixed reference exponent
-    # (dv > 256: wide kernel; dk, dv <= 128: duo kernel)
+    # (dv > 256: wide kernel; dk, dv <= 256: duo kernel)
     s1 = lib.sdpa_dev_kv_splits_bf16(32768, 65536, 128, 128)
     assert lib.sdpa_dev_workspace_bytes_bf16(32768, 65536, 128, 128) == (s1 * 32768 * (128 + 2) * 4 if s1 > 1 else 0) + 256 * s1 * 4
-    s0 = lib.sdpa_dev_kv_splits_bf16(32768, 65536, 256, 256)
-    assert lib.sdpa_dev_workspace_bytes_bf16(32768, 65536, 256, 256) == (s0 * 32768 * (256 + 2) * 4 if s0 > 1 else 0)
+    s0 = lib.sdpa_dev_kv_splits_bf16(32768, 65536, 512, 256)      # general kernel: no flags
+    assert lib.sdpa_dev_workspace_bytes_bf16(32768, 65536, 512, 256) == (s0 * 32768 * (256 + 2) * 4 if s0 > 1 else 0)
     assert lib.sdpa_dev_kv_splits_bf16(70000, 4096, 64, 64) == 1 and lib.sdpa_dev_workspace_bytes_bf16(70000, 4096, 64, 64) == 547 * 4
     splits = lib.sdpa_dev_kv_splits_bf16(32768, 65536, 512, 512)
     assert splits == 1 and lib.sdpa_dev_workspace_bytes_bf16(32768, 65536, 512, 512) == 256 * 4

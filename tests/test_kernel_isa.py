@@ -1,0 +1,94 @@
+"""CPU: a build-time look at the ISA hipcc emits for the hand-scheduled kernels.
+
+Their speed rests on properties the source cannot express and a compiler upgrade (or an innocent
+edit) can silently break: NO scratch traffic inside the steady-state loop (a spilled fragment is
+reloaded behind an `s_waitcnt vmcnt(0)` that also waits for every LDS-DMA piece in flight), the
+accumulators staying in the accumulator file (no per-step v_accvgpr shuttles), and the LDS
+fragment-read count per MFMA that each design claims.  The kernel source is compiled to assembly
+(device only, seconds) and the largest loop of each kernel is inspected."""
+import os
+import re
+import subprocess
+from collections import Counter
+
+import pytest
+
+from conftest import PKG, ROOT
+
+HIPCC = "/opt/rocm/bin/hipcc"
+CSRC = os.path.join(ROOT, PKG, "csrc")
+
+
+def device_asm(tmp_path_factory, src):
+    out = str(tmp_path_factory.mktemp("isa") / (src + ".s"))
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fvisibility=hidden",
+                           "-Wno-unused-result", "-Wno-inline-asm", "--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", out])
+    return open(out).read().split("\n")
+
+
+def kernel_lines(lines, name_re):
+    start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN4sdpa\S*" + name_re + r"\S*:", l))
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    return lines[start:end]
+
+
+def main_loop_mix(k):
+    """instruction histogram of the backward-branch loop of a kernel that holds the most MFMAs"""
+    labels = {m.group(1): i for i, l in enumerate(k) if (m := re.match(r"^(\.LBB\d+_\d+):", l))}
+    def mix(lo, hi):
+        c = Counter()
+        for l in k[lo:hi + 1]:
+            m = re.match(r"^\t([a-z_0-9]+)", l)
+            if m:
+                c[m.group(1)] += 1
+        return c
+
+    best = None
+    for i, l in enumerate(k):
+        m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            c = mix(labels[m.group(1)], i)
+            n = sum(v for name, v in c.items() if name.startswith("v_mfma"))
+            # innermost loop with the most MFMAs: ties go to the shorter span
+            if best is None or n > best[0] or (n == best[0] and i - labels[m.group(1)] < best[1]):
+                best = (n, i - labels[m.group(1)], c)
+    assert best is not None, "no loop found"
+    return best[2]
+
+
+@pytest.fixture(scope="module")
+def bf16_asm(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc here")
+    return device_asm(tmp_path_factory, "sdpa_fwd_bf16.hip")
+
+
+@pytest.mark.parametrize("dk,dv", [(64, 64), (64, 128), (64, 256), (128, 64), (128, 128), (128, 256),
+                                   (256, 64), (256, 128), (256, 256)])
+def test_duo_kernel_loop_is_spill_free_and_reads_one_fragment_per_two_mfmas(dk, dv, bf16_asm):
+    c = main_loop_mix(kernel_lines(bf16_asm, "fused_bf16_duo_kernelILi%dELi%dE" % (dk, dv)))
+    mfma = c["v_mfma_f32_32x32x16_bf16"]
+    assert mfma == 2 * (2 * dk // 16 + 4 * dv // 32), c          # the loop body is two steps
+    assert sum(v for k, v in c.items() if k.startswith("scratch_")) == 0, "scratch traffic inside the loop: %s" % c
+    assert c["ds_read_b128"] * 2 == mfma, "every LDS fragment must feed two MFMAs: %s" % c
+    # at most one O tile (16 registers) crosses the back-edge through VGPRs (dv = 256: the file is full)
+    assert c["v_accvgpr_read_b32"] <= 16 and c["v_accvgpr_write_b32"] <= 16, c
+    assert c["v_exp_f32"] == 64 and c["global_load_lds_dwordx4"] == 2 * (dk // 64 + dv // 64), c
+
+
+def test_wide_kernel_loop_is_spill_free(bf16_asm):
+    c = main_loop_mix(kernel_lines(bf16_asm, "fused_bf16_wide_kernelILi512ELi0E"))
+    assert c["v_mfma_f32_32x32x16_bf16"] == 128 and c["ds_read_b128"] == 128, c
+    assert sum(v for k, v in c.items() if k.startswith("scratch_")) == 0, c
+    # one O tile crosses the back-edge through VGPRs (the accumulator file is completely full)
+    assert c["v_accvgpr_read_b32"] <= 16 and c["v_accvgpr_write_b32"] <= 16, c
+
+
+def test_f32_pipelined_kernel_loop_is_spill_free(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc here")
+    asm = device_asm(tmp_path_factory, "sdpa_fwd_f32.hip")
+    c = main_loop_mix(kernel_lines(asm, "fused_pipelined_kernelILi128ELi128ELi0E"))
+    assert c["v_mfma_f32_32x32x2_f32"] == 256, c                  # two tiles x (64 + 64) MFMAs per wave
+    assert sum(v for k, v in c.items() if k.startswith("scratch_")) == 0, c
+    assert c["v_exp_f32"] == 32 and c["global_load_lds_dwordx4"] == 32, c          # 2 tiles x (8 K + 8 V) 1-KiB pieces
