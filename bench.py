@@ -51,6 +51,8 @@ WORKLOADS = {
     "config1": dict(m=512, n=512, d=64),           # configs[0]
     "config4": dict(m=131072, n=65536, d=128),     # configs[3], many Q batches
     "config5": dict(m=32768, n=65536, d=512),      # configs[4], bf16 MFMA path (use --precision bf16)
+    "d256": dict(m=32768, n=65536, d=256),         # head-dim series of the bf16 path (--precision bf16)
+    "d64": dict(m=32768, n=65536, d=64),
 }
 F32_MFMA_PEAK_TFLOPS = 157.3                       # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 BF16_MFMA_PEAK_TFLOPS = 2500.0                     # dense bf16 MFMA peak (no 2:1 sparsity)
@@ -137,10 +139,10 @@ def cpu_baseline(m, n, d, budget_rows=8192):
 
 
 def kernel_source_stamp():
-    """identifies the build a profile was taken from: sha256 over the kernel sources (git is not
-    available on the GPU box)"""
+    """identifies the build a profile of the fp32 fused kernel was taken from: sha256 over the
+    sources that define it (git is not available on the GPU box)"""
     h = hashlib.sha256()
-    for f in ("sdpa_fwd_f32.hip", "sdpa_fwd_bf16.hip", "sdpa_internal.h"):
+    for f in ("sdpa_fwd_f32.hip", "sdpa_internal.h"):
         h.update(open(os.path.join(ROOT, PKG, "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

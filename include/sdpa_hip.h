@@ -123,7 +123,10 @@ SDPA_API const char *sdpa_version(void);
  * row maximum rises by more than 2^24 in the fp32 kernels, 2^32 in the bf16
  * wide kernel), which spends that much of fp32's exponent headroom: the
  * un-normalised contrib of a row overflows for |V|*n above ~2^104 (fp32) /
- * ~2^96 (bf16 wide), where the reference's eager rescale would not.          */
+ * ~2^96 (bf16 wide), where the reference's eager rescale would not.  The bf16
+ * duo kernel (dk, dv <= 256) keeps NO reference exponent while every score of
+ * a row stays within |q.k/sqrt(dk)| <= 55 (rows outside are recomputed by the
+ * rescaling kernel, no loss): there contrib overflows for |V|*n above ~2^47.  */
 SDPA_API int sdpa_attention_f64(const double *Q, const double *K, const double *V,
                                 double *result, int m, int n, int dk, int dv,
                                 int flags);

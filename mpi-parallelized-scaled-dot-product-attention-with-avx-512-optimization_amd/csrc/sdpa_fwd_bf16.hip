@@ -917,7 +917,7 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
 //     the chains deliver exp2-domain scores and P = v_exp_f32(score): the reference exponent is
 //     ZERO, no fma, no per-tile state.  The raw
 //     row max is a running v_max3; after the last tile it is exchanged across the half-waves once,
-//     becomes lmax, and a workgroup with a row whose scores left +-100 (log2 domain) is flagged and
+//     becomes lmax, and a workgroup with a row whose scores left +-80 (log2 domain) is flagged and
 //     redone by the general kernel right behind this one (in-loop rescale there);
 //   * K (three buffers) and Vt (two) by LDS-DMA, issued piece by piece between MFMAs, one barrier
 //     per step; image layouts and swizzles are the wide kernel's.
@@ -1049,7 +1049,9 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
             for (int tt = 0; tt < NT; ++tt) asm volatile("" : "+a"(oacc[b][tt]));
     };
     pin_o();
-    constexpr float kRangeLog2 = 100.0f;                  // |score * log2e / sqrt(dk)| <= 100, else the block is redone
+    // |score * log2e / sqrt(dk)| <= 80 (|q.k/sqrt(dk)| <= 55), else the block is redone: P <= 2^80 leaves
+    // 2^47 of fp32 headroom for sum_j P_j |V_j|
+    constexpr float kRangeLog2 = 80.0f;
     float max_rel[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};  // exp2 domain
 
     // ---- K and Vt staging by LDS-DMA (the wide kernel's scheme)
@@ -1317,7 +1319,7 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             // reference exponent 0: P = 2^score is exact to fp32 rounding while the row's scores stay
-            // inside +-kRangeLog2 (|q.k/sqrt(dk)| < 69); a row that leaves that range on either side --
+            // inside +-kRangeLog2 (|q.k/sqrt(dk)| <= 55); a row that leaves that range on either side --
             // overflow, or every P flushed to zero -- sends its workgroup to the redo pass
             max_rel[b] = halfwave_max(smax[b]);
             redo |= __any(!(fabsf(max_rel[b]) <= kRangeLog2));

@@ -61,7 +61,7 @@ if f is not None and w is not None:
     import hashlib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    for fn in ("sdpa_fwd_f32.hip", "sdpa_fwd_bf16.hip", "sdpa_internal.h"):
+    for fn in ("sdpa_fwd_f32.hip", "sdpa_internal.h"):       # the fp32 fused kernel's sources (bench.py checks this)
         h.update(open(os.path.join(root, "mpi-parallelized-scaled-dot-product-attention-with-avx-512-optimization_amd", "csrc", fn), "rb").read())
     t = {"per_launch_bytes": f * 1024 * 2 + w * 1024, "fetch_size_kib": f, "write_size_kib": w,
          "kernel_src_sha16": h.hexdigest()[:16],      # bench.py quotes the figure only for this build
