@@ -7,7 +7,8 @@ Metric: Q-rows/sec (plus achieved TFLOP/s) of the K/V-sharded fused attention ho
 m=32768, n=65536, dk=dv=128 ("headline"), fp32 compute / fp64 in-out.  One "step" is one full
 pass of the hot path over the synthetic problem with the fp64 inputs already resident in HBM:
     K/V shard fp64->fp32 convert, then per Q batch: Q convert, fused online-softmax kernel,
-    [N>1: all-reduce(MAX), rescale, all-reduce(SUM), normalise, reduce(SUM) over RCCL],
+    [N>1: all-gather of the (lmax,lsum) pairs + one merge pass (or --merge allreduce: the reference's
+     all-reduce(MAX), rescale, all-reduce(SUM), normalise), then reduce(SUM) over RCCL],
     fp32->fp64 result on the root.
 N>1 is launched by torch.distributed.run, one rank per GPU; K/V rows are sharded with
 owner_count/owner_disp, Q is replicated (resident input), total work is fixed ("strong").
@@ -234,9 +235,9 @@ def main():
     ap.add_argument("--plan", default="kv", choices=["kv", "qrows"],
                     help="multi-GPU plan: kv = K/V rows sharded + the reference's merge collectives "
                          "(the headline); qrows = query rows sharded, K/V replicated, no merge collective")
-    ap.add_argument("--merge", default="allreduce", choices=["allreduce", "gather"],
-                    help="shard merge: the reference's all-reduce(MAX)+all-reduce(SUM) (default), or one "
-                         "all-gather of the (lmax,lsum) pairs -- same algebra, one collective fewer")
+    ap.add_argument("--merge", default="gather", choices=["allreduce", "gather"],
+                    help="shard merge: one all-gather of the (lmax,lsum) pairs (default, as the C host: same "
+                         "algebra, one collective fewer), or the reference's literal all-reduce(MAX)+all-reduce(SUM)")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="single-GPU dry run of ONE rank's share of an N-rank K/V-sharded job "
                          "(K/V rows = n/N); a tuning aid, the printed line is not a benchmark result")

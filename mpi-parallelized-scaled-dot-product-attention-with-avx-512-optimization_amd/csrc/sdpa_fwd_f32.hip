@@ -738,7 +738,7 @@ __global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, 
 template <int DKS, int DVS>
 __global__ __launch_bounds__(256, 1) void fused_dksplit_kernel(
     PartialArgs a, int kv_per_split, int n_qblocks, int n_chunks, float scale) {
-    // DKS: dk slice of one wave (dk is treated as padded to 4*DKS = 256 or 512)
+    // DKS: dk slice of one wave (dk is treated as padded to 4*DKS = 256, 384 or 512)
     constexpr int NU = DKS / 8;         // 16-byte K reads (4 MFMA k-steps each) per tile per lane
     constexpr int NT = DVS / 32;        // 32-row O^T blocks per wave; also floats per V read
     constexpr int XLD = 20;             // floats per lane in the exchange buffer: 16 + pad, b128 conflict-free
@@ -1212,11 +1212,18 @@ hipError_t launch_shard_partial(const PartialArgs &a_in, hipStream_t s) {
     a.tune = 0;
 #endif
     if (uses_dksplit(a.dk, a.dv) && !(a.tune & 8)) {   // $SDPA_TUNE&8: the kernels it replaced
-        if (a.dk > kMaxMfmaDk) {
+        if (a.dk > 384) {
             switch (dksplit_slice(a.dv)) {
                 case 32: return launch_dksplit<128, 32>(a, s);
                 case 64: return launch_dksplit<128, 64>(a, s);
                 default: return launch_dksplit<128, 128>(a, s);
+            }
+        }
+        if (a.dk > kMaxMfmaDk) {       // 256 < dk <= 384: 96-wide dk slices, no score MFMAs on padding
+            switch (dksplit_slice(a.dv)) {
+                case 32: return launch_dksplit<96, 32>(a, s);
+                case 64: return launch_dksplit<96, 64>(a, s);
+                default: return launch_dksplit<96, 128>(a, s);
             }
         }
         switch (dksplit_slice(a.dv)) {

@@ -61,6 +61,9 @@ def engine(pkg, monkeypatch):
     (513, 7000, 64, 64, "D4", None),        # late spike key sits in the last chunk
     (300, 5000, 72, 40, "D3", None),        # register-staged kernel (padded dims), peaky
     (200, 6000, 300, 96, "D2", None),       # dk-split kernel
+    (140, 5000, 100, 200, "D2", None),      # fp32 dv > 128: two dv chunks per launch, every chunk into the slots
+    (20, 3000, 600, 48, "D2", None),        # dk > 512: the VALU any-shape kernel (one split per launch)
+    (300, 5000, 512, 200, "D1", "bf16"),    # bf16 general kernel (dk = 512, dv <= 256): no redo flags
     (700, 9000, 128, 128, "D2", "bf16"),    # bf16 pipe kernel: chunks of the transposed Vt image
     (260, 5000, 512, 512, "D1", "bf16"),    # bf16 wide kernel (redo flags live beside the slots)
 ])
