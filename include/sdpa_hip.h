@@ -119,14 +119,14 @@ SDPA_API const char *sdpa_version(void);
  * owner_count/owner_disp (:19-27) and merged with the algebra of :340-380
  * (flags choose the collective schedule).  The first Q batch streams the K/V
  * shard host->device in chunks and starts computing on chunk 0.
- * Numerical range: the kernels rescale their accumulators lazily (only when a
- * row maximum rises by more than 2^24 in the fp32 kernels, 2^32 in the bf16
- * wide kernel), which spends that much of fp32's exponent headroom: the
- * un-normalised contrib of a row overflows for |V|*n above ~2^104 (fp32) /
- * ~2^96 (bf16 wide), where the reference's eager rescale would not.  The bf16
- * duo kernel (dk, dv <= 256) keeps NO reference exponent while every score of
- * a row stays within |q.k/sqrt(dk)| <= 55 (rows outside are recomputed by the
- * rescaling kernel, no loss): there contrib overflows for |V|*n above ~2^47.  */
+ * Numerical range: the fp32 kernels rescale their accumulators lazily (only
+ * when a row maximum rises by more than 2^24), which spends that much of
+ * fp32's exponent headroom: the un-normalised contrib of a row overflows for
+ * |V|*n above ~2^104, where the reference's eager rescale would not.  The
+ * bf16 duo and wide kernels keep NO reference exponent (P = 2^score) while
+ * the row's sum of 2^score stays inside [2^-80, 2^80] -- roughly every score
+ * within |q.k/sqrt(dk)| <= 55; rows outside are recomputed by the rescaling
+ * kernel, no loss: there contrib overflows for |V| above ~2^47.            */
 SDPA_API int sdpa_attention_f64(const double *Q, const double *K, const double *V,
                                 double *result, int m, int n, int dk, int dv,
                                 int flags);
@@ -234,8 +234,12 @@ SDPA_API int sdpa_dev_finish_f64(const float *contrib, int ldo, const float *lsu
  *                                  dvp = sdpa_dev_bf16_dvp(dv), ldvt = sdpa_dev_bf16_ldn(n_local)
  *                                  (n_local padded to 32), pads zero.
  * sdpa_dev_cvt_d2bf_q (Q), sdpa_dev_cvt_d2bf (K) and sdpa_dev_cvt_d2bf_t (V) write these images
- * from dense fp64.  dk <= 512, dv <= 1024.  lmax/lsum/contrib are those of the scores so computed
- * (lmax in natural-log units, as in the fp32 variant).                              */
+ * from dense fp64.  dk <= 512, dv <= 1024.  contrib/lsum are those of the scores so computed,
+ * relative to lmax (natural-log units) as in the fp32 variant -- but lmax is here a REFERENCE
+ * EXPONENT, not necessarily the row max: the fixed-reference kernels (dk, dv <= 256, and dv > 256)
+ * return the power of two that puts lsum in [1, 2), so lmax + ln(lsum) is the row's log-sum-exp
+ * and max_j s_ij <= lmax + ln 2 <= max_j s_ij + ln(2 n_local).  Every merge of this library (and
+ * attention-mpi.c:340-380) is invariant under that choice.                                   */
 SDPA_API int  sdpa_dev_bf16_ld(int dk);
 SDPA_API int  sdpa_dev_bf16_dvp(int dv);
 SDPA_API long sdpa_dev_bf16_ldn(long n_local);

@@ -37,6 +37,7 @@ namespace sdpa {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -572,7 +573,6 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
     // the Q image is pre-multiplied by log2(e)/sqrtf(dk) by its converter (sdpa_dev_cvt_d2bf_q), so
     // the MFMA chains deliver exp2-domain scores: the multiplier of the softmax argument is 1
     (void)scale;
-    constexpr float c = 1.0f;
 
     u32x4 qf[NKS];
 #pragma unroll
@@ -593,8 +593,11 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
         for (int tt = 0; tt < NT; ++tt) asm volatile("" : "+a"(oacc[tt]));
     };
     pin_o();
-    constexpr float kDeferLog2 = 32.0f;                   // P <= 2^32; beyond that the block is redone
-    float m_ref = 0.f, max_rel = 0.f, l_run = 0.f;       // exp2 domain, see the fp32 kernel
+    // Reference exponent ZERO: P = exp2(score), nothing else per element (the Q image carries
+    // log2e/sqrt(dk)).  No row max is tracked: the row sum tells after the last tile whether the row
+    // stayed in range (redo flag) and which power of two to fold out.  VALU issue does not overlap
+    // MFMA issue on a SIMD (profiles/r02/mfma_valu_overlap_bf16.log): every VALU op is matrix-pipe time.
+    float l_run = 0.f;                                    // this half-wave's share of the row sum
 
     // ---- K and Vt staging by LDS-DMA
     const unsigned lds_base = __builtin_amdgcn_readfirstlane(
@@ -718,17 +721,21 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
     // alone); the tail steps do, because hipcc spills around them and may touch the tile at once.
     int kr = 1, kw = 0;
     f32x16 sx;                                             // the score tile
-    // exp of element r is issued one slot before its sum/pack: the transcendental's latency is
-    // never waited on, and it needs no s_nop behind it
-    auto p_exp = [&](int r) __attribute__((always_inline)) {
-        asm volatile("v_exp_f32 %0, %1" : "=v"(sx[r]) : "v"(fmaf(sx[r], c, -m_ref)));
-    };
+    // exp2 in place, issued one element before its row-sum add and bf16 pack: a transcendental's result
+    // is never read by the next instruction
     // (the packed pair goes straight into its word of the P operand: no staging array to keep alive)
-    auto p_acc = [&](int r, u32x4 (&pout)[2]) __attribute__((always_inline)) {
-        asm volatile("v_add_f32 %0, %0, %1" : "+v"(l_run) : "v"(sx[r]));   // pinned: hipcc sinks the adds into one chain
-        if (r & 1) pout[(r >> 1) / 4][(r >> 1) % 4] = bpin_pack(sx[r - 1], sx[r]);
+    auto p_elem = [&](int r, u32x4 (&pout)[2]) __attribute__((always_inline)) {
+        asm volatile("v_exp_f32 %0, %0" : "+v"(sx[r]));
+        if (r >= 1) {
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(l_run) : "v"(sx[r - 1]));   // pinned: hipcc sinks the adds into one chain
+            if (((r - 1) & 1) == 1) pout[((r - 1) >> 1) / 4][((r - 1) >> 1) % 4] = bpin_pack(sx[r - 2], sx[r - 1]);
+        }
     };
-    auto step = [&](auto has_next, auto fenced, const u32x4 (&pb)[2], u32x4 (&pn)[2], int t) __attribute__((always_inline)) -> bool {
+    auto p_close = [&](u32x4 (&pout)[2]) __attribute__((always_inline)) {      // element 15, >= 1 instruction behind its exp2
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(l_run) : "v"(sx[15]));
+        pout[1][3] = bpin_pack(sx[14], sx[15]);
+    };
+    auto step = [&](auto has_next, auto fenced, const u32x4 (&pb)[2], u32x4 (&pn)[2], int t) __attribute__((always_inline)) {
         constexpr bool HAS_NEXT = decltype(has_next)::value;
         constexpr bool FENCED = decltype(fenced)::value;
         const int vbuf = t & 1;
@@ -759,7 +766,6 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
 
         // [B]
         if constexpr (HAS_NEXT) mask_ragged(sx, t + 1);
-        float tmax = -INFINITY;
         constexpr int SLOTS = 2 * NT;                     // P.V MFMAs of this step
         constexpr int VD = SDPA_WIDE_VD;                   // V fragment prefetch depth
         // next step reads the next K buffer: advance the fragment addresses in place
@@ -779,17 +785,11 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
             if (slot + VD < SLOTS) vq[slot % VD] = vfrag(vbuf, slot + VD);
             if constexpr (HAS_NEXT) {
                 if (slot % 4 == 1) dma_v_piece(t + 1, vbuf ^ 1, slot / 4);       // VPW == 8 pieces over 32 slots
-                // first read of the score tile: four MFMAs + four LDS reads (>= 11 issue slots,
-                // the MFMA->VALU requirement for an 8-pass MFMA) behind the chain's last link.
-                // The row max reads the raw scores, so it goes before the exps overwrite them.
+                // first read of the score tile: >= 11 issue slots (the MFMA->VALU requirement for an
+                // 8-pass MFMA) behind the chain's last link
                 if constexpr (!(ABL & 4)) {
-                    if (slot >= 4 && slot < 12) tmax = bpin_max3(tmax, sx[2 * (slot - 4)], sx[2 * (slot - 4) + 1]);
-                    if (slot == 12) tmax = halfwave_max(fmaf(tmax, c, -m_ref));
-                    if (slot >= 12 && slot < 28) {
-                        p_exp(slot - 12);
-                        if (slot > 12) p_acc(slot - 13, pn);
-                    }
-                    if (slot == 28) p_acc(15, pn);
+                    if (slot >= 12 && slot < 28) p_elem(slot - 12, pn);
+                    if (slot == 28) p_close(pn);
                 } else if (slot == 4) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) pn[q / 4][q % 4] = __builtin_bit_cast(unsigned, sx[q]);
@@ -799,14 +799,10 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
         }
         __builtin_amdgcn_sched_barrier(0);
         PIN_O_IN_LOOP(3);
-        bool pending = false;
         if constexpr (HAS_NEXT) {
-            pending = __any(tmax > kDeferLog2);
-            max_rel = fmaxf(max_rel, tmax);
             kr = kr_next;
             kw = kw == 2 ? 0 : kw + 1;
         }
-        return pending;
     };
 
     if (T > 0) {
@@ -827,48 +823,43 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
         }
         mfma_result_fence(sx);
         mask_ragged(sx, 0);
-        float tmax = sx[0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sx[r]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        m_ref = tmax * c;                               // finite: every tile has a valid key row
         // P(0)
         u32x4 pA[2], pB[2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            p_exp(r);
-            if (r > 0) p_acc(r - 1, pA);
-        }
-        p_acc(15, pA);
+        for (int r = 0; r < 16; ++r) p_elem(r, pA);
+        p_close(pA);
         __syncthreads();                                // K(0) fully consumed before K(3) lands on it
 #pragma unroll
         for (int u = 0; u < NKA; ++u) kaddr[u] += (unsigned)(KTILE * 2);   // step 0 reads K(1) in buffer 1
 
-        // Steady state.  A tile whose row max exceeds the reference exponent by more than
-        // 2^kDeferLog2 would need the accumulators rescaled -- and ANY VALU access to the 256
-        // AGPR-resident O values in or around this loop (even on a never-taken branch, even an
-        // early exit) makes hipcc copy and spill accumulator tiles on the hot path.  So this
-        // kernel has no rescale at all: the wave only records that its (q block, split) does not
-        // fit, carries on (its numbers are then meaningless), and the launcher runs the general
-        // kernel right behind this one over the flagged blocks, which rewrites their rows.
+        // Steady state.  ANY VALU access to the 256 AGPR-resident O values in or around this loop
+        // (a rescale, even on a never-taken branch, even an early exit) makes hipcc copy and spill
+        // accumulator tiles on the hot path.  So this kernel has no rescale and no reference exponent
+        // at all: a row whose sum left [2^-80, 2^80] (overflow, or every P flushed to zero) flags its
+        // (q block, split) after the loop, and the launcher runs the general kernel right behind this
+        // one over the flagged blocks, which rewrites their rows.
         int t = 0;
-        bool redo = false;
         for (; t + 2 < T; t += 2) {
-            redo |= step(std::true_type(), std::false_type(), pA, pB, t);
-            redo |= step(std::true_type(), std::false_type(), pB, pA, t + 1);
+            step(std::true_type(), std::false_type(), pA, pB, t);
+            step(std::true_type(), std::false_type(), pB, pA, t + 1);
         }
         if (T - t == 2) {
-            redo |= step(std::true_type(), std::true_type(), pA, pB, t);
+            step(std::true_type(), std::true_type(), pA, pB, t);
             step(std::false_type(), std::true_type(), pB, pA, t + 1);
         } else {
             step(std::false_type(), std::true_type(), pA, pB, t);
         }
-        if (redo && lane == 0) a.redo[split * n_qblocks + qblock] = a.redo_gen;
     }
+    // max_j P_j <= l <= n max_j P_j: inside [2^-80, 2^80] nothing overflowed (2^47 of fp32 headroom
+    // left for sum_j P_j |V_j|) and the row did not flush to zero
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const bool ok = l_tot >= 0x1p-80f && l_tot <= 0x1p80f;
+    if (T > 0 && __any(!ok) && lane == 0) a.redo[split * n_qblocks + qblock] = a.redo_gen;
+    // fold out the power of two just below the row sum: exact, and lsum lands in [1, 2)
+    const int fold_exp = ok ? __builtin_amdgcn_frexp_expf(l_tot) - 1 : 0;
 
-    // ---- epilogue: fold the true row max back in, write this chunk's columns
-    const float fold = __builtin_amdgcn_exp2f(-max_rel);
-    const float l_tot = (l_run + __shfl_xor(l_run, 32)) * fold;
+    // ---- epilogue: the triple relative to lmax = fold_exp * ln 2 (a reference exponent, not the row
+    //      max: any value makes a valid triple for the merges), this chunk's columns
     float *out = a.contrib;
     float *omax = a.lmax, *osum = a.lsum;
     int ldo = a.ldo;
@@ -885,11 +876,11 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int col = 32 * tt + crow16(r, hi);
-                if (dv0 + col < a.dv) orow[col] = oacc[tt][r] * fold;
+                if (dv0 + col < a.dv) orow[col] = __builtin_amdgcn_ldexpf(oacc[tt][r], -fold_exp);
             }
         if (hi == 0 && chunk == 0) {
-            omax[qrow] = T > 0 ? (m_ref + max_rel) * 0.69314718055994530942f : -INFINITY;
-            osum[qrow] = l_tot;
+            omax[qrow] = T > 0 ? (float)fold_exp * 0.69314718055994530942f : -INFINITY;
+            osum[qrow] = __builtin_amdgcn_ldexpf(l_tot, -fold_exp);
         }
     }
 }
@@ -947,11 +938,10 @@ struct DuoCfg {
 #ifdef SDPA_DUO_NKB          // tools/build_variant.sh: ring depth A/B
     static constexpr int NKB = SDPA_DUO_NKB;
 #else
-    // (3, except at dk = dv = 256, where the VGPR file is exactly full and the 3- and 4-buffer
-    //  rotations tip hipcc into spilling a Q fragment inside the loop -- a scratch reload sits behind an
-    //  s_waitcnt vmcnt(0) that also waits for the DMA in flight: 1.92 ms against 1.75 ms with 5 buffers,
-    //  whose rotation happens to allocate cleanly; tests/test_kernel_isa.py guards the property)
-    static constexpr int NKB = DK + DV > 384 ? 5 : 3;
+    // (at dk = dv = 256 the VGPR file is exactly full and some ring depths tip hipcc into spilling a Q
+    //  fragment inside the loop -- a scratch reload sits behind an s_waitcnt vmcnt(0) that also waits for
+    //  the DMA in flight: +16..27 % -- tests/test_kernel_isa.py guards the property for every instantiation)
+    static constexpr int NKB = 3;
 #endif
     static constexpr int NVB = NKB - 1;
     static constexpr size_t lds_bytes = ((size_t)NKB * 32 * DK + (size_t)NVB * DV * 32) * 2;
@@ -960,6 +950,10 @@ struct DuoCfg {
 #ifndef SDPA_DUO_PIN_IN_LOOP
 #define SDPA_DUO_PIN_IN_LOOP 1
 #endif
+#ifndef SDPA_DUO_SCALAR_CLAMP
+#define SDPA_DUO_SCALAR_CLAMP 0
+#endif
+
 #define DUO_PIN_O() do { if constexpr (SDPA_DUO_PIN_IN_LOOP) pin_o(); } while (0)
 template <int DK, int DV>
 __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
@@ -1051,8 +1045,8 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
     pin_o();
     // |score * log2e / sqrt(dk)| <= 80 (|q.k/sqrt(dk)| <= 55), else the block is redone: P <= 2^80 leaves
     // 2^47 of fp32 headroom for sum_j P_j |V_j|
-    constexpr float kRangeLog2 = 80.0f;
-    float max_rel[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};  // exp2 domain
+    float l_run[2] = {0.f, 0.f}, l_tot[2] = {0.f, 0.f};    // exp2 domain
+    int fold_exp[2] = {0, 0};
 
     // ---- K and Vt staging by LDS-DMA (the wide kernel's scheme)
     const unsigned lds_base = __builtin_amdgcn_readfirstlane(
@@ -1067,6 +1061,13 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
                      : "memory" SDPA_M0_CLOBBER);
     };
     const unsigned klane = (unsigned)((lane / KCH) * DK * 2 + (((lane % KCH) ^ ((lane / KCH) & SWZ)) << 4));
+#if SDPA_DUO_SCALAR_CLAMP
+    unsigned kfull[KPW <= 2 ? KPW : 1];
+    if constexpr (KPW <= 2) {
+#pragma unroll
+        for (int j = 0; j < KPW; ++j) kfull[j] = klane ^ (unsigned)((((wave * KPW + j) * RPP) & SWZ) << 4);
+    }
+#endif
     auto dma_k_piece = [&](int tile, int buf, int j) __attribute__((always_inline)) {
         const int base = kv_begin + tile * kKvTile;
         const int last = kv_end - 1 - base;
@@ -1074,10 +1075,24 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
         const int row0 = (wave * KPW + j) * RPP;                  // wave-uniform, a multiple of RPP:
         const unsigned swz = (unsigned)((row0 & SWZ) << 4);       // (row0 + x) & SWZ == (row0 & SWZ) ^ x
         const unsigned dst = lds_base + (unsigned)(buf * KTILE * 2 + (wave * KPW + j) * 1024);
+#if SDPA_DUO_SCALAR_CLAMP       // tools/build_variant.sh, TIMING ONLY (wrong on a ragged last tile): no per-lane clamp
+        const int over = max(row0 + RPP - 1 - last, 0);
+        const char *src = kb + (ptrdiff_t)(row0 - over) * (DK * 2);
+        if constexpr (KPW <= 2) {
+            dma_piece(src, kfull[j], dst);
+        } else {
+            unsigned off;
+            asm volatile("v_xor_b32 %0, %1, %2" : "=v"(off) : "s"(swz), "v"(klane));
+            dma_piece(src, off, dst);
+        }
+#else
+        // rows past the shard's end (only the last tile has any) re-read its last row: finite data,
+        // their scores are masked
         unsigned off;                                             // volatile: not hoisted into KPW live registers
         asm volatile("v_xor_b32 %0, %1, %2" : "=v"(off) : "s"(swz), "v"(klane));
         const unsigned row = (unsigned)min(row0 + (int)(lane / KCH), last);
         dma_piece(kb, row * (DK * 2) + (off % (DK * 2)), dst);
+#endif
     };
     const unsigned vlane = (unsigned)((size_t)(lane >> 2) * a.ldvt * 2u) + (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
     auto dma_v_piece = [&](int tile, int buf, int j) __attribute__((always_inline)) {
@@ -1122,16 +1137,14 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
     };
 
     // ---- softmax slices.  Slice i = element r = i % 16 of block b = i / 16 of score set sx:
-    //   e = exp2(s)  (issued now);  l += e, bf16 pack  (of the PREVIOUS slice: the
-    //   transcendental's latency is never waited on);  row max of the raw scores every other slice.
-    // State carried between slices of one tile: ecur/eprev (the two newest e values), pw (packed).
-    struct SliceState {
-        float e0, e1;              // e of element r-1 (pending add/pack) and r-2 (its pack partner)
-    };
-    // running max of the RAW scores of the lane's query row, per block, over the whole K/V range:
-    // the reference exponent is fixed, so nothing in the loop depends on it -- the cross-half
-    // exchange, the redo test and max_rel are done once, after the last tile
-    float smax[2] = {-INFINITY, -INFINITY};
+    //   e = exp2(s)  (issued now);  l += e, bf16 pack  (of the PREVIOUS slice: the transcendental's
+    //   latency is never waited on).  Nothing else: the reference exponent is ZERO and no row max is
+    //   tracked -- the row sum itself tells, after the last tile, whether the row stayed in range and
+    //   which power of two to fold out (epilogue).  (Tried and measured slower on the same box,
+    //   profiles/r02/bf16_slice_variants_ab.log: v_pk_add_f32 row sums, +6 % at d = 128.)
+    // State carried between slices of one tile: the two newest P values (element r-1: pending add and
+    // pack partner; r-2: its pack partner).
+    struct SliceState { float e0 = 0.f, e1 = 0.f; };
     auto slice = [&](int i, f32x16 (&sx)[2], SliceState &st, u32x4 (&pout)[2][2]) __attribute__((always_inline)) {
         const int b = i / 16, r = i % 16;
         if constexpr (SDPA_DUO_ABL & 1) {
@@ -1147,7 +1160,6 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
             asm volatile("v_add_f32 %0, %0, %1" : "+v"(l_run[b]) : "v"(st.e0));
             if (((r - 1) & 1) == 1) pout[b][((r - 1) >> 1) / 4][((r - 1) >> 1) % 4] = bpin_pack(st.e1, st.e0);
         }
-        if ((r & 1) == 0) smax[b] = bpin_max3(smax[b], sx[b][r], sx[b][r + 1]);
         st.e1 = st.e0;
         st.e0 = e;
         if (r == 15) {                                 // close the block
@@ -1275,7 +1287,6 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
         f32x16 sA[2], sB[2];
         u32x4 pA[2][2], pB[2][2];
         SliceState stA, stB;
-        stA.e0 = stA.e1 = stB.e0 = stB.e1 = 0.f;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             const u32x4 kf = kfrag(ks);
@@ -1318,11 +1329,14 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
         bool redo = false;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            // reference exponent 0: P = 2^score is exact to fp32 rounding while the row's scores stay
-            // inside +-kRangeLog2 (|q.k/sqrt(dk)| <= 55); a row that leaves that range on either side --
-            // overflow, or every P flushed to zero -- sends its workgroup to the redo pass
-            max_rel[b] = halfwave_max(smax[b]);
-            redo |= __any(!(fabsf(max_rel[b]) <= kRangeLog2));
+            // reference exponent 0: P = 2^score.  max_j P_j <= l <= n max_j P_j, so a row sum inside
+            // [2^-80, 2^80] means nothing overflowed (2^47 of fp32 headroom left for sum_j P_j |V_j|) and
+            // the row did not flush to zero; a row outside -- or a NaN -- sends its workgroup to the redo pass
+            l_tot[b] = l_run[b] + __shfl_xor(l_run[b], 32);
+            const bool ok = l_tot[b] >= 0x1p-80f && l_tot[b] <= 0x1p80f;
+            redo |= __any(!ok);
+            // fold out the power of two just below the row sum: exact, and lsum lands in [1, 2)
+            fold_exp[b] = ok ? __builtin_amdgcn_frexp_expf(l_tot[b]) - 1 : 0;
         }
         if (redo && lane == 0) {                        // flags are per 128-row block of the redo kernel
             const int q128 = 2 * qblock;
@@ -1331,7 +1345,8 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
         }
     }
 
-    // ---- epilogue: fold the true row max back in
+    // ---- epilogue: the triple relative to lmax = fold_exp * ln 2 (the reference exponent of this
+    //      row: any value makes a valid triple for the merges; this one keeps lsum in [1, 2))
     float *out = a.contrib;
     float *omax = a.lmax, *osum = a.lsum;
     int ldo = a.ldo;
@@ -1344,8 +1359,6 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int qrow = qrow0 + 32 * b;
-        const float fold = __builtin_amdgcn_exp2f(-max_rel[b]);
-        const float l_tot = (l_run[b] + __shfl_xor(l_run[b], 32)) * fold;
         if (qrow < a.m) {
             float *orow = out + (size_t)qrow * ldo;
 #pragma unroll
@@ -1353,11 +1366,11 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int col = 32 * tt + crow16(r, hi);
-                    if (col < a.dv) orow[col] = oacc[b][tt][r] * fold;
+                    if (col < a.dv) orow[col] = __builtin_amdgcn_ldexpf(oacc[b][tt][r], -fold_exp[b]);
                 }
             if (hi == 0) {
-                omax[qrow] = T > 0 ? max_rel[b] * 0.69314718055994530942f : -INFINITY;
-                osum[qrow] = l_tot;
+                omax[qrow] = T > 0 ? (float)fold_exp[b] * 0.69314718055994530942f : -INFINITY;
+                osum[qrow] = __builtin_amdgcn_ldexpf(l_tot[b], -fold_exp[b]);
             }
         }
     }

@@ -108,8 +108,9 @@ def test_bf16_shapes(m, n, dk, dv, dist, pkg, be, orc, O):
 
 
 def test_bf16_wide_steep_scores_take_the_redo_pass(pkg, be, O):
-    """dv > 256 runs the wide kernel, which has no accumulator rescale: a q block whose row max
-    climbs more than 2^32 above its first tile's is flagged and redone by the general kernel.
+    """dv > 256 runs the wide kernel, which has no accumulator rescale and the reference exponent
+    zero: a q block with a row whose sum of 2^score leaves [2^-80, 2^80] is flagged and redone by the
+    general kernel.
     Block 0 (rows 0..127) climbs 0.5 nat per key, block 1 has flat scores and must stay on the
     wide kernel's own result."""
     m, n, d = 256, 1024, 512
@@ -138,8 +139,8 @@ def test_bf16_wide_steep_scores_take_the_redo_pass(pkg, be, O):
 @pytest.mark.parametrize("d", [64, 128, 256])
 def test_bf16_duo_steep_scores_take_the_redo_pass(d, pkg, be, O):
     """dk, dv <= 256 run the duo kernel (two query blocks per wave, 256-row workgroups), which like
-    the wide kernel keeps the first tile's reference exponent: a workgroup in which some row's max
-    climbs more than 2^32 above it flags its two 128-row blocks and the general kernel redoes them.
+    the wide kernel computes against the reference exponent zero: a workgroup in which some row's sum
+    of 2^score leaves [2^-80, 2^80] flags its two 128-row blocks and the general kernel redoes them.
     Rows 0..127 climb 0.5 nat per key (workgroup 0 is redone, including its flat rows 128..255);
     workgroup 1 (rows 256..511, flat scores) must stay on the duo kernel's own result."""
     m, n = 512, 1024
@@ -181,8 +182,10 @@ def test_bf16_duo_every_instantiation(dk, dv, pkg, be, orc, O):
 
 @pytest.mark.parametrize("d", [128, 512])
 def test_bf16_kv_splits_and_triple(d, pkg, be, O):
-    """long K/V with few query blocks: in-GPU splits; the triple's lmax is the fp32-exact row max of
-    the scores of the bf16 operand images (d = 128: duo kernel, d = 512: wide kernel)"""
+    """long K/V with few query blocks: in-GPU splits.  The triple of the fixed-reference kernels
+    (d = 128: duo, d = 512: wide) is relative to a power of two, not to the row max: lmax is the
+    reference exponent that puts lsum in [1, 2), and lmax + ln(lsum) is the row's log-sum-exp of the
+    scores of the bf16 operand images"""
     m, n = 256, 8192
     assert pkg.load().sdpa_dev_kv_splits_bf16(m, n, d, d) > 1
     Q, K, V = O.make_inputs(m, n, d, d, "D2", seed=4)
@@ -190,9 +193,32 @@ def test_bf16_kv_splits_and_triple(d, pkg, be, O):
     assert np.abs(got - O.numpy_attention_f64(Q, K, V)).max() <= bf16_tol(V)
     sa = pkg.ShardedAttention(be, precision="bf16")
     sa.load_kv_from_root(K, V, n, d, d)
-    _, lmax, _ = sa.batch_partial(sa.convert_q(torch.from_numpy(Q).cuda()))
+    _, lmax, lsum = sa.batch_partial(sa.convert_q(torch.from_numpy(Q).cuda()))
+    lmax = lmax.cpu().numpy().astype(np.float64); lsum = lsum.cpu().numpy().astype(np.float64)
     s = (q_image_f64(Q) @ to_bf16_f64(K).T) / np.sqrt(np.float32(d))
-    assert np.abs(lmax.cpu().numpy() - s.max(axis=1)).max() <= 1e-4 * max(1.0, np.abs(s).max())
+    lse = s.max(axis=1) + np.log(np.exp(s - s.max(axis=1, keepdims=True)).sum(axis=1))
+    assert np.abs(lmax + np.log(lsum) - lse).max() <= 1e-4 * max(1.0, np.abs(lse).max())
+    assert (lsum > 0).all() and np.abs(lmax - s.max(axis=1)).max() <= np.log(n) + 1.0
+
+
+@pytest.mark.parametrize("d", [128, 512])
+@pytest.mark.parametrize("offset", [-40.0, 40.0, -70.0, 70.0])
+def test_bf16_fixed_reference_range(d, offset, pkg, be, O):
+    """The duo and wide kernels compute P = 2^score against the reference exponent ZERO.  Rows whose
+    scores sit +-40 nats from zero are still inside their range (row sums within 2^+-80); at +-70 nats
+    (2^+-101) the row sum leaves it -- overflow on one side, P flushed towards zero on the other -- and
+    the general kernel redoes the block.  Either way the answer is the oracle's."""
+    m, n = 256, 2048 + 5
+    rng = np.random.default_rng(int(1000 + d + offset))
+    Q = rng.standard_normal((m, d)) * 0.3
+    K = rng.standard_normal((n, d)) * 0.3
+    Q[:, 0] = np.sqrt(d)
+    K[:, 0] = offset                              # every score of every row moves by `offset` nats
+    V = rng.standard_normal((n, d))
+    got = dev_attention_bf16(pkg, be, Q, K, V)
+    want = O.numpy_attention_f64(q_image_f64(Q), to_bf16_f64(K), to_bf16_f64(V))
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= 4e-3 * max(1.0, np.abs(V).max())
 
 
 def test_bf16_host_level_flag_and_shard_merge(pkg, be, orc, O):
