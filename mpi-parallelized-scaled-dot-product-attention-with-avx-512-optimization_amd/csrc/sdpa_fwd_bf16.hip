@@ -954,6 +954,7 @@ struct DuoCfg {
 #define SDPA_DUO_SCALAR_CLAMP 0
 #endif
 
+
 #define DUO_PIN_O() do { if constexpr (SDPA_DUO_PIN_IN_LOOP) pin_o(); } while (0)
 template <int DK, int DV>
 __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
@@ -1141,7 +1142,8 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
     //   latency is never waited on).  Nothing else: the reference exponent is ZERO and no row max is
     //   tracked -- the row sum itself tells, after the last tile, whether the row stayed in range and
     //   which power of two to fold out (epilogue).  (Tried and measured slower on the same box,
-    //   profiles/r02/bf16_slice_variants_ab.log: v_pk_add_f32 row sums, +6 % at d = 128.)
+    //   +6 % at d = 128 each: v_pk_add_f32 row sums, and v_dot2_f32_bf16 row sums of the packed
+    //   weights -- profiles/r02/bf16_slice_variants_ab.log, bf16_dot2_rowsum_ab.log.)
     // State carried between slices of one tile: the two newest P values (element r-1: pending add and
     // pack partner; r-2: its pack partner).
     struct SliceState { float e0 = 0.f, e1 = 0.f; };
