@@ -110,20 +110,43 @@ int env_int(const char *name, int dflt) {
 // RAII page-locking of caller-owned host arrays (best effort: a range that cannot be registered,
 // e.g. because the caller already allocated it page-locked, is simply left as it is).
 struct HostPins {
-    void *ptr[4];
+    void *ptr[8];
     int n = 0;
+    double us = 0.0;                                        // host time spent registering
     void add(const void *p, size_t bytes) {
-        if (bytes < (1u << 20) || n >= 4) return;          // small arrays: not worth the call
+        if (bytes < (1u << 20) || n >= 8) return;          // small arrays: not worth the call
+        const double t0 = now_us();
         if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) == hipSuccess)
             ptr[n++] = const_cast<void *>(p);
         else
             (void)hipGetLastError();
+        us += now_us() - t0;
     }
     ~HostPins() {
         for (int i = 0; i < n; ++i)
             if (hipHostUnregister(ptr[i]) != hipSuccess) (void)hipGetLastError();
     }
 };
+
+// Where a caller array is cut in two for registration in two goes (progressive pinning, see
+// sdpa_attention_f64): a page boundary, so that the two registered ranges share no page.  A copy
+// that straddles the cut is issued in two parts -- the runtime only treats a host range as
+// page-locked when it lies inside ONE registration.
+struct PinCuts {
+    const char *k = nullptr, *v = nullptr;
+};
+PinCuts &CUT = *new PinCuts;
+
+hipError_t copy_h2d_cut(void *dst, const void *src, size_t bytes, const char *cut, hipStream_t st) {
+    const char *s0 = (const char *)src;
+    if (cut && s0 < cut && cut < s0 + bytes) {
+        const size_t head = (size_t)(cut - s0);
+        hipError_t e = hipMemcpyAsync(dst, s0, head, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return e;
+        return hipMemcpyAsync((char *)dst + head, cut, bytes - head, hipMemcpyHostToDevice, st);
+    }
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+}
 
 // Whatever path leaves sdpa_attention_f64 -- also an error in the middle of the pipeline -- no
 // queued copy, kernel or collective may still reference the caller's arrays when they are
@@ -463,8 +486,8 @@ int stage_half(const Plan &pl, Rank &rk, const RankPlan &rp, const double *src, 
     const int cols = is_v ? pl.dv : pl.dk;
     double *stage = (double *)(is_v ? rk.v64.p : rk.k64.p) + (size_t)ch.k0 * cols;
     hipEvent_t copied = rk.ev_h2d[2 * c + (is_v ? 1 : 0)];
-    HIP_TRY(hipMemcpyAsync(stage, src + row0 * cols, (size_t)ch.keys * cols * sizeof(double), hipMemcpyHostToDevice,
-                           rk.s_cp));
+    HIP_TRY(copy_h2d_cut(stage, src + row0 * cols, (size_t)ch.keys * cols * sizeof(double), is_v ? CUT.v : CUT.k,
+                         rk.s_cp));
     HIP_TRY(hipEventRecord(copied, rk.s_cp));
     HIP_TRY(hipStreamWaitEvent(rk.s_in, copied, 0));
     if (!is_v) {
@@ -718,18 +741,59 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
     // registered ones at ~57 GB/s and truly asynchronously, which the whole enqueue-then-wait
     // structure below relies on for its overlap (it stays correct without).  Nothing stays
     // registered after the call (no pointer is retained).
+    //
+    // Progressive pinning (one rank, streamed K/V): registering costs ~3.8 us per MiB of host time
+    // (0.85 ms for the metric shape's 224 MiB), so only what the FIRST copies need is registered up
+    // front -- K/V chunk 0 (cut at a page boundary) -- and the rest right behind the enqueue of the
+    // work it does not gate: Q behind chunk 0's copies, the K/V remainders behind Q's, `result` (whose
+    // pages a caller has typically never touched: registering it faults them in) right before the
+    // first rows go home, when the batch's kernels are already queued.  The GPU works while the host
+    // registers.
     HostPins pins;
     DrainOnExit drain;
-    const double t_reg0 = now_us();
-    {
-        const char *env = getenv("SDPA_HOST_REGISTER");
-        if (!env || atoi(env) != 0) {
-            pins.add(K, (size_t)n * dk * sizeof(double));
-            pins.add(V, (size_t)n * dv * sizeof(double));
+    struct ClearCuts { ~ClearCuts() { CUT = PinCuts(); } } clear_cuts;
+    CUT = PinCuts();
+    const bool do_pin = !getenv("SDPA_HOST_REGISTER") || atoi(getenv("SDPA_HOST_REGISTER")) != 0;
+    const size_t k_bytes = (size_t)n * dk * sizeof(double), v_bytes = (size_t)n * dv * sizeof(double);
+    bool progressive = false;
+    const bool want_progressive = !getenv("SDPA_PROGRESSIVE_PIN") || atoi(getenv("SDPA_PROGRESSIVE_PIN")) != 0;
+    if (do_pin && P == 1 && pl.r[0].chunks.size() > 1 && !PF.active && want_progressive) {
+        const size_t c0 = (size_t)pl.r[0].chunks[0].keys;
+        auto cut_of = [](const double *base, size_t head_bytes, size_t total) -> const char * {
+            const uintptr_t c = ((uintptr_t)base + head_bytes + 4095) & ~(uintptr_t)4095;
+            return c < (uintptr_t)base + total ? (const char *)c : nullptr;
+        };
+        CUT.k = cut_of(K, c0 * dk * sizeof(double), k_bytes);
+        CUT.v = cut_of(V, c0 * dv * sizeof(double), v_bytes);
+        progressive = CUT.k && CUT.v;
+        if (!progressive) CUT = PinCuts();
+    }
+    // stage 0: before the first copy is enqueued; 1: behind K/V chunk 0; 2: behind Q; 3: before the first D2H
+    auto pin_stage = [&](int stage) {
+        if (!do_pin) return;
+        if (!progressive) {
+            if (stage != 0) return;
+            pins.add(K, k_bytes);
+            pins.add(V, v_bytes);
             pins.add(Q, (size_t)m * dk * sizeof(double));
             pins.add(result, (size_t)m * dv * sizeof(double));
+            return;
         }
-    }
+        switch (stage) {
+            case 0:
+                pins.add(K, (size_t)(CUT.k - (const char *)K));
+                pins.add(V, (size_t)(CUT.v - (const char *)V));
+                break;
+            case 1: pins.add(Q, (size_t)m * dk * sizeof(double)); break;
+            case 2:
+                pins.add(CUT.k, k_bytes - (size_t)(CUT.k - (const char *)K));
+                pins.add(CUT.v, v_bytes - (size_t)(CUT.v - (const char *)V));
+                break;
+            default: pins.add(result, (size_t)m * dv * sizeof(double)); break;
+        }
+    };
+    bool result_pinned = false;
+    pin_stage(0);
     const double t_reg1 = now_us();
 
     Rank &root = E.r[0];
@@ -776,6 +840,7 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
             // chunks.  q64[s] was last read by the convert of batch b-2 (ev_q[s]); qf[s] by its
             // kernels (ev_run[s]).
             if (b == 0 && C > 0) SDPA_TRY(stage_chunk(pl, rk, rp, g, K, V, 0));
+            if (b == 0) pin_stage(1);
             if (b >= 2) {
                 HIP_TRY(hipStreamWaitEvent(rk.s_cp, rk.ev_q[s], 0));
                 HIP_TRY(hipStreamWaitEvent(rk.s_in, rk.ev_run[s], 0));
@@ -788,6 +853,7 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
                 SDPA_TRY(stage_q_rows(pl, rk, Q, s, i0, 0, bs, rk.ev_qh[0], rk.ev_q[s]));
             }
             if (b == 0) {
+                pin_stage(2);
                 for (int c = 1; c < C; ++c) SDPA_TRY(stage_chunk(pl, rk, rp, g, K, V, c));
                 if (g == 0) HIP_TRY(hipEventRecord(rk.ev_kv_done, rk.s_in));
             }
@@ -804,6 +870,10 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
             // rows [j0, j0+jr) are complete in contrib[s]/stat[s]: step 5 with gsum = lsum fused with
             // the fp64 writeback (attention-mpi.c:358-362, :373), then they go home
             auto finish_rows = [&](int ev, int j0, int jr) -> int {
+                if (!result_pinned) {        // behind the enqueue of (nearly) all of the batch's kernels
+                    pin_stage(3);
+                    result_pinned = true;
+                }
                 HIP_TRY(sdpa::launch_finish_f64((const float *)rk.contrib[s].p + (size_t)j0 * pl.ldo, pl.ldo,
                                                 (const float *)rk.stat[s].p + bs + j0,
                                                 (double *)rk.out64[s].p + (size_t)j0 * dv, jr, dv, rk.s_run));
@@ -935,7 +1005,7 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
     sdpa_timing &T = E.last;
     T = sdpa_timing();
     T.total_us = t_exit - t_enter;
-    T.register_us = t_reg1 - t_reg0;
+    T.register_us = pins.us;
     T.kernel_us = kernel_ms * 1e3;
     if (n_brackets >= 2) {
         const int rank0_chunks = (int)pl.r[0].chunks.size();

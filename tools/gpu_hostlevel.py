@@ -14,7 +14,8 @@ sweep = "--sweep" in sys.argv
 pinned = "--pinned" in sys.argv
 lib = pkg.load()
 pkg.init(1)
-KNOBS = ("SDPA_QBATCH", "SDPA_KV_CHUNK_MIN", "SDPA_KV_CHUNK_MAX", "SDPA_ROW_PIECES", "SDPA_PIECE_MIN_ROWS", "SDPA_HOST_REGISTER")
+KNOBS = ("SDPA_QBATCH", "SDPA_KV_CHUNK_MIN", "SDPA_KV_CHUNK_MAX", "SDPA_ROW_PIECES", "SDPA_PIECE_MIN_ROWS", "SDPA_HOST_REGISTER",
+         "SDPA_PROGRESSIVE_PIN")
 SWEEP = [{},
          {"SDPA_ROW_PIECES": 1},
          {"SDPA_ROW_PIECES": 2},
