@@ -31,10 +31,12 @@
 // Kernels in this file:
 //   fused_pipelined_kernel<DK,DV>   dense dk, dv in {64,128}: LDS-DMA staging, XOR-swizzled K image,
 //                                   two live score tiles (the shipped path of every BASELINE fp32
-//                                   config; 142 TFLOP/s = 90.5 % of peak at the metric shape)
+//                                   config; 143 TFLOP/s = 91 % of peak at the metric shape); and dense
+//                                   {256,256}, {256,128}, {128,256} at one wave per SIMD (O^T in the
+//                                   accumulator file, asm score chains: 137 TFLOP/s at dk = dv = 256)
 //   fused_partial_kernel<DKP,DVP>   any dk <= 256 (padded to 32/64/128/256), any dv (chunks of <= 128
 //                                   columns): register-staged
-//   fused_dksplit_kernel<DKS,DVS>   256 < dk <= 512, and 128 < dk <= 256 with dv > 128: the four waves split dk
+//   fused_dksplit_kernel<DKS,DVS>   256 < dk <= 512, and non-dense 128 < dk <= 256 with dv > 128: the four waves split dk
 //                                   (scores) and dv (accumulate), partial score tiles exchanged through LDS,
 //                                   K/V straight from global memory
 //   generic_partial_kernel          dk > 512: VALU-only correctness path
@@ -51,6 +53,7 @@
 namespace sdpa {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x1 __attribute__((ext_vector_type(1)));
@@ -97,6 +100,13 @@ template <int NT> struct VFrag;
 template <> struct VFrag<4> {
     f32x4 v;
     static __device__ __forceinline__ VFrag load(const float *p) { return {*reinterpret_cast<const f32x4 *>(p)}; }
+};
+template <> struct VFrag<8> {      // two float4, 128 columns apart (tiles 0..3 and 4..7)
+    f32x8 v;
+    static __device__ __forceinline__ VFrag load(const float *p) {
+        const f32x4 lo = *reinterpret_cast<const f32x4 *>(p), up = *reinterpret_cast<const f32x4 *>(p + 128);
+        return {__builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, 6, 7)};
+    }
 };
 template <> struct VFrag<2> {
     f32x2 v;
@@ -361,7 +371,7 @@ __global__ __launch_bounds__(256, (DKP > 128) ? 1 : 2) void fused_partial_kernel
 }
 
 // ---------------------------------------------------------------------------
-// Software-pipelined variant for dense dk, dv in {64, 128} (leading dimensions equal to
+// Software-pipelined variant for dense dk, dv in {64, 128, 256} (leading dimensions equal to
 // the dims, i.e. no padding columns).  Same maths and same outputs as
 // fused_partial_kernel; what changes is the schedule inside a wave:
 //   * K/V tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave
@@ -378,11 +388,22 @@ __global__ __launch_bounds__(256, (DKP > 128) ? 1 : 2) void fused_partial_kernel
 // ABL: timing-only ablation switches (results are wrong when non-zero; $SDPA_TUNE selects them):
 //   1 = no DMA / no barrier in the steady state, 2 = no LDS fragment reads, 4 = no softmax VALU
 template <int DK, int DV, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, int kv_per_split,
-                                                                  int n_qblocks, float scale) {
+__global__ __launch_bounds__(256, (DK + DV > 256) ? 1 : 2) void fused_pipelined_kernel(PartialArgs a, int kv_per_split,
+                                                                                       int n_qblocks, float scale) {
     constexpr int NU = DK / 8;                // 16-byte K reads per tile per lane
-    constexpr int PPU = 16 / NU;              // P values finished per 4-MFMA QK^T step
+    constexpr int PPU = NU <= 16 ? 16 / NU : 1;   // P values finished per 4-MFMA QK^T step ...
+    constexpr int PEV = NU <= 16 ? 1 : NU / 16;   // ... of every PEV-th step (dk = 256: every other one)
     constexpr int NT = DV / 32;               // O^T tiles
+    // V columns of a lane: NV consecutive floats per vector read, NH reads 128 columns apart.  O^T tile
+    // tt, row i is V column (tt / NV) * 32 NV + NV i + tt % NV  (dv <= 128: NT i + tt)
+    constexpr int NV = NT < 4 ? NT : 4;
+    constexpr int NH = NT / NV;
+    // One wave per SIMD with the whole 512-register file (dk + dv > 256): O^T lives in the accumulator
+    // file and is touched by nothing but MFMAs and "+a" asm (any plain VALU use of it makes hipcc shuttle
+    // tiles between the files on the hot path, as in the bf16 wide kernel); the score chains are inline-asm
+    // MFMAs with VGPR C/D, because in this mode hipcc puts every builtin MFMA result in AGPRs and the
+    // softmax works on VGPRs.  hipcc sees no MFMA inside an asm statement: wait states are placed by hand.
+    constexpr bool WIDE = DK + DV > 256;
     constexpr int KTILE = kKvTile * DK;       // floats
     constexpr int VTILE = kKvTile * DV;
     constexpr int KCH = DK / 4;               // 16-byte chunks per K row
@@ -427,6 +448,26 @@ __global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, 
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+    auto pin_o = [&]() __attribute__((always_inline)) {
+        if constexpr (WIDE) {
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) asm volatile("" : "+a"(oacc[tt]));
+        }
+    };
+    pin_o();
+    // one link of a score chain: sx += k * q over two contraction indices
+    auto score_link = [&](f32x16 &sx, float kv, float qv) __attribute__((always_inline)) {
+        if constexpr (WIDE) {
+            // s_nop 1: "VALU write -> MFMA read" needs 2 wait states and the allocator may set an operand up right in front
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(sx) : "v"(kv), "v"(qv));
+        } else {
+            sx = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, qv, sx, 0, 0, 0);
+        }
+    };
+    // a 16-pass MFMA's result may be read by the VALU 18 wait states after issue
+    auto score_fence = [&](f32x16 &sx) __attribute__((always_inline)) {
+        if constexpr (WIDE) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(sx));
+    };
     // Softmax state of this lane's query row, all in the exp2 domain:
     //   m_ref   reference exponent the accumulators are relative to (the row max when it was
     //           last moved; NOT moved for rises below kDeferLog2 -- fp32 has the headroom)
@@ -523,6 +564,7 @@ __global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, 
     auto mask_ragged = [&](f32x16 &sx, int tile) __attribute__((always_inline)) {
         const int valid = kv_end - (kv_begin + tile * kKvTile);
         if (valid < kKvTile) {
+            score_fence(sx);
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (crow(r, hi) >= valid) sx[r] = -INFINITY;
@@ -537,10 +579,21 @@ __global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, 
         if (__any(tmax > kDeferLog2)) {
             const float jump = fmaxf(tmax, 0.f);
             const float alpha = fast_exp2(-jump);
+            if constexpr (WIDE) {           // O stays in the accumulator file: read - scale - write back inside asm
 #pragma unroll
-            for (int tt = 0; tt < NT; ++tt)
+                for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[tt][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) {
+                        float tmp;
+                        asm volatile("v_accvgpr_read_b32 %1, %0\n\ts_nop 0\n\tv_mul_f32 %1, %1, %2\n\ts_nop 0\n\tv_accvgpr_write_b32 %0, %1"
+                                     : "+a"(oacc[tt][r]), "=&v"(tmp) : "v"(alpha));
+                    }
+            } else {
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[tt][r] *= alpha;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) sx[r] -= jump;
             l_run *= alpha;
@@ -555,6 +608,7 @@ __global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, 
     auto step = [&](auto has_next, f32x16 &su, f32x16 &sm, int t) __attribute__((always_inline)) {
         constexpr bool HAS_NEXT = decltype(has_next)::value;
         const int vbuf = t & 1, kbuf = (t + 1) & 1;
+        pin_o();
         if (t + 2 < T) dma_k(t + 2, t & 1);
         if (t + 1 < T) dma_v(t + 1, (t + 1) & 1);
         if constexpr (HAS_NEXT) {
@@ -579,12 +633,12 @@ __global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, 
                 float4 kn2 = kn;
                 if (u + 2 < NU) kn2 = kfrag(kbuf, u + 2);
                 __builtin_amdgcn_sched_barrier(0);
-                sm = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[u].x, sm, 0, 0, 0);
-                sm = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[u].y, sm, 0, 0, 0);
-                sm = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[u].z, sm, 0, 0, 0);
-                sm = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[u].w, sm, 0, 0, 0);
+                score_link(sm, kf.x, qf[u].x);
+                score_link(sm, kf.y, qf[u].y);
+                score_link(sm, kf.z, qf[u].z);
+                score_link(sm, kf.w, qf[u].w);
 #pragma unroll
-                for (int r = u * PPU; r < (u + 1) * PPU; ++r) {
+                for (int r = (u / PEV) * PPU; r < (u % PEV == 0 ? (u / PEV + 1) * PPU : 0); ++r) {
                     if constexpr (ABL & 4) {
                         asm volatile("" : "+v"(su[r]));
                     } else {
@@ -609,7 +663,7 @@ __global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, 
 
         // [B] O^T += V(t)^T.P(t)^T on the matrix pipe  ||  row max of S^T(t+1) on the VALU
         if constexpr (HAS_NEXT) mask_ragged(sm, t + 1);
-        const float *vt = Vs + vbuf * VTILE + NT * li + 4 * hi * DV;
+        const float *vt = Vs + vbuf * VTILE + NV * li + 4 * hi * DV;
         float tmax = -INFINITY;
         auto vload = [&](int r) __attribute__((always_inline)) -> VFrag<NT> {
             if constexpr (ABL & 2) {
@@ -621,6 +675,7 @@ __global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, 
                 return VFrag<NT>::load(vt + crow(r, 0) * DV);
             }
         };
+        static_assert(NH == 1 || NT == 8, "VFrag<8> reads two float4 128 columns apart");
         VFrag<NT> vf = vload(0);
         VFrag<NT> vn = vload(1);
 #pragma unroll
@@ -641,6 +696,7 @@ __global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, 
             vn = vn2;
         }
         __builtin_amdgcn_sched_barrier(0);
+        pin_o();
         if constexpr (HAS_NEXT && !(ABL & 4)) absorb_rel(tmax, sm);
         stage_fence();                        // drain this wave's DMAs, then barrier
     };
@@ -657,11 +713,12 @@ __global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, 
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const float4 kf = kfrag(0, u);
-            sA = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[u].x, sA, 0, 0, 0);
-            sA = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[u].y, sA, 0, 0, 0);
-            sA = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[u].z, sA, 0, 0, 0);
-            sA = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[u].w, sA, 0, 0, 0);
+            score_link(sA, kf.x, qf[u].x);
+            score_link(sA, kf.y, qf[u].y);
+            score_link(sA, kf.z, qf[u].z);
+            score_link(sA, kf.w, qf[u].w);
         }
+        score_fence(sA);
         mask_ragged(sA, 0);
         float tmax = sA[0];
 #pragma unroll
@@ -705,10 +762,12 @@ __global__ __launch_bounds__(256, 2) void fused_pipelined_kernel(PartialArgs a, 
         float *orow = out + (size_t)qrow * ldo;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int col0 = NT * crow(r, hi);
-            if constexpr (NT == 4) {
-                *reinterpret_cast<float4 *>(orow + col0) =
-                    make_float4(oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]);
+            const int col0 = NV * crow(r, hi);
+            if constexpr (NV == 4) {
+#pragma unroll
+                for (int h = 0; h < NH; ++h)
+                    *reinterpret_cast<float4 *>(orow + 128 * h + col0) =
+                        make_float4(oacc[4 * h][r], oacc[4 * h + 1][r], oacc[4 * h + 2][r], oacc[4 * h + 3][r]);
             } else {
                 *reinterpret_cast<float2 *>(orow + col0) = make_float2(oacc[0][r], oacc[1][r]);
             }
@@ -1211,6 +1270,14 @@ hipError_t launch_shard_partial(const PartialArgs &a_in, hipStream_t s) {
 #else
     a.tune = 0;
 #endif
+    // dense 64/128/256-wide operands take the software-pipelined LDS-DMA kernel ($SDPA_TUNE&4: off)
+    const bool dense = a.ldq == a.dk && a.ldk == a.dk && a.ldv == a.dv && a.ldo % 4 == 0 &&
+                       (reinterpret_cast<uintptr_t>(a.K) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.V) & 15) == 0;
+    if (dense && !(a.tune & 4)) {       // one wave per SIMD: Q (128 VGPRs at dk = 256) and O^T (128 AGPRs at dv = 256) resident
+        if (a.dk == 256 && a.dv == 256) return launch_pipelined<256, 256>(a, s);
+        if (a.dk == 256 && a.dv == 128) return launch_pipelined<256, 128>(a, s);
+        if (a.dk == 128 && a.dv == 256) return launch_pipelined<128, 256>(a, s);
+    }
     if (uses_dksplit(a.dk, a.dv) && !(a.tune & 8)) {   // $SDPA_TUNE&8: the kernels it replaced
         if (a.dk > 384) {
             switch (dksplit_slice(a.dv)) {
@@ -1239,9 +1306,6 @@ hipError_t launch_shard_partial(const PartialArgs &a_in, hipStream_t s) {
         hipLaunchKernelGGL(generic_partial_kernel, dim3((a.m + 3) / 4), dim3(256), lds, s, a, scale);
         return hipGetLastError();
     }
-    // dense 64/128-wide operands take the software-pipelined LDS-DMA kernel ($SDPA_TUNE&4: off)
-    const bool dense = a.ldq == a.dk && a.ldk == a.dk && a.ldv == a.dv && a.ldo % 4 == 0 &&
-                       (reinterpret_cast<uintptr_t>(a.K) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.V) & 15) == 0;
     if (dense && !(a.tune & 4)) {
         if (a.dk == 128 && a.dv == 128) {
 #ifdef SDPA_ABLATIONS

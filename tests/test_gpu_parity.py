@@ -145,6 +145,10 @@ SHAPES = [
     (20,    70, 600,  48, "D2"),      # dk > 512: VALU any-shape kernel
     (1,      1, 400,   1, "D2"),      # dk-split, smallest possible
     (65,    33, 260, 130, "D3"),      # dk-split, one row past a 64-row workgroup, one key past a tile
+    (300, 1000, 256, 256, "D2"),      # dense 256-wide: pipelined kernel, one wave per SIMD, ragged last tile
+    (129, 2055, 256, 128, "D3"),      # same kernel family, dk = 256 / dv = 128, peaky
+    (257,  700, 128, 256, "D4"),      # dk = 128 / dv = 256, late spike key
+    (513, 8192, 256, 256, "D1"),      # several q blocks, in-GPU K/V splits
 ]
 
 
@@ -433,7 +437,8 @@ def test_gathered_merge_equals_two_phase(pkg, be, orc, O):
     check(got, want, V, "gathered merge, one empty shard")
 
 
-@pytest.mark.parametrize("m,n,dk,dv", [(192, 4096, 64, 64), (160, 4096, 128, 128), (100, 3000, 48, 40), (64, 2048, 200, 136)])
+@pytest.mark.parametrize("m,n,dk,dv", [(192, 4096, 64, 64), (160, 4096, 128, 128), (100, 3000, 48, 40), (64, 2048, 200, 136),
+                                       (160, 4096, 256, 256), (130, 2048, 256, 128), (130, 2048, 128, 256)])
 def test_steep_softmax_exercises_the_rescale_paths(m, n, dk, dv, pkg, be, orc, O):
     """Scores with a standard deviation of ~25: the row max keeps jumping by far more than the
     deferred-rescale threshold (2^24) between tiles, so the rare rescale branches of every kernel

@@ -88,11 +88,28 @@ def test_wide_kernel_loop_is_spill_free(bf16_asm):
     assert c["v_accvgpr_read_b32"] <= 16 and c["v_accvgpr_write_b32"] <= 16, c
 
 
-def test_f32_pipelined_kernel_loop_is_spill_free(tmp_path_factory):
+@pytest.fixture(scope="module")
+def f32_asm(tmp_path_factory):
     if not os.path.exists(HIPCC):
         pytest.skip("no hipcc here")
-    asm = device_asm(tmp_path_factory, "sdpa_fwd_f32.hip")
-    c = main_loop_mix(kernel_lines(asm, "fused_pipelined_kernelILi128ELi128ELi0E"))
+    return device_asm(tmp_path_factory, "sdpa_fwd_f32.hip")
+
+
+def test_f32_pipelined_kernel_loop_is_spill_free(f32_asm):
+    c = main_loop_mix(kernel_lines(f32_asm, "fused_pipelined_kernelILi128ELi128ELi0E"))
     assert c["v_mfma_f32_32x32x2_f32"] == 256, c                  # two tiles x (64 + 64) MFMAs per wave
     assert sum(v for k, v in c.items() if k.startswith("scratch_")) == 0, c
     assert c["v_exp_f32"] == 32 and c["global_load_lds_dwordx4"] == 32, c          # 2 tiles x (8 K + 8 V) 1-KiB pieces
+
+
+@pytest.mark.parametrize("dk,dv", [(256, 256), (256, 128), (128, 256)])
+def test_f32_pipelined_kernel_one_wave_per_simd_keeps_o_in_the_accumulator_file(dk, dv, f32_asm):
+    """dense 256-wide dims: 512 registers per wave, score chains as inline-asm MFMAs with VGPR C/D, O^T
+    in AGPRs.  No scratch in the loop, and the only accumulator-file moves are the ones written by hand
+    in the (cold) deferred-rescale branch: one read and one write per O^T register and step."""
+    c = main_loop_mix(kernel_lines(f32_asm, "fused_pipelined_kernelILi%dELi%dELi0E" % (dk, dv)))
+    assert c["v_mfma_f32_32x32x2_f32"] == 2 * (dk // 2 + 16 * dv // 32), c       # two tiles per loop body
+    assert sum(v for k, v in c.items() if k.startswith("scratch_")) == 0, c
+    assert c["v_accvgpr_read_b32"] == dv and c["v_accvgpr_write_b32"] == dv, c  # 2 steps x (dv/32 tiles x 16) / ... cold branch only
+    assert c["v_exp_f32"] <= 34 and c["global_load_lds_dwordx4"] == 2 * (dk // 16 + dv // 16), c
+
