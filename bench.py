@@ -436,10 +436,11 @@ def main():
             pad = 512 if d > 256 else 256 if d > 128 else 128 if d > 64 else 64
             kernel_name = ("sdpa::fused_bf16_wide_kernel<%d,0> (+ its redo pass)" % pad if d > 256
                            else "sdpa::fused_bf16_duo_kernel<%d,%d> (+ its redo pass)" % (pad, pad))
-        elif d in (64, 128):
+        elif d in (64, 128, 256):
             kernel_name = "sdpa::fused_pipelined_kernel<%d,%d,0>" % (d, d)
         elif 128 < d <= 512:
-            kernel_name = "sdpa::fused_dksplit_kernel<%d,%d>" % (128 if d > 256 else 64, 128 if d > 256 else 64)
+            dks = 128 if d > 384 else 96 if d > 256 else 64
+            kernel_name = "sdpa::fused_dksplit_kernel<%d,%d>" % (dks, 128 if d > 256 else 64)
         else:
             kernel_name = "sdpa::fused_partial_kernel / generic_partial_kernel"
         total_flop = 4.0 * m * n * d
