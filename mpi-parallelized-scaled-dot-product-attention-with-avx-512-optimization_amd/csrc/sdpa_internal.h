@@ -18,7 +18,7 @@ constexpr int kQRowsPerBlock = 128;   // 4 waves x 32 query rows
 constexpr int kKvTile        = 32;    // K/V rows per LDS tile
 constexpr int kMaxFastDim    = 128;   // dk, dv <= 128: one dv chunk, two workgroups per CU
 constexpr int kMaxMfmaDk     = 256;   // dk <= 256 takes an MFMA kernel (any dv, 128-column chunks)
-constexpr int kMaxDkSplit    = 512;   // 256 < dk <= 512: the dk-split MFMA kernel (waves split dk and dv)
+constexpr int kMaxDkSplit    = 1024;  // 256 < dk <= 1024: the dk-split MFMA kernel (waves split dk and dv)
 
 struct PartialArgs {
     const float *Q;  int ldq;

@@ -145,6 +145,10 @@ SHAPES = [
     (20,    70, 600,  48, "D2"),      # dk > 512: VALU any-shape kernel
     (1,      1, 400,   1, "D2"),      # dk-split, smallest possible
     (65,    33, 260, 130, "D3"),      # dk-split, one row past a 64-row workgroup, one key past a tile
+    (70,   333, 1024, 64, "D2"),      # 512 < dk <= 1024: dk-split kernel, 256-wide slices, one q block per workgroup
+    (129,  700, 600, 300, "D1"),      # same, ragged dk (the last wave's slice mostly padding), 64-col dv slices
+    (33,  2055, 1000, 1000, "D3"),    # same, dv > 512 -> two chunks, peaky, in-GPU splits
+    (20,    70, 1100, 48, "D2"),      # dk > 1024: VALU any-shape kernel
     (300, 1000, 256, 256, "D2"),      # dense 256-wide: pipelined kernel, one wave per SIMD, ragged last tile
     (129, 2055, 256, 128, "D3"),      # same kernel family, dk = 256 / dv = 128, peaky
     (257,  700, 128, 256, "D4"),      # dk = 128 / dv = 256, late spike key
