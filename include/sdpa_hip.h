@@ -139,6 +139,15 @@ SDPA_API int sdpa_last_timing(struct sdpa_timing *out);
  * :504); sdpa_attention_f64 works without it, the first call is just slower.               */
 SDPA_API int sdpa_prepare(int m, int n, int dk, int dv, int flags);
 
+/* The schedule sdpa_attention_f64 would run for this problem on `ranks` ranks (1..16), as one JSON
+ * object in buf: Q batch size and count, row pieces, and per rank its K/V rows (owner_count /
+ * owner_disp, attention-mpi.c:19-27) or query rows (SDPA_F_PLAN_QROWS), the streamed K/V chunks
+ * [first key, keys, in-launch splits, first slot] and the scratch it needs.  Reads the same
+ * environment knobs as the call itself.  Pure host arithmetic: needs no GPU and no engine.
+ * SDPA_EINVAL when buf is too small.                                                          */
+SDPA_API int sdpa_plan_describe(int m, int n, int dk, int dv, int flags, int ranks, char *buf,
+                                size_t len);
+
 /* Optional: for hosts that produce or READ K and V incrementally (the CLI's file reader with
  * SDPA_CLI_PREFETCH=1, attention.c:100-121).  Says that rows [0, k_rows_final) of K and
  * [0, v_rows_final) of V are final in host memory; the engine starts moving every K/V chunk that

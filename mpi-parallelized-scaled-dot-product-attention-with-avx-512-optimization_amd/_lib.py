@@ -46,6 +46,7 @@ _PROTOS = {
     "sdpa_attention_f64": (_c_int, [_c_void_p] * 4 + [_c_int] * 5),
     "sdpa_last_timing": (_c_int, [ctypes.POINTER(SdpaTiming)]),
     "sdpa_prepare": (_c_int, [_c_int] * 5),
+    "sdpa_plan_describe": (_c_int, [_c_int] * 6 + [ctypes.c_char_p, ctypes.c_size_t]),
     "sdpa_kv_prefetch": (_c_int, [_c_void_p, _c_void_p] + [_c_int] * 7),
     "sdpa_host_alloc": (_c_void_p, [ctypes.c_size_t]),
     "sdpa_host_free": (None, [_c_void_p]),

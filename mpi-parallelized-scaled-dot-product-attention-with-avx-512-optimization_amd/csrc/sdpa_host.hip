@@ -33,6 +33,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <string>
 #include <vector>
 
 namespace {
@@ -255,9 +256,10 @@ bool want_bf16(int flags) {
     return bf16;
 }
 
-void make_plan(Plan &pl, int m, int n, int dk, int dv, int flags) {
+// ranks > 0: plan for that many ranks without an engine (sdpa_plan_describe: collectives assumed for P > 1)
+void make_plan(Plan &pl, int m, int n, int dk, int dv, int flags, int ranks = 0) {
     pl.m = m; pl.n = n; pl.dk = dk; pl.dv = dv;
-    pl.P = E.n;
+    pl.P = ranks > 0 ? ranks : E.n;
     pl.bf16 = want_bf16(flags);
     pl.qrows = (flags & SDPA_F_PLAN_QROWS) != 0;
     if (const char *v = getenv("SDPA_PLAN")) pl.qrows = pl.qrows || strcmp(v, "qrows") == 0;
@@ -265,7 +267,7 @@ void make_plan(Plan &pl, int m, int n, int dk, int dv, int flags) {
     pl.merge_allreduce = (flags & SDPA_F_MERGE_ALLREDUCE) != 0;
     if (const char *v = getenv("SDPA_MERGE")) pl.merge_allreduce = pl.merge_allreduce || strcmp(v, "allreduce") == 0;
     const bool force = getenv("SDPA_FORCE_COLLECTIVES") && atoi(getenv("SDPA_FORCE_COLLECTIVES")) != 0;
-    pl.collectives = !pl.qrows && (pl.P > 1 || force) && E.coll != nullptr;
+    pl.collectives = !pl.qrows && (pl.P > 1 || force) && (ranks > 0 || E.coll != nullptr);
 
     pl.ldo = round4(dv);
     if (pl.bf16) {
@@ -1082,6 +1084,39 @@ void *sdpa_host_alloc(size_t bytes) {
 
 void sdpa_host_free(void *p) {
     if (p && hipHostFree(p) != hipSuccess) (void)hipGetLastError();
+}
+
+// The schedule sdpa_attention_f64 would run for this problem on `ranks` ranks, as one JSON object.
+// Pure host arithmetic (no device, no engine): what the CPU test-suite checks the planner with.
+int sdpa_plan_describe(int m, int n, int dk, int dv, int flags, int ranks, char *buf, size_t len) {
+    if (!buf || len == 0 || ranks < 1 || ranks > sdpa::kMaxRanks) return SDPA_EINVAL;
+    if (m < 0 || n < 0 || dk < 1 || dv < 1) return SDPA_EINVAL;
+    Plan pl;
+    make_plan(pl, m, n, dk, dv, flags, ranks);
+    std::string o;
+    char t[256];
+    snprintf(t, sizeof t, "{\"ranks\": %d, \"bf16\": %d, \"qrows\": %d, \"collectives\": %d, \"merge_allreduce\": %d, "
+             "\"q_batch\": %d, \"q_batches\": %d, \"row_pieces\": %d, \"piece_min_rows\": %d, \"r\": [",
+             pl.P, pl.bf16 ? 1 : 0, pl.qrows ? 1 : 0, pl.collectives ? 1 : 0, pl.merge_allreduce ? 1 : 0, pl.B, pl.nb,
+             pl.row_pieces, pl.piece_min_rows);
+    o += t;
+    for (int g = 0; g < pl.P; ++g) {
+        const RankPlan &rp = pl.r[g];
+        snprintf(t, sizeof t, "%s{\"key_off\": %d, \"key_cnt\": %d, \"row_off\": %d, \"row_cnt\": %d, \"n_slots\": %d, "
+                 "\"ws_bytes\": %zu, \"piece_rows\": %d, \"chunks\": [", g ? ", " : "", rp.key_off, rp.key_cnt, rp.row_off,
+                 rp.row_cnt, rp.n_slots, rp.ws_bytes, piece_rows_of(pl, std::min(pl.B, rp.row_cnt)));
+        o += t;
+        for (size_t c = 0; c < rp.chunks.size(); ++c) {
+            snprintf(t, sizeof t, "%s[%d, %d, %d, %d]", c ? ", " : "", rp.chunks[c].k0, rp.chunks[c].keys,
+                     rp.chunks[c].splits, rp.chunks[c].slot0);
+            o += t;
+        }
+        o += "]}";
+    }
+    o += "]}";
+    if (o.size() + 1 > len) return SDPA_EINVAL;
+    memcpy(buf, o.c_str(), o.size() + 1);
+    return SDPA_OK;
 }
 
 int sdpa_prepare(int m, int n, int dk, int dv, int flags) {

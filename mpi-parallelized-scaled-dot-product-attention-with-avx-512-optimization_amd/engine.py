@@ -80,6 +80,15 @@ def attention(Q, K, V, flags=0, precision=None, plan=None, merge=None):
     return out
 
 
+def plan(m, n, dk, dv, flags=0, ranks=1):
+    """The schedule sdpa_attention_f64 would run (sdpa_plan_describe): needs no GPU."""
+    import ctypes
+    import json
+    buf = ctypes.create_string_buffer(1 << 18)
+    check(_lib.load().sdpa_plan_describe(m, n, dk, dv, flags, ranks, buf, len(buf)), "sdpa_plan_describe")
+    return json.loads(buf.value.decode())
+
+
 def last_timing():
     t = SdpaTiming()
     check(_lib.load().sdpa_last_timing(ctypes.byref(t)), "sdpa_last_timing")

@@ -1,0 +1,133 @@
+"""CPU: the planner of the C host (sdpa_plan_describe -- the schedule sdpa_attention_f64 runs: Q batches,
+row pieces, per-rank K/V or query-row ranges, streamed K/V chunks, in-launch splits and their slots).
+Pure host arithmetic, so it is checked here without a GPU: partitions are the reference's
+owner_count / owner_disp (attention-mpi.c:19-27), chunks tile a shard exactly on boundaries every
+operand image's tiling divides, slots are dense, and the environment knobs do what INTEGRATION.md says."""
+import pytest
+
+SDPA_F_NO_PIPELINE, SDPA_F_BF16, SDPA_F_PLAN_QROWS, SDPA_F_MERGE_ALLREDUCE = 1, 2, 4, 8
+
+SHAPES = [(32768, 65536, 128, 128), (8192, 8192, 128, 128), (512, 512, 64, 64), (131072, 65536, 128, 128),
+          (32768, 262144, 128, 128), (32768, 65536, 512, 512), (1, 1, 1, 1), (300, 5000, 100, 200), (77, 3, 64, 64),
+          (5, 100000, 256, 256), (40000, 7, 33, 1000)]
+
+
+@pytest.fixture(autouse=True)
+def clean_env(monkeypatch):
+    for k in ("SDPA_QBATCH", "SDPA_KV_CHUNK_MIN", "SDPA_KV_CHUNK_MAX", "SDPA_ROW_PIECES", "SDPA_PIECE_MIN_ROWS",
+              "SDPA_PLAN", "SDPA_MERGE", "SDPA_PRECISION", "SDPA_FORCE_COLLECTIVES"):
+        monkeypatch.delenv(k, raising=False)
+
+
+def check_rank(pl, rp, n_keys_expected, rows_expected):
+    assert rp["key_cnt"] == n_keys_expected and rp["row_cnt"] == rows_expected
+    ch = rp["chunks"]
+    if rp["key_cnt"] == 0:
+        assert ch == [] and rp["n_slots"] == 0
+        return
+    # chunks tile [0, key_cnt) in order; every inner boundary is a multiple of 1024 keys
+    assert ch[0][0] == 0 and sum(c[1] for c in ch) == rp["key_cnt"]
+    for a, b in zip(ch, ch[1:]):
+        assert b[0] == a[0] + a[1] and b[0] % 1024 == 0
+    # slots are dense and in launch order; every launch has at least one split
+    slot = 0
+    for k0, keys, splits, slot0 in ch:
+        assert keys > 0 and 1 <= splits <= 64 and slot0 == slot
+        slot += splits
+    assert rp["n_slots"] == slot
+    # in-launch splits never cut below 4 tiles of 32 keys (8 for the bf16 duo kernel)
+    for k0, keys, splits, slot0 in ch:
+        assert splits == 1 or keys // splits >= 4 * 32 - 32
+    pr = rp["piece_rows"]
+    rows0 = min(pl["q_batch"], rp["row_cnt"])
+    assert (pr == rows0) or (pr % 128 == 0 and pl["piece_min_rows"] <= pr < rows0) or rows0 == 0
+
+
+@pytest.mark.parametrize("m,n,dk,dv", SHAPES)
+@pytest.mark.parametrize("ranks", [1, 2, 3, 8, 16])
+@pytest.mark.parametrize("flags", [0, SDPA_F_BF16])
+def test_kv_sharded_plan(m, n, dk, dv, ranks, flags, pkg, orc):
+    if flags & SDPA_F_BF16 and (dk > 512 or dv > 1024):
+        pytest.skip("outside the bf16 path")
+    pl = pkg.plan(m, n, dk, dv, flags, ranks)
+    assert pl["ranks"] == ranks and pl["qrows"] == 0 and pl["bf16"] == (1 if flags & SDPA_F_BF16 else 0)
+    assert pl["collectives"] == (1 if ranks > 1 else 0)
+    assert pl["q_batch"] == min(32768, m) and pl["q_batches"] == -(-m // pl["q_batch"])
+    off = 0
+    for g, rp in enumerate(pl["r"]):
+        assert rp["key_off"] == orc.owner_disp(n, ranks, g) == off
+        check_rank(pl, rp, orc.owner_count(n, ranks, g), m)
+        assert rp["row_off"] == 0
+        off += rp["key_cnt"]
+    assert off == n
+
+
+@pytest.mark.parametrize("m,n,dk,dv", SHAPES)
+@pytest.mark.parametrize("ranks", [2, 5, 8])
+def test_query_row_sharded_plan(m, n, dk, dv, ranks, pkg, orc):
+    pl = pkg.plan(m, n, dk, dv, SDPA_F_PLAN_QROWS, ranks)
+    assert pl["qrows"] == 1 and pl["collectives"] == 0
+    off = 0
+    for g, rp in enumerate(pl["r"]):
+        assert rp["key_off"] == 0 and rp["row_off"] == orc.owner_disp(m, ranks, g) == off
+        check_rank(pl, rp, n, orc.owner_count(m, ranks, g))
+        off += rp["row_cnt"]
+    assert off == m
+    assert pl["q_batch"] == min(32768, max(1, orc.owner_count(m, ranks, 0)))
+    # one rank cannot shard query rows: the flag is ignored
+    assert pkg.plan(m, n, dk, dv, SDPA_F_PLAN_QROWS, 1)["qrows"] == 0
+
+
+def test_metric_shape_schedule_is_the_documented_one(pkg):
+    """chunks of 4096, 4096, 8192, 16384, ... keys, 4 row pieces of 8192 rows"""
+    pl = pkg.plan(32768, 65536, 128, 128)
+    rp = pl["r"][0]
+    assert [c[1] for c in rp["chunks"]] == [4096, 4096, 8192, 16384, 16384, 16384]
+    assert pl["row_pieces"] == 4 and rp["piece_rows"] == 8192 and pl["q_batches"] == 1
+    # config 4: four Q batches over the same K/V schedule
+    assert pkg.plan(131072, 65536, 128, 128)["q_batches"] == 4
+    # config 3 on 8 ranks: each rank's 32768 keys
+    p8 = pkg.plan(32768, 262144, 128, 128, 0, 8)
+    assert all([c[1] for c in r["chunks"]] == [4096, 4096, 8192, 16384] for r in p8["r"])
+
+
+def test_knobs(pkg, monkeypatch):
+    base = pkg.plan(100000, 100000, 128, 128)
+    assert base["q_batch"] == 32768 and base["q_batches"] == 4
+    monkeypatch.setenv("SDPA_QBATCH", "10000")
+    assert pkg.plan(100000, 100000, 128, 128)["q_batches"] == 10
+    monkeypatch.delenv("SDPA_QBATCH")
+    monkeypatch.setenv("SDPA_KV_CHUNK_MIN", "8192")
+    monkeypatch.setenv("SDPA_KV_CHUNK_MAX", "8192")
+    ch = pkg.plan(32768, 65536, 128, 128)["r"][0]["chunks"]
+    assert [c[1] for c in ch] == [8192] * 8
+    monkeypatch.setenv("SDPA_KV_CHUNK_MIN", "5000")          # rounded down to a multiple of 1024
+    monkeypatch.setenv("SDPA_KV_CHUNK_MAX", "5000")
+    assert [c[1] for c in pkg.plan(32768, 65536, 128, 128)["r"][0]["chunks"]][:3] == [4096] * 3
+    monkeypatch.delenv("SDPA_KV_CHUNK_MIN"); monkeypatch.delenv("SDPA_KV_CHUNK_MAX")
+    monkeypatch.setenv("SDPA_ROW_PIECES", "1")
+    assert pkg.plan(32768, 65536, 128, 128)["r"][0]["piece_rows"] == 32768
+    monkeypatch.delenv("SDPA_ROW_PIECES")
+    # SDPA_F_NO_PIPELINE: one batch, one chunk, no pieces (the round-1 structure)
+    pl = pkg.plan(100000, 100000, 128, 128, SDPA_F_NO_PIPELINE)
+    assert pl["q_batches"] == 1 and pl["q_batch"] == 100000 and len(pl["r"][0]["chunks"]) == 1 and pl["row_pieces"] == 1
+    # the environment selects plan / merge / precision like the flags do
+    monkeypatch.setenv("SDPA_PLAN", "qrows"); monkeypatch.setenv("SDPA_PRECISION", "bf16")
+    pl = pkg.plan(1000, 1000, 64, 64, 0, 4)
+    assert pl["qrows"] == 1 and pl["bf16"] == 1
+    monkeypatch.delenv("SDPA_PLAN")
+    monkeypatch.setenv("SDPA_MERGE", "allreduce")
+    assert pkg.plan(1000, 1000, 64, 64, 0, 4)["merge_allreduce"] == 1
+    assert pkg.plan(1000, 1000, 64, 64, SDPA_F_MERGE_ALLREDUCE, 4)["merge_allreduce"] == 1
+
+
+def test_describe_rejects_bad_arguments(pkg):
+    import ctypes
+    lib = pkg.load()
+    buf = ctypes.create_string_buffer(8)
+    assert lib.sdpa_plan_describe(10, 10, 4, 4, 0, 1, buf, len(buf)) < 0          # buffer too small
+    big = ctypes.create_string_buffer(1 << 16)
+    assert lib.sdpa_plan_describe(10, 10, 4, 4, 0, 0, big, len(big)) < 0          # ranks out of range
+    assert lib.sdpa_plan_describe(10, 10, 4, 4, 0, 17, big, len(big)) < 0
+    assert lib.sdpa_plan_describe(10, 10, 0, 4, 0, 1, big, len(big)) < 0
+    assert lib.sdpa_plan_describe(0, 0, 4, 4, 0, 2, big, len(big)) == 0            # empty problem: empty plan
