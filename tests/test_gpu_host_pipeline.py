@@ -79,6 +79,9 @@ def test_kv_chunk_streaming_matches_oracle(m, n, dk, dv, dist, prec, engine, orc
     t = pkg.last_timing()
     assert t["kv_chunks"] >= 3 and t["q_batches"] == 1, t
     assert t["fused_launches"] == t["kv_chunks"] - 2 + 2 * n_pieces(m), t      # first and last chunk in row pieces
+    # what ran is what the GPU-free planner (tests/test_host_plan.py) says would run
+    pl = pkg.plan(m, n, dk, dv, 2 if prec == "bf16" else 0, 1)
+    assert t["kv_chunks"] == len(pl["r"][0]["chunks"]) and t["q_batches"] == pl["q_batches"]
     check(got, want, V, "streamed", tol)
     # same problem, nothing streamed and nothing cut in pieces: must agree to rounding
     got1 = pkg.attention(Q, K, V, flags=1, precision=prec)      # SDPA_F_NO_PIPELINE
