@@ -950,9 +950,6 @@ struct DuoCfg {
 #ifndef SDPA_DUO_PIN_IN_LOOP
 #define SDPA_DUO_PIN_IN_LOOP 1
 #endif
-#ifndef SDPA_DUO_SCALAR_CLAMP
-#define SDPA_DUO_SCALAR_CLAMP 0
-#endif
 
 
 #define DUO_PIN_O() do { if constexpr (SDPA_DUO_PIN_IN_LOOP) pin_o(); } while (0)
@@ -1062,13 +1059,6 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
                      : "memory" SDPA_M0_CLOBBER);
     };
     const unsigned klane = (unsigned)((lane / KCH) * DK * 2 + (((lane % KCH) ^ ((lane / KCH) & SWZ)) << 4));
-#if SDPA_DUO_SCALAR_CLAMP
-    unsigned kfull[KPW <= 2 ? KPW : 1];
-    if constexpr (KPW <= 2) {
-#pragma unroll
-        for (int j = 0; j < KPW; ++j) kfull[j] = klane ^ (unsigned)((((wave * KPW + j) * RPP) & SWZ) << 4);
-    }
-#endif
     auto dma_k_piece = [&](int tile, int buf, int j) __attribute__((always_inline)) {
         const int base = kv_begin + tile * kKvTile;
         const int last = kv_end - 1 - base;
@@ -1076,24 +1066,14 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
         const int row0 = (wave * KPW + j) * RPP;                  // wave-uniform, a multiple of RPP:
         const unsigned swz = (unsigned)((row0 & SWZ) << 4);       // (row0 + x) & SWZ == (row0 & SWZ) ^ x
         const unsigned dst = lds_base + (unsigned)(buf * KTILE * 2 + (wave * KPW + j) * 1024);
-#if SDPA_DUO_SCALAR_CLAMP       // tools/build_variant.sh, TIMING ONLY (wrong on a ragged last tile): no per-lane clamp
-        const int over = max(row0 + RPP - 1 - last, 0);
-        const char *src = kb + (ptrdiff_t)(row0 - over) * (DK * 2);
-        if constexpr (KPW <= 2) {
-            dma_piece(src, kfull[j], dst);
-        } else {
-            unsigned off;
-            asm volatile("v_xor_b32 %0, %1, %2" : "=v"(off) : "s"(swz), "v"(klane));
-            dma_piece(src, off, dst);
-        }
-#else
         // rows past the shard's end (only the last tile has any) re-read its last row: finite data,
-        // their scores are masked
+        // their scores are masked.  (A scalar-only variant -- whole pieces moved back by a pointer fix, no
+        // per-lane clamp -- cannot keep the valid rows of a straddling piece in place, and timed the same
+        // on full tiles: profiles/r02/bf16_scalar_clamp_ab.log.)
         unsigned off;                                             // volatile: not hoisted into KPW live registers
         asm volatile("v_xor_b32 %0, %1, %2" : "=v"(off) : "s"(swz), "v"(klane));
         const unsigned row = (unsigned)min(row0 + (int)(lane / KCH), last);
         dma_piece(kb, row * (DK * 2) + (off % (DK * 2)), dst);
-#endif
     };
     const unsigned vlane = (unsigned)((size_t)(lane >> 2) * a.ldvt * 2u) + (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
     auto dma_v_piece = [&](int tile, int buf, int j) __attribute__((always_inline)) {
