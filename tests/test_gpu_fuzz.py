@@ -103,3 +103,44 @@ def test_fuzz_host_boundary(prec, pkg, orc, O, monkeypatch):
         assert got.shape == want.shape and np.isfinite(got).all(), (m, n, dk, dv, dist, prec, knobs)
         rel = np.abs(got - want).max() / tol
         assert rel <= 1.0, "case %d %s %s: err/tol = %.3f" % (it, (m, n, dk, dv, dist, prec), knobs, rel)
+
+
+def test_fuzz_loopback_ranks(pkg, orc, O, monkeypatch):
+    """the C host's P > 1 pipeline on loopback ranks (SDPA_VIRTUAL_GPUS): random P, plan, merge, precision,
+    shapes with n < P (empty shards) and ragged batches"""
+    assert torch.cuda.is_available()
+    rng = np.random.default_rng(31337)
+    knob_names = ("SDPA_VIRTUAL_GPUS", "SDPA_QBATCH", "SDPA_KV_CHUNK_MIN", "SDPA_KV_CHUNK_MAX", "SDPA_ROW_PIECES",
+                  "SDPA_PIECE_MIN_ROWS")
+    try:
+        for it in range(max(8, CASES // 4)):
+            P = int(rng.choice([2, 3, 4, 5, 8, 16]))
+            prec = "bf16" if it % 3 == 2 else None
+            m, n, dk, dv = draw_shape(rng, prec == "bf16", it)
+            if it % 2 == 0 and dk * dv <= 256 * 256:
+                n = int(rng.choice([P - 1, P, P + 1, 700, 3000, 5000]))
+            n = max(1, n)
+            plan = "qrows" if it % 5 == 4 else None
+            merge = "allreduce" if it % 2 else None
+            knobs = {"SDPA_VIRTUAL_GPUS": P, "SDPA_QBATCH": int(rng.choice([64, 192, 32768])),
+                     "SDPA_KV_CHUNK_MIN": 1024, "SDPA_KV_CHUNK_MAX": int(rng.choice([1024, 4096])),
+                     "SDPA_ROW_PIECES": int(rng.choice([1, 4])), "SDPA_PIECE_MIN_ROWS": 128}
+            pkg.shutdown()
+            for k, v in knobs.items():
+                monkeypatch.setenv(k, str(v))
+            pkg.init(1)
+            dist = ["D1", "D2", "D4"][int(rng.integers(0, 3))]
+            Q, K, V = O.make_inputs(m, n, dk, dv, dist, seed=12000 + it)
+            got = pkg.attention(Q, K, V, precision=prec, plan=plan, merge=merge)
+            t = pkg.last_timing()
+            assert t["n_gpus"] == P and t["virtual_ranks"] == 1, t
+            want = O.numpy_attention_f64(Q, K, V)
+            tol = bf16_tol(V) if prec else fp32_tol(V)
+            assert np.isfinite(got).all(), (P, m, n, dk, dv, dist, prec, plan, merge)
+            rel = np.abs(got - want).max() / tol
+            assert rel <= 1.0, "case %d P=%d %s %s/%s: err/tol = %.3f" % (it, P, (m, n, dk, dv, dist, prec), plan, merge, rel)
+    finally:
+        pkg.shutdown()
+        for k in knob_names:
+            monkeypatch.delenv(k, raising=False)
+        pkg.init(1)
