@@ -1282,7 +1282,7 @@ __global__ __launch_bounds__(256, 1) void fused_dksplit_q_kernel(
 // triples of one GPU.  One thread per (row, 4 columns).
 // ---------------------------------------------------------------------------
 __global__ void split_merge_kernel(PartialArgs a) {
-    const int c4n = a.ws_ld / 4;
+    const int c4n = (a.dv + 3) / 4;            // real columns only: contrib's rows may be narrower than the slots'
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)a.m * c4n) return;
     const int row = (int)(idx / c4n), c4 = (int)(idx % c4n);
@@ -1424,14 +1424,14 @@ int pick_kv_splits(int m, int n_local, int dk, int dv) {
 size_t workspace_bytes(int m, int n_local, int dk, int dv) {
     const int s = pick_kv_splits(m, n_local, dk, dv);
     if (s <= 1) return 0;
-    const size_t ws_ld = (size_t)((dv + 3) / 4) * 4;
+    const size_t ws_ld = (size_t)dense_ld(dv);         // the padded kernels write whole 64/128/256-column rows
     return (size_t)s * (size_t)m * (ws_ld + 2) * sizeof(float);
 }
 
 hipError_t launch_split_merge(const PartialArgs &a_in, hipStream_t s) {
     PartialArgs a = a_in;
     if (a.ws_rows <= 0) a.ws_rows = a.m;
-    const long work = (long)a.m * (a.ws_ld / 4);
+    const long work = (long)a.m * ((a.dv + 3) / 4);
     hipLaunchKernelGGL(split_merge_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
@@ -1550,13 +1550,19 @@ hipError_t launch_shard_partial(const PartialArgs &a_in, hipStream_t s) {
 #else
     a.tune = 0;
 #endif
-    // dense 64/128/256-wide operands take the software-pipelined LDS-DMA kernel ($SDPA_TUNE&4: off)
-    const bool dense = a.ldq == a.dk && a.ldk == a.dk && a.ldv == a.dv && a.ldo % 4 == 0 &&
+    // Operand images whose rows are 64 / 128 / 256 floats wide (dims padded with zero columns, the
+    // header's contract for columns [dk, ld)) take the software-pipelined LDS-DMA kernel of that width:
+    // same padded MFMA work as the any-shape kernels, at the pipelined kernel's rate.  The softmax
+    // scale is 1/sqrt of the TRUE dk; contrib rows must hold the padded width ($SDPA_TUNE&4: off).
+    const int kp = a.ldq, vp = a.ldv;
+    const bool dense = a.ldq == a.ldk && (kp == 64 || kp == 128 || kp == 256) && kp >= a.dk &&
+                       (vp == 64 || vp == 128 || vp == 256) && vp >= a.dv && a.ldo >= vp && a.ldo % 4 == 0 &&
+                       (a.kv_splits <= 1 || a.ws_ld >= vp) &&
                        (reinterpret_cast<uintptr_t>(a.K) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.V) & 15) == 0;
     if (dense && !(a.tune & 4)) {       // one wave per SIMD: Q (128 VGPRs at dk = 256) and O^T (128 AGPRs at dv = 256) resident
-        if (a.dk == 256 && a.dv == 256) return launch_pipelined<256, 256>(a, s);
-        if (a.dk == 256 && a.dv == 128) return launch_pipelined<256, 128>(a, s);
-        if (a.dk == 128 && a.dv == 256) return launch_pipelined<128, 256>(a, s);
+        if (kp == 256 && vp == 256) return launch_pipelined<256, 256>(a, s);
+        if (kp == 256 && vp == 128) return launch_pipelined<256, 128>(a, s);
+        if (kp == 128 && vp == 256) return launch_pipelined<128, 256>(a, s);
     }
     if (uses_dksplit(a.dk, a.dv) && !(a.tune & 8)) {   // $SDPA_TUNE&8: the kernels it replaced
         if (a.dk > 512 && a.dk <= 768) {     // 192-wide dk slices, ONE query block per workgroup
@@ -1601,7 +1607,7 @@ hipError_t launch_shard_partial(const PartialArgs &a_in, hipStream_t s) {
         return hipGetLastError();
     }
     if (dense && !(a.tune & 4)) {
-        if (a.dk == 128 && a.dv == 128) {
+        if (kp == 128 && vp == 128) {
 #ifdef SDPA_ABLATIONS
             switch ((a.tune >> 4) & 7) {     // timing-only ablations, see fused_pipelined_kernel
                 case 1: return launch_pipelined<128, 128, 1>(a, s);
@@ -1614,12 +1620,12 @@ hipError_t launch_shard_partial(const PartialArgs &a_in, hipStream_t s) {
 #endif
             return launch_pipelined<128, 128>(a, s);
         }
-        if (a.dk == 64 && a.dv == 64) return launch_pipelined<64, 64>(a, s);
-        if (a.dk == 128 && a.dv == 64) return launch_pipelined<128, 64>(a, s);
-        if (a.dk == 64 && a.dv == 128) return launch_pipelined<64, 128>(a, s);
+        if (kp == 64 && vp == 64) return launch_pipelined<64, 64>(a, s);
+        if (kp == 128 && vp == 64) return launch_pipelined<128, 64>(a, s);
+        if (kp == 64 && vp == 128) return launch_pipelined<64, 128>(a, s);
     }
-    const int kp = pad_dim(a.dk), vp = dv_chunk(a.dv);
-#define SDPA_CASE(KP, VP) if (kp == KP && vp == VP) return launch_fast<KP, VP>(a, s);
+    const int kpad = pad_dim(a.dk), vchunk = dv_chunk(a.dv);
+#define SDPA_CASE(KP, VP) if (kpad == KP && vchunk == VP) return launch_fast<KP, VP>(a, s);
     SDPA_CASE(256, 128) SDPA_CASE(256, 64) SDPA_CASE(256, 32)
     SDPA_CASE(128, 128) SDPA_CASE(128, 64) SDPA_CASE(128, 32)
     SDPA_CASE(64, 128)  SDPA_CASE(64, 64)  SDPA_CASE(64, 32)

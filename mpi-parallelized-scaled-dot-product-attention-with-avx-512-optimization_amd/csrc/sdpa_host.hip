@@ -275,8 +275,11 @@ void make_plan(Plan &pl, int m, int n, int dk, int dv, int flags, int ranks = 0)
         pl.ldv = 0;
         pl.q_elem = pl.kv_elem = sizeof(unsigned short);
     } else {
-        pl.ldq = pl.ldk = round4(dk);
-        pl.ldv = round4(dv);
+        // head dims in (32, 256] are padded to 64 / 128 / 256 columns: every such shape then runs the
+        // pipelined LDS-DMA kernel (sdpa_internal.h: dense_ld)
+        pl.ldq = pl.ldk = sdpa::dense_ld(dk);
+        pl.ldv = sdpa::dense_ld(dv);
+        pl.ldo = std::max(pl.ldo, pl.ldv);
         pl.q_elem = pl.kv_elem = sizeof(float);
     }
 

@@ -18,6 +18,10 @@ constexpr int kQRowsPerBlock = 128;   // 4 waves x 32 query rows
 constexpr int kKvTile        = 32;    // K/V rows per LDS tile
 constexpr int kMaxFastDim    = 128;   // dk, dv <= 128: one dv chunk, two workgroups per CU
 constexpr int kMaxMfmaDk     = 256;   // dk <= 256 takes an MFMA kernel (any dv, 128-column chunks)
+// Leading dimension the fp32 operand images and the contrib rows are best given: head dims in (32, 256]
+// padded (with zero columns) to 64 / 128 / 256, so that they take the LDS-DMA pipelined kernel whatever
+// the dims are -- it does the padded MFMA work the any-shape kernels do as well, at its own rate.
+inline int dense_ld(int d) { return d <= 32 ? (d + 3) / 4 * 4 : d <= 64 ? 64 : d <= 128 ? 128 : d <= 256 ? 256 : (d + 3) / 4 * 4; }
 constexpr int kMaxDkSplit    = 1024;  // 256 < dk <= 1024: the dk-split MFMA kernel (waves split dk and dv)
 
 struct PartialArgs {

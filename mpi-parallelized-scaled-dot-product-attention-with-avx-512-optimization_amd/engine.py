@@ -34,6 +34,16 @@ def round4(x):
     return (x + 3) // 4 * 4
 
 
+def dense_ld(d):
+    """leading dimension of an fp32 operand image: head dims in (32, 256] padded (zero columns) to
+    64 / 128 / 256, the widths of the pipelined LDS-DMA kernel (csrc/sdpa_internal.h: dense_ld)"""
+    return round4(d) if d <= 32 or d > 256 else 64 if d <= 64 else 128 if d <= 128 else 256
+
+
+def _ld(be, d):
+    return be.image_ld(d) if hasattr(be, "image_ld") else round4(d)
+
+
 def owner_count(n, size, rank):
     """attention-mpi.c:19-22."""
     return _lib.load().sdpa_owner_count(n, size, rank)
@@ -125,10 +135,13 @@ class HipBackend:
     def empty(self, shape, dtype):
         return torch.empty(shape, dtype=dtype, device=self.device)
 
+    def image_ld(self, d):
+        return dense_ld(d)
+
     def cvt_d2f(self, x64):
-        """cvt_d2f_avx512 (attention-mpi.c:31-64): [rows, cols] f64 -> [rows, round4(cols)] f32."""
+        """cvt_d2f_avx512 (attention-mpi.c:31-64): [rows, cols] f64 -> [rows, dense_ld(cols)] f32, pad columns zero."""
         rows, cols = x64.shape
-        ld = round4(cols)
+        ld = dense_ld(cols)
         out = self.empty((rows, ld), torch.float32)
         if rows:
             assert x64.is_contiguous() and x64.dtype == torch.float64
@@ -151,7 +164,7 @@ class HipBackend:
         """online_softmax_attention (attention-mpi.c:168-189) for every row of Qf against one shard."""
         m = Qf.shape[0]
         n_local = Kf.shape[0]
-        ldo = round4(dv)
+        ldo = max(round4(dv), Vf.shape[1])          # rows as wide as the V image's (the padded kernels write them whole)
         contrib = self.empty((m, ldo), torch.float32)
         lmax = self.empty((m,), torch.float32)
         lsum = self.empty((m,), torch.float32)
@@ -290,8 +303,8 @@ class ShardedAttention:
         assert self.precision == "f32", "the root-scatter path distributes fp32 shards"
 
         cmax = owner_count(n, self.world, 0)             # rank 0 owns the largest shard
-        shard_k = be.empty((cmax, round4(dk)), torch.float32)
-        shard_v = be.empty((cmax, round4(dv)), torch.float32)
+        shard_k = be.empty((cmax, _ld(be, dk)), torch.float32)
+        shard_v = be.empty((cmax, _ld(be, dv)), torch.float32)
         lists = (None, None)
         if self.rank == self.root:
             Kf = be.cvt_d2f(be.to_device(K64, torch.float64).contiguous())
@@ -299,8 +312,8 @@ class ShardedAttention:
             lk, lv = [], []
             for r in range(self.world):
                 c, d = owner_count(n, self.world, r), owner_disp(n, self.world, r)
-                pk = be.empty((cmax, round4(dk)), torch.float32).zero_()
-                pv = be.empty((cmax, round4(dv)), torch.float32).zero_()
+                pk = be.empty((cmax, _ld(be, dk)), torch.float32).zero_()
+                pv = be.empty((cmax, _ld(be, dv)), torch.float32).zero_()
                 pk[:c] = Kf[d:d + c]
                 pv[:c] = Vf[d:d + c]
                 lk.append(pk)
@@ -464,7 +477,7 @@ def attention_mpi(Q, K, V, m, n, dk, dv, rank, world, dist=None, group=None, bac
         if rank == root:
             qf = be.cvt_d2f(be.to_device(Q64[i0:i0 + bs], torch.float64).contiguous())
         else:
-            qf = be.empty((bs, round4(dk)), torch.float32)
+            qf = be.empty((bs, _ld(be, dk)), torch.float32)
         w = dist.broadcast(qf, src=root, group=group, async_op=True) if world > 1 else None
         return qf, w
 

@@ -248,8 +248,9 @@ def test_cvt_d2f_is_round_to_nearest_even_and_pads_zero(be):
     x[0, 0] = 1.0 + 2.0 ** -24            # exactly halfway between two floats -> even
     x[0, 1] = 1.0 + 2.0 ** -24 + 2.0 ** -40
     y = be.cvt_d2f(x)
-    assert y.shape == (37, 72)
+    assert y.shape == (37, 128)           # head dims in (32, 256] are padded to 64 / 128 / 256 zero-filled columns
     assert torch.equal(y[:, :70], x.to(torch.float32)) and torch.all(y[:, 70:] == 0)
+    assert be.cvt_d2f(x[:, :30].contiguous()).shape == (37, 32) and be.cvt_d2f(torch.zeros(3, 300, dtype=torch.float64, device="cuda")).shape == (3, 300)
     assert y[0, 0].item() == 1.0 and y[0, 1].item() > 1.0
     z = be.cvt_f2d(y, 70)
     assert torch.equal(z, y[:, :70].to(torch.float64))
