@@ -181,6 +181,12 @@ SDPA_API int sdpa_owner_disp(int n, int size, int rank);
  * sdpa_dev_shard_partial_f32 must be zero (sdpa_dev_cvt_d2f writes them so).
  * Operand base pointers must be 16-byte aligned (SDPA_EINVAL otherwise).        */
 
+/* The leading dimension to give the fp32 images of a matrix with d columns (and the contrib rows
+ * of a dv-column result): d in (32, 256] padded to 64 / 128 / 256, otherwise d rounded up to 4.
+ * Images of those widths run the LDS-DMA pipelined kernels whatever the head dims are; any other
+ * ld >= d (multiple of 4, pad columns zero) is accepted and takes the any-shape kernels.        */
+SDPA_API int sdpa_dev_dense_ld(int d);
+
 /* fp64 -> fp32, round-to-nearest-even; dst[r*ld + c], pad columns zeroed.
  * Replaces cvt_d2f_avx512 (attention-mpi.c:31-64).                           */
 SDPA_API int sdpa_dev_cvt_d2f(const double *src, float *dst, long rows, int cols,

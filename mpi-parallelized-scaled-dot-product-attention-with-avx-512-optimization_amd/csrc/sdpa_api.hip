@@ -121,6 +121,8 @@ int sdpa_dev_shard_partial_f32(const float *Qf, int ldq, const float *Kf, int ld
     return SDPA_OK;
 }
 
+int sdpa_dev_dense_ld(int d) { return d < 1 ? 0 : sdpa::dense_ld(d); }
+
 int sdpa_dev_merge_rescale(float *contrib, int ldo, float *lsum, const float *lmax, const float *gmax,
                            int m, int dv, void *stream) {
     if (!contrib || !lsum || !lmax || !gmax || m <= 0 || dv <= 0 || check_ld(ldo, dv)) return SDPA_EINVAL;

@@ -37,6 +37,18 @@ def test_owner_partition_matches_oracle(n, size, pkg, orc):
         assert pkg.owner_disp(n, size, r) == orc.owner_disp(n, size, r)
 
 
+def test_dense_ld_python_and_c_agree(pkg):
+    """leading dimension of the fp32 operand images: (32, 256] padded to 64 / 128 / 256, else rounded to 4"""
+    lib = pkg.load()
+    from importlib import import_module
+    eng = import_module(pkg.__name__ + ".engine")
+    for d in range(1, 700):
+        assert lib.sdpa_dev_dense_ld(d) == eng.dense_ld(d) >= d and eng.dense_ld(d) % 4 == 0
+    assert [lib.sdpa_dev_dense_ld(d) for d in (1, 32, 33, 64, 65, 100, 128, 129, 256, 257)] == \
+        [4, 32, 64, 64, 128, 128, 128, 256, 256, 260]
+    assert lib.sdpa_dev_dense_ld(0) == 0
+
+
 def test_bf16_image_geometry_helpers(pkg):
     """host-side layout contract of the bf16 operand images (include/sdpa_hip.h): padded leading
     dimensions, the key order of a Vt row, the workspace of the wide (dv > 256) kernel"""
