@@ -981,6 +981,10 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
         }
         HIP_TRY(hipSetDevice(root.dev));
         HIP_TRY(hipStreamWaitEvent(root.s_out, root.ev_run[s], 0));
+        if (!result_pinned) {            // (one rank with forced collectives: the rows leave here, not in finish_rows)
+            pin_stage(3);
+            result_pinned = true;
+        }
         HIP_TRY(hipMemcpyAsync(result + (size_t)i0 * dv, root.out64[s].p, (size_t)bs * dv * sizeof(double),
                                hipMemcpyDeviceToHost, root.s_out));
         HIP_TRY(hipEventRecord(root.ev_out[s], root.s_out));
