@@ -29,6 +29,7 @@
  *                      sdpa_host_alloc when the engine is created before the read -- the file
  *                      format and the reader's error behaviour stay attention.c:84-121)
  */
+#define _POSIX_C_SOURCE 200809L   /* clock_gettime under -std=c11 */
 #include "sdpa_cli.h"
 
 /* ---- the drop-in boundary ------------------------------------------------ */

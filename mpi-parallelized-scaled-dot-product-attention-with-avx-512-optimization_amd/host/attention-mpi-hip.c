@@ -21,6 +21,7 @@
  * Built by mpicc (gcc underneath); sees nothing but the C header.  Environment as
  * attention-hip.c (SDPA_GPUS, SDPA_PLAN, SDPA_MERGE, SDPA_VERBOSE, SDPA_TIME_INIT, SDPA_PINNED_IO).
  */
+#define _POSIX_C_SOURCE 200809L   /* clock_gettime under -std=c11 */
 #include <mpi.h>
 
 #include "sdpa_cli.h"
