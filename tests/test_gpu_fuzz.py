@@ -144,3 +144,24 @@ def test_fuzz_loopback_ranks(pkg, orc, O, monkeypatch):
         for k in knob_names:
             monkeypatch.delenv(k, raising=False)
         pkg.init(1)
+
+
+@pytest.mark.parametrize("prec", [None, "bf16"])
+@pytest.mark.parametrize("shape", [(300, 1000, 128, 128), (260, 700, 256, 256), (130, 5000, 64, 64), (140, 900, 100, 72),
+                                   (70, 600, 512, 512)])
+def test_nan_in_one_query_row_stays_in_that_row(prec, shape, pkg, be, O):
+    """a NaN in Q poisons exactly its own output row (as in attention.c:28-75, rows are independent):
+    no other row of the workgroup, wave or redo block may change, nothing hangs"""
+    m, n, dk, dv = shape
+    Q, K, V = O.make_inputs(m, n, dk, dv, "D2", seed=m + dk)
+    bad = [3, m - 1] if m > 130 else [3]
+    Qn = Q.copy()
+    Qn[bad, 0] = np.nan
+    tol = bf16_tol(V) if prec else fp32_tol(V)
+    want = O.numpy_attention_f64(Q, K, V)
+    for got in (dev_attention(pkg, be, Qn, K, V, prec), pkg.attention(Qn, K, V, precision=prec)):
+        assert np.isnan(got[bad]).all()
+        good = np.ones(m, dtype=bool)
+        good[bad] = False
+        assert np.isfinite(got[good]).all()
+        assert np.abs(got[good] - want[good]).max() <= tol
