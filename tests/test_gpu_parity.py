@@ -149,6 +149,8 @@ SHAPES = [
     (129,  700, 600, 300, "D1"),      # same, ragged dk (the last wave's slice mostly padding), 64-col dv slices
     (33,  2055, 1000, 1000, "D3"),    # same, dv > 512 -> two chunks, peaky, in-GPU splits
     (20,    70, 1100, 48, "D2"),      # dk > 1024: VALU any-shape kernel
+    (40,   300, 100, 1500, "D2"),     # dv > 1024: twelve 128-column chunks (any dv while dk <= 1024)
+    (70,   200, 600, 2100, "D1"),     # same on the one-block dk-split kernel: five 512-column chunks
     (300, 1000, 256, 256, "D2"),      # dense 256-wide: pipelined kernel, one wave per SIMD, ragged last tile
     (129, 2055, 256, 128, "D3"),      # same kernel family, dk = 256 / dv = 128, peaky
     (257,  700, 128, 256, "D4"),      # dk = 128 / dv = 256, late spike key
@@ -166,6 +168,17 @@ def test_shapes_device_level(m, n, dk, dv, dist, pkg, be, orc, O):
 def test_shapes_host_level(m, n, dk, dv, dist, pkg, orc, O):
     Q, K, V = O.make_inputs(m, n, dk, dv, dist, seed=m + n)
     check(pkg.attention(Q, K, V), orc.attention_f64(Q, K, V), V, "host level")
+
+
+def test_dv_beyond_1024_host_level(pkg, orc, O):
+    """the reference takes any dv; here the MFMA kernels chunk the value columns, so any dv works while
+    dk <= 1024 (only the VALU any-shape kernel, dk > 1024, is limited to 1024 columns: SDPA_EUNSUP)"""
+    Q, K, V = O.make_inputs(50, 3000, 128, 1300, "D2", seed=8)
+    check(pkg.attention(Q, K, V), orc.attention_f64(Q, K, V), V, "dv = 1300, streamed")
+    Q, K, V = O.make_inputs(8, 40, 1100, 1500, "D1", seed=9)
+    with pytest.raises(pkg.SdpaError) as e:
+        pkg.attention(Q, K, V)
+    assert e.value.code == pkg._lib.SDPA_EUNSUP
 
 
 def test_host_level_q_pipeline_batches(pkg, orc, O, monkeypatch):
