@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 CASES = int(os.environ.get("SDPA_FUZZ_CASES", "60"))
 DK = [1, 3, 16, 31, 32, 33, 63, 64, 65, 96, 127, 128, 129, 192, 255, 256, 257, 300, 383, 384, 385, 500, 512,
       513, 600, 768, 769, 1000, 1024, 1025, 1100]
-DV = [1, 5, 31, 32, 33, 64, 65, 100, 128, 129, 200, 256, 257, 384, 512, 513, 700, 1024]
+DV = [1, 5, 31, 32, 33, 64, 65, 100, 128, 129, 200, 256, 257, 384, 512, 513, 700, 1024, 1500]
 DENSE = [64, 128, 256]
 
 
@@ -32,7 +32,7 @@ def draw_shape(rng, bf16, it):
         dv = int(rng.choice(DENSE + ([512] if bf16 else [])))
     else:
         dk = int(rng.choice([d for d in DK if not bf16 or d <= 512]))
-        dv = int(rng.choice([d for d in DV if not bf16 or d <= 1024]))
+        dv = int(rng.choice([d for d in DV if d <= 1024 or (not bf16 and dk <= 1024)]))   # wider only on the MFMA kernels
     m = int(rng.choice([1, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 511, 513, 700]))
     big = dk * dv > 300 * 300
     n = int(rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 100, 255, 256, 257, 1000] +
