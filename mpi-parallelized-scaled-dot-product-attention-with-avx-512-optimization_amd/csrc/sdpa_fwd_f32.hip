@@ -46,6 +46,7 @@
 #include "sdpa_internal.h"
 
 #include <math.h>
+#include <algorithm>
 #include <stdlib.h>
 
 #include <stdint.h>
@@ -1599,12 +1600,21 @@ hipError_t launch_shard_partial(const PartialArgs &a_in, hipStream_t s) {
         }
     }
     if (a.dk > kMaxMfmaDk) {
-        if (a.dv > 64 * kGenericMaxCols) return hipErrorInvalidValue;
         const size_t lds = (size_t)4 * a.ldq * sizeof(float);
-        if (lds > 64 * 1024) return hipErrorInvalidValue;
+        if (lds > 64 * 1024) return hipErrorInvalidValue;          // dk <= 4096
         const float scale = 1.0f / sqrtf((float)a.dk);
-        hipLaunchKernelGGL(generic_partial_kernel, dim3((a.m + 3) / 4), dim3(256), lds, s, a, scale);
-        return hipGetLastError();
+        // the kernel holds 64 * kGenericMaxCols value columns per row: wider V goes in column chunks, one
+        // launch each (the scores are recomputed; lmax / lsum come out the same from every chunk)
+        for (int c0 = 0; c0 < a.dv; c0 += 64 * kGenericMaxCols) {
+            PartialArgs ac = a;
+            ac.V = a.V + c0;
+            ac.contrib = a.contrib + c0;
+            ac.dv = std::min(64 * kGenericMaxCols, a.dv - c0);
+            hipLaunchKernelGGL(generic_partial_kernel, dim3((a.m + 3) / 4), dim3(256), lds, s, ac, scale);
+            const hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
     }
     if (dense && !(a.tune & 4)) {
         if (kp == 128 && vp == 128) {

@@ -570,7 +570,7 @@ int check_shape(const void *Q, const void *K, const void *V, const void *result,
                 int dv, int flags, bool need_ptrs) {
     if (need_ptrs && (!Q || !K || !V || !result)) return SDPA_EINVAL;
     if (m <= 0 || n <= 0 || dk <= 0 || dv <= 0) return SDPA_EINVAL;
-    if (want_bf16(flags) ? (dk > 512 || dv > 1024) : (dv > 1024 && dk > sdpa::kMaxDkSplit)) return SDPA_EUNSUP;
+    if (want_bf16(flags) ? (dk > 512 || dv > 1024) : dk > 4096) return SDPA_EUNSUP;
     return SDPA_OK;
 }
 

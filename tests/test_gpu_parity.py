@@ -170,12 +170,15 @@ def test_shapes_host_level(m, n, dk, dv, dist, pkg, orc, O):
     check(pkg.attention(Q, K, V), orc.attention_f64(Q, K, V), V, "host level")
 
 
-def test_dv_beyond_1024_host_level(pkg, orc, O):
-    """the reference takes any dv; here the MFMA kernels chunk the value columns, so any dv works while
-    dk <= 1024 (only the VALU any-shape kernel, dk > 1024, is limited to 1024 columns: SDPA_EUNSUP)"""
+def test_dv_beyond_1024_host_level(pkg, be, orc, O):
+    """the reference takes any dv; here the MFMA kernels chunk the value columns, and the VALU
+    any-shape kernel (dk > 1024) is launched once per 1024 columns; only dk > 4096 is refused"""
     Q, K, V = O.make_inputs(50, 3000, 128, 1300, "D2", seed=8)
     check(pkg.attention(Q, K, V), orc.attention_f64(Q, K, V), V, "dv = 1300, streamed")
-    Q, K, V = O.make_inputs(8, 40, 1100, 1500, "D1", seed=9)
+    Q, K, V = O.make_inputs(8, 40, 1100, 2500, "D1", seed=9)
+    check(pkg.attention(Q, K, V), orc.attention_f64(Q, K, V), V, "dk = 1100, dv = 2500: three launches of the any-shape kernel")
+    check(dev_attention(pkg, be, Q, K, V), orc.attention_f64(Q, K, V), V, "same, device level")
+    Q, K, V = O.make_inputs(2, 3, 4100, 8, "D1", seed=10)
     with pytest.raises(pkg.SdpaError) as e:
         pkg.attention(Q, K, V)
     assert e.value.code == pkg._lib.SDPA_EUNSUP
