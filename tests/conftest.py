@@ -11,6 +11,13 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.dirname(os.path.abspath(__
         sys.path.insert(0, p)
 
 
+# A HIP queue error (illegal instruction, aperture violation, hardware exception) makes the runtime
+# abort() SILENTLY at its default log level; at level 1 (errors only) it names the error first, so a
+# box-specific abort explains itself in the driver's pytest log.  Must be set
+# before the runtime is loaded, i.e. before torch / libsdpa_hip.so are imported.
+os.environ.setdefault("AMD_LOG_LEVEL", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
