@@ -22,6 +22,8 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
                    on the launch stream, over the timed region) vs the 157.3 TFLOP/s f32-MFMA peak
   cpu_baseline  -- the reference's own AVX-512+MPI program (oracle/_ref, kind "reference") or the
                    oracle port, timed on this host's cores on a bounded row sample (N=1 only)
+  clock_prewarm_steps -- untimed steps run before the W warmup steps (about --prewarm-ms of GPU work)
+                   so that short steps are not timed on the core clock's ramp from idle
   parity_max_err / parity_tol -- the run certifies its own output: after the closing fence
                    (outside the timed region) 64 random rows of the LAST timed step's result are
                    compared with the fp64 restatement of attention.c:20-75 on the same inputs; the
@@ -241,6 +243,10 @@ def main():
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="single-GPU dry run of ONE rank's share of an N-rank K/V-sharded job "
                          "(K/V rows = n/N); a tuning aid, the printed line is not a benchmark result")
+    ap.add_argument("--prewarm-ms", type=float, default=60.0,
+                    help="untimed steps run BEFORE the W warmup steps until about this much GPU work has been "
+                         "issued, so that the core clock has finished ramping when the timed region starts "
+                         "(0 = off; see the DVFS note in main())")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
                     help="operand precision of the fused kernel (the headline metric is f32)")
     args = ap.parse_args()
@@ -380,6 +386,19 @@ def main():
             torch.cuda.synchronize()
 
     run = step_qrows if qrows else step
+    # DVFS: from an idle start the core clock of this part needs ~20 ms of continuous matrix work to
+    # reach its plateau -- the same fused launch (8192 x 8192, d = 128) takes 290 us at the start and
+    # 253 us from then on (profiles/r02/short_step_clock_ramp.log).  W = 3 warmup steps cover that at
+    # the metric shape on one GPU (23 ms) but not when a step is short (config 2: 1 ms of warmup; one
+    # rank's 1/8 share of the metric shape: 3.6 ms), where the whole timed region used to sit on the
+    # ramp (-10..15 %).  So a fixed number of extra UNTIMED steps goes first; the count is derived from
+    # the shape alone, so that every rank of an N-rank job runs the same number of collectives.
+    rows_est = pkg.owner_count(m, world, 0) if qrows else m
+    keys_est = n if qrows else (cnt if args.emulate_ranks > 1 else pkg.owner_count(n, world, 0))
+    est_step_ms = 4.0 * rows_est * keys_est * d / (1000e12 if args.precision == "bf16" else 120e12) * 1e3 + 0.03
+    prewarm_steps = int(min(400, np.ceil(args.prewarm_ms / est_step_ms))) if args.prewarm_ms > 0 else 0
+    for _ in range(prewarm_steps):
+        run(False)
     for _ in range(args.warmup):
         run(False)
     if not qrows:
@@ -458,6 +477,7 @@ def main():
             "value": m / (elapsed / args.steps),
             "unit": "Q-rows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "clock_prewarm_steps": prewarm_steps,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": "strong",

@@ -15,8 +15,16 @@ for (m, n, d) in [(32768, 65536, d) for d in dims] + [(8192, 8192, 128)]:
     sa.load_kv_shard_f64(K, V, n, d, d)
     qb = sa.convert_q(Q)
     del Q, K, V
+    # warm by time, not by count: from idle the core clock needs ~20 ms of matrix work to reach its
+    # plateau (profiles/r02/short_step_clock_ramp.log); WARM_MS=0 restores the old two-launch warmup
+    import time
+    warm_s = float(os.environ.get("WARM_MS", "60")) * 1e-3
     for _ in range(2): sa.batch_partial(qb)
     torch.cuda.synchronize()
+    t_w = time.perf_counter()
+    while time.perf_counter() - t_w < warm_s:
+        for _ in range(4): sa.batch_partial(qb)
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 10
     e0.record()
