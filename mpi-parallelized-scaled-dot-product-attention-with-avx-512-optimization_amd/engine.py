@@ -360,7 +360,9 @@ class ShardedAttention:
         if self.merge == "gather":
             mine = torch.stack((lmax, lsum))                              # [2, m]
             stats = be.empty((self.world if self.world > 1 else 1, 2, lmax.shape[0]), torch.float32)
-            dist.all_gather(list(stats.unbind(0)), mine, group=self.group)
+            # one ncclAllGather straight into the [world, 2, m] image (a list of output tensors would
+            # cost a staging buffer and `world` copy kernels per batch)
+            dist.all_gather_into_tensor(stats.view(-1, lmax.shape[0]), mine, group=self.group)
             be.merge_gathered(contrib, stats, self.rank if self.world > 1 else 0, self.dv)   # :342-362
             work = dist.reduce(contrib, dst=self.root, op=dist.ReduceOp.SUM, group=self.group,
                                async_op=async_reduce)                     # :380
