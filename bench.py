@@ -150,6 +150,16 @@ def kernel_source_stamp():
     return h.hexdigest()[:16]
 
 
+def prewarm_step_count(rows, keys, d, precision, prewarm_ms):
+    """untimed steps that amount to about `prewarm_ms` of GPU work: a function of the launch shape
+    only (no clock, no measurement), so that every rank of an N-rank job computes the same count and
+    issues the same number of collectives"""
+    if prewarm_ms <= 0:
+        return 0
+    est_step_ms = 4.0 * rows * keys * d / (1000e12 if precision == "bf16" else 120e12) * 1e3 + 0.03
+    return int(min(400, np.ceil(prewarm_ms / est_step_ms)))
+
+
 def parity_check(res_rows, rows, Q64, kv_shards, precision):
     """checker leg (outside the timed region): `rows` of the last step's fp64 result against the
     fp64 oracle on the same inputs.  kv_shards = [(K64, V64)] per rank, in owner order."""
@@ -395,8 +405,7 @@ def main():
     # the shape alone, so that every rank of an N-rank job runs the same number of collectives.
     rows_est = pkg.owner_count(m, world, 0) if qrows else m
     keys_est = n if qrows else (cnt if args.emulate_ranks > 1 else pkg.owner_count(n, world, 0))
-    est_step_ms = 4.0 * rows_est * keys_est * d / (1000e12 if args.precision == "bf16" else 120e12) * 1e3 + 0.03
-    prewarm_steps = int(min(400, np.ceil(args.prewarm_ms / est_step_ms))) if args.prewarm_ms > 0 else 0
+    prewarm_steps = prewarm_step_count(rows_est, keys_est, d, args.precision, args.prewarm_ms)
     for _ in range(prewarm_steps):
         run(False)
     for _ in range(args.warmup):
