@@ -10,8 +10,18 @@ pass of the hot path over the synthetic problem with the fp64 inputs already res
     [N>1: all-gather of the (lmax,lsum) pairs + one merge pass (or --merge allreduce: the reference's
      all-reduce(MAX), rescale, all-reduce(SUM), normalise), then reduce(SUM) over RCCL],
     fp32->fp64 result on the root.
-N>1 is launched by torch.distributed.run, one rank per GPU; K/V rows are sharded with
-owner_count/owner_disp, Q is replicated (resident input), total work is fixed ("strong").
+N>1 runs one rank per GPU over RCCL (torch.distributed backend "nccl").  Either the caller launches
+the ranks (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`, RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or -- like the reference, which is one
+command line at any P (README.md:137-141) -- `python bench.py --gpus N` alone: with no WORLD_SIZE in
+the environment it re-executes itself under torch.distributed.run on a free local port and passes
+rank 0's JSON line through.  Fewer than N visible GPUs is a hard failure ("N GPUs requested, k
+visible", non-zero exit, no JSON).  K/V rows are sharded with owner_count/owner_disp, Q is replicated
+(resident input), total work is fixed ("strong").
+Dev mode (never a result; the metric says DRY RUN): SDPA_BENCH_BACKEND=gloo SDPA_BENCH_SHARE_GPU=1
+puts every rank on cuda:0 and stages the collectives through host memory over gloo, so that the
+launch logic, the per-rank seeding, the cross-step reduce pipeline and the N>1 parity re-draw run
+for real on a one-GPU box (tests/test_gpu_bench_multirank.py).
 Q batches form a software pipeline that runs across steps: the RCCL reduce of a batch stays in
 flight under the converts and the fused kernel of the next one (the reference overlaps its
 MPI_Ireduce the same way, attention-mpi.c:364-380); every step's work, including the last reduce
@@ -20,6 +30,8 @@ and the fp64 writeback, finishes inside the timed region.
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   roofline      -- fused kernel: algorithmic FLOP per launch / average launch time (HIP events
                    on the launch stream, over the timed region) vs the 157.3 TFLOP/s f32-MFMA peak
+  rccl          -- what the process group reported: world size, backend, RCCL's NCCL-API version, and
+                   an all-reduce of ones that must come back as the world size (null at N=1)
   cpu_baseline  -- the reference's own AVX-512+MPI program (oracle/_ref, kind "reference") or the
                    oracle port, timed on this host's cores on a bounded row sample (N=1 only)
   clock_prewarm_steps -- untimed steps run before the W warmup steps (about --prewarm-ms of GPU work)
@@ -233,6 +245,84 @@ def boundary_timing(pkg, m, n, d, precision):
     return out
 
 
+def dry_run_mode():
+    """dev mode: ranks share cuda:0 and talk over gloo (host-staged).  Never a benchmark result."""
+    return (os.environ.get("SDPA_BENCH_BACKEND", "nccl") == "gloo",
+            os.environ.get("SDPA_BENCH_SHARE_GPU") == "1")
+
+
+def launch_command(n, port, argv):
+    """the driver's own launch line for N ranks on one node (rendezvous on 127.0.0.1)"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: run the N ranks ourselves,
+    exactly as the driver's launcher would (one process per GPU under torch.distributed.run), and
+    hand rank 0's stdout (the one JSON line) and the exit code through."""
+    import socket
+    _, share = dry_run_mode()
+    visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if visible == 0:
+        raise SystemExit("bench.py needs a GPU")
+    if visible < n and not share:
+        raise SystemExit("bench: %d GPUs requested, %d visible" % (n, visible))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this platform
+    env.setdefault("OMP_NUM_THREADS", "1")
+    sys.stdout.flush()
+    raise SystemExit(subprocess.call(launch_command(n, port, sys.argv[1:]), env=env))
+
+
+class HostStagedDist:
+    """dev mode only (SDPA_BENCH_BACKEND=gloo): torch.distributed over gloo with every payload staged
+    through host memory, so the run does not depend on which collectives gloo implements for device
+    tensors.  Synchronous; the call ORDER on every rank is what the dry run is for."""
+
+    def __init__(self, dist):
+        self._d = dist
+        self.ReduceOp = dist.ReduceOp
+
+    def all_reduce(self, t, op=None, group=None, async_op=False):
+        c = t.cpu()
+        self._d.all_reduce(c, op=op if op is not None else self._d.ReduceOp.SUM, group=group)
+        t.copy_(c)
+
+    def all_gather_into_tensor(self, out, inp, group=None, async_op=False):
+        parts = [torch.empty(inp.shape, dtype=inp.dtype) for _ in range(self._d.get_world_size())]
+        self._d.all_gather(parts, inp.cpu().contiguous(), group=group)
+        out.copy_(torch.cat(parts).reshape(out.shape))
+
+    def reduce(self, t, dst, op=None, group=None, async_op=False):
+        c = t.cpu()
+        self._d.reduce(c, dst=dst, op=op if op is not None else self._d.ReduceOp.SUM, group=group)
+        t.copy_(c)
+        return None
+
+    def gather(self, t, gather_list=None, dst=0, group=None):
+        lst = [torch.empty(t.shape, dtype=t.dtype) for _ in gather_list] if gather_list is not None else None
+        self._d.gather(t.cpu(), lst, dst=dst, group=group)
+        if gather_list is not None:
+            for o, c in zip(gather_list, lst):
+                o.copy_(c)
+
+    def barrier(self):
+        self._d.barrier()
+
+    def get_world_size(self):
+        return self._d.get_world_size()
+
+    def get_backend(self):
+        return self._d.get_backend()
+
+    def destroy_process_group(self):
+        self._d.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -261,18 +351,24 @@ def main():
                     help="operand precision of the fused kernel (the headline metric is f32)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args.gpus)                   # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run "
-                             "--nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    gloo, share_gpu = dry_run_mode()
+    dry_run = (gloo or share_gpu) and world > 1
+    visible = torch.cuda.device_count()
+    if world > visible and not share_gpu:
+        raise SystemExit("bench: %d GPUs requested, %d visible" % (world, visible))
+    dev_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
+    rccl_info = None
     # SDPA_BENCH_FORCE_DIST=1 runs the RCCL choreography even at world size 1 (a one-rank
     # communicator), to exercise the collective call path on a single-GPU box.
     force_dist = os.environ.get("SDPA_BENCH_FORCE_DIST") == "1"
@@ -286,10 +382,25 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            if gloo:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+                backend_name = dist.get_backend()
+                dist = HostStagedDist(dist)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                backend_name = dist.get_backend()
+            # the communicator exists and saw `world` ranks: an all-reduce of ones comes back as the world size
             warm = torch.ones(1, device=dev)
             dist.all_reduce(warm)
             torch.cuda.synchronize()
+            try:
+                ver = ".".join(str(x) for x in torch.cuda.nccl.version())
+            except Exception:  # noqa: BLE001
+                ver = None
+            rccl_info = {"world_size": dist.get_world_size(), "backend": backend_name,
+                         "version": None if gloo else ver, "allreduce_of_ones": float(warm.item())}
+            if rccl_info["allreduce_of_ones"] != float(world):
+                raise SystemExit("bench: all-reduce of ones over %d ranks returned %r" % (world, rccl_info["allreduce_of_ones"]))
         finally:
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
@@ -482,10 +593,13 @@ def main():
                 traffic = None
         line = {
             "metric": ("DRY RUN of 1 of %d ranks, not a result: " % args.emulate_ranks if args.emulate_ranks > 1 else "") +
+                      ("DRY RUN (%s%s), not a result: " % ("gloo, host-staged collectives" if gloo else "rccl",
+                                                          ", all ranks on cuda:0" if share_gpu else "") if dry_run else "") +
                       "Q-rows/sec, fused online-softmax attention m=%d n=%d dk=dv=%d" % (m, n, d),
             "value": m / (elapsed / args.steps),
             "unit": "Q-rows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "rccl": rccl_info,
             "clock_prewarm_steps": prewarm_steps,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,

@@ -1,5 +1,5 @@
 """CPU: what bench.py promises before it touches a GPU -- it refuses to run without one (there is no
-CPU leg that could stand in for the measured path), refuses a --gpus/WORLD_SIZE mismatch, stamps the
+CPU leg that could stand in for the measured path), refuses a --gpus/WORLD_SIZE mismatch, launches its own ranks for --gpus N (after counting GPUs), stamps the
 PMC traffic figure with the kernel sources it was measured on, and derives its untimed clock
 pre-warm from the shape alone (every rank of an N-rank job must issue the same collectives)."""
 import json
@@ -33,10 +33,57 @@ def test_bench_without_a_gpu_fails_loudly_and_prints_no_result():
 
 
 def test_bench_refuses_a_world_size_mismatch():
-    r = run(["--gpus", "2"])
-    assert r.returncode != 0 and "torch.distributed.run" in r.stderr and r.stdout == ""
     r = run(["--gpus", "1"], env={"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=4 does not match --gpus 1" in r.stderr
+
+
+@pytest.mark.skipif(HAS_GPU, reason="checks the no-GPU failure mode")
+def test_bench_gpus_n_without_a_launcher_launches_itself_and_needs_gpus():
+    """`python bench.py --gpus N` is one command line at any N (the reference: README.md:137-141): with no
+    WORLD_SIZE it starts its own ranks -- after checking that the GPUs exist.  Here there are none."""
+    r = run(["--gpus", "2"])
+    assert r.returncode != 0 and "needs a GPU" in r.stderr and r.stdout == ""
+
+
+def test_self_launch_uses_the_drivers_launch_line():
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.launch_command(8, 29611, ["--gpus", "8", "--steps", "5", "--warmup", "2"])
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29611"
+    assert cmd[-7] == BENCH and cmd[-6:] == ["--gpus", "8", "--steps", "5", "--warmup", "2"]
+
+
+def test_host_staged_gloo_adapter_world_2(tmp_path):
+    """the dev-mode collective adapter (SDPA_BENCH_BACKEND=gloo) on CPU tensors, world size 2:
+    all-gather layout [world, 2, m] as engine.batch_merge reads it, reduce to the root, all-reduce MAX"""
+    child = r'''
+import sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import bench
+rank = int(sys.argv[2])
+dist.init_process_group("gloo", init_method="file://" + sys.argv[3], rank=rank, world_size=2)
+d = bench.HostStagedDist(dist)
+mine = torch.stack((torch.full((5,), float(rank)), torch.full((5,), 10.0 + rank)))
+stats = torch.empty((2, 2, 5))
+d.all_gather_into_tensor(stats.view(-1, 5), mine)
+assert stats[0, 0, 0] == 0 and stats[0, 1, 0] == 10 and stats[1, 0, 0] == 1 and stats[1, 1, 0] == 11
+t = torch.full((3,), 1.0 + rank)
+assert d.reduce(t, dst=0, op=d.ReduceOp.SUM, async_op=True) is None
+assert rank != 0 or bool((t == 3).all())
+x = torch.tensor([float(rank)])
+d.all_reduce(x, op=d.ReduceOp.MAX)
+assert x.item() == 1.0 and d.get_world_size() == 2
+d.barrier()
+d.destroy_process_group()
+'''
+    store = str(tmp_path / "store")
+    ps = [subprocess.Popen([sys.executable, "-c", child, ROOT, str(r), store], stderr=subprocess.PIPE, text=True)
+          for r in range(2)]
+    for p in ps:
+        _, err = p.communicate(timeout=240)
+        assert p.returncode == 0, err[-1500:]
 
 
 def test_traffic_stamp_names_the_shipped_kernel_sources():
