@@ -574,6 +574,22 @@ int check_shape(const void *Q, const void *K, const void *V, const void *result,
     return SDPA_OK;
 }
 
+// What only the plan knows: the bf16 kernels carry Vt byte offsets in 32 bits and a rank's Vt image
+// spans its whole shard (ldvt = pad_n(key_cnt)), so padded dv x shard keys x 2 bytes must stay below
+// 4 GiB (dv = 1024: ~2 M keys per rank).  Refused HERE, before anything is pinned, copied or queued --
+// the launcher's own check would fire in the middle of the pipeline (sdpa_dev_shard_partial_bf16
+// refuses the same shapes at the device level).
+int check_plan(const Plan &pl) {
+    if (!pl.bf16) return SDPA_OK;
+    for (const RankPlan &rp : pl.r)
+        if ((double)sdpa::bf16_pad_dv(pl.dv) * (double)sdpa::bf16_pad_n(rp.key_cnt) * 2.0 >= 4294967296.0) {
+            fprintf(stderr, "sdpa: bf16 path: dv=%d with %d keys on one rank exceeds the kernels' 32-bit Vt offsets\n",
+                    pl.dv, rp.key_cnt);
+            return SDPA_EUNSUP;
+        }
+    return SDPA_OK;
+}
+
 void destroy_rank(Rank &g) {
     if (hipSetDevice(g.dev) != hipSuccess) return;
     (void)hipDeviceSynchronize();
@@ -728,6 +744,7 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
 
     Plan pl;
     make_plan(pl, m, n, dk, dv, flags);
+    SDPA_TRY(check_plan(pl));
     SDPA_TRY(ensure_buffers(pl));
     const int P = pl.P;
     // K/V rows a sdpa_kv_prefetch() of THIS problem already moved are not moved again; a prefetch
@@ -1047,6 +1064,16 @@ int sdpa_kv_prefetch(const double *K, const double *V, int m, int n, int dk, int
     SDPA_TRY(lazy_init());
     Plan pl;
     make_plan(pl, m, n, dk, dv, flags);
+    SDPA_TRY(check_plan(pl));
+    // the chunk layout is a function of environment knobs as well: a prefetch planned differently
+    // from this call (other SDPA_KV_CHUNK_*, SDPA_QBATCH, rank count) starts over instead of
+    // indexing its per-chunk state with the new plan's chunk numbers
+    if (PF.active && PF.matches(K, V, m, n, dk, dv, flags)) {
+        bool same = (int)PF.k_done.size() == pl.P && (int)PF.v_done.size() == pl.P;
+        for (int g = 0; same && g < pl.P; ++g)
+            same = PF.k_done[g].size() == pl.r[g].chunks.size() && PF.v_done[g].size() == pl.r[g].chunks.size();
+        if (!same) PF.reset();
+    }
     if (!PF.matches(K, V, m, n, dk, dv, flags)) {
         SDPA_TRY(ensure_buffers(pl));
         PF.reset();
@@ -1132,6 +1159,7 @@ int sdpa_prepare(int m, int n, int dk, int dv, int flags) {
     // 1. every device buffer the real call will use, at its real size
     Plan pl;
     make_plan(pl, m, n, dk, dv, flags);
+    SDPA_TRY(check_plan(pl));
     SDPA_TRY(ensure_buffers(pl));
     // 2. one small call through the same code path: loads the code objects, sets the kernel
     //    attributes, creates the timing events (the kernel variants depend on dk, dv only)

@@ -27,7 +27,11 @@ import torch
 from . import _lib
 from ._lib import SdpaError, SdpaTiming, check
 
-DEFAULT_Q_BATCH = 8192   # the reference uses B = 512 (attention-mpi.c:200); an internal constant
+# Rows per Q batch.  The reference uses B = 512 (attention-mpi.c:200), an internal constant of its
+# pipeline; here 32768 rows = 256 query blocks, which with 2 in-launch K/V splits is one full wave of
+# 512 workgroups -- the fused kernel's best shape, and the C host's default (csrc/sdpa_host.hip,
+# $SDPA_QBATCH)
+DEFAULT_Q_BATCH = 32768
 
 
 def round4(x):
@@ -301,28 +305,33 @@ class ShardedAttention:
                                    be.to_device(V64, torch.float64).contiguous(), n, dk, dv)
             return
         assert self.precision == "f32", "the root-scatter path distributes fp32 shards"
-
-        cmax = owner_count(n, self.world, 0)             # rank 0 owns the largest shard
-        shard_k = be.empty((cmax, _ld(be, dk)), torch.float32)
-        shard_v = be.empty((cmax, _ld(be, dv)), torch.float32)
-        lists = (None, None)
+        # Shard by shard (the Scatterv of :258-264 as point-to-point messages of the exact row counts):
+        # the root moves ONE shard's fp64 rows to its device, converts them, keeps its own or sends the
+        # rest -- never more than one shard of staging on the root, no padded copies.  The rows cross the
+        # root's PCIe link once; that is inherent in the reference's contract that only rank 0 holds the
+        # matrices (the C host, where every rank reads the caller's arrays itself, uses P links).
+        ldk, ldv = _ld(be, dk), _ld(be, dv)
         if self.rank == self.root:
-            Kf = be.cvt_d2f(be.to_device(K64, torch.float64).contiguous())
-            Vf = be.cvt_d2f(be.to_device(V64, torch.float64).contiguous())
-            lk, lv = [], []
+            K64 = K64 if torch.is_tensor(K64) else torch.as_tensor(K64)
+            V64 = V64 if torch.is_tensor(V64) else torch.as_tensor(V64)
             for r in range(self.world):
                 c, d = owner_count(n, self.world, r), owner_disp(n, self.world, r)
-                pk = be.empty((cmax, _ld(be, dk)), torch.float32).zero_()
-                pv = be.empty((cmax, _ld(be, dv)), torch.float32).zero_()
-                pk[:c] = Kf[d:d + c]
-                pv[:c] = Vf[d:d + c]
-                lk.append(pk)
-                lv.append(pv)
-            lists = (lk, lv)
-        self.dist.scatter(shard_k, lists[0], src=self.root, group=self.group)
-        self.dist.scatter(shard_v, lists[1], src=self.root, group=self.group)
-        self.Kf = shard_k[:cnt].contiguous()
-        self.Vf = shard_v[:cnt].contiguous()
+                if c == 0 and r != self.root:
+                    continue
+                kf = be.cvt_d2f(be.to_device(K64[d:d + c], torch.float64).contiguous())
+                vf = be.cvt_d2f(be.to_device(V64[d:d + c], torch.float64).contiguous())
+                if r == self.root:
+                    self.Kf, self.Vf = kf, vf
+                else:
+                    self.dist.send(kf, dst=r, group=self.group)
+                    self.dist.send(vf, dst=r, group=self.group)
+        else:
+            self.Kf = be.empty((cnt, ldk), torch.float32)
+            self.Vf = be.empty((cnt, ldv), torch.float32)
+            if cnt > 0:
+                self.dist.recv(self.Kf, src=self.root, group=self.group)
+                self.dist.recv(self.Vf, src=self.root, group=self.group)
+        self.n_local = cnt
 
     def load_kv_shard_f64(self, K64_local, V64_local, n, dk, dv):
         """This rank's rows of K and V are on its device in fp64 (bench: resident inputs): convert

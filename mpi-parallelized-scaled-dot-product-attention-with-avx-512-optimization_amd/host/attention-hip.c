@@ -56,6 +56,7 @@ int main(int argc, char **argv)
     if (!time_init) {
         precheck_file(argv[1]);
         die_if(sdpa_init(gpus_from_env()), "sdpa_init");
+        note_unused_gpus();
         const char *pin = getenv("SDPA_PINNED_IO");
         use_pinned = !(pin && pin[0] == '0');
         const char *pf = getenv("SDPA_CLI_PREFETCH");

@@ -26,6 +26,12 @@
 
 #include "sdpa_cli.h"
 
+/* a fatal error on rank 0 ends the whole job: ranks > 0 are blocked in the template's MPI_Reduce */
+static void abort_job(int code)
+{
+    MPI_Abort(MPI_COMM_WORLD, code);
+}
+
 /* ---- the drop-in boundary ------------------------------------------------ */
 void attention(double *Q, double *K, double *V, double *result,
                int m, int n, int dk, int dv, int mpi_rank, int mpi_size)
@@ -47,6 +53,7 @@ int main(int argc, char **argv)
     MPI_Init(&argc, &argv);
     MPI_Comm_rank(MPI_COMM_WORLD, &rank);
     MPI_Comm_size(MPI_COMM_WORLD, &size);
+    cli_fail = abort_job;
 
     const double t_start = now_ms();
     const bool verbose = getenv("SDPA_VERBOSE") != NULL;
@@ -61,6 +68,10 @@ int main(int argc, char **argv)
         if (!time_init) {
             precheck_file(argv[1]);
             die_if(sdpa_init(gpus_from_env()), "sdpa_init");
+            note_unused_gpus();
+            if (size > 1)       /* the reference would compute on every rank; here they wait */
+                fprintf(stderr, "%s: %d MPI ranks: rank 0 drives the GPU(s), ranks 1..%d only take part in the "
+                        "template's MPI_Reduce\n", cli_name, size, size - 1);
             const char *pin = getenv("SDPA_PINNED_IO");
             use_pinned = !(pin && pin[0] == '0');
         }
@@ -69,7 +80,7 @@ int main(int argc, char **argv)
         result = host_doubles((size_t)m * (size_t)dv);
         if (!result) {
             fprintf(stderr, "%s: out of memory\n", cli_name);
-            MPI_Abort(MPI_COMM_WORLD, 1);
+            cli_exit(1);
         }
         if (!time_init) die_if(sdpa_prepare(m, n, dk, dv, SDPA_F_DEFAULT), "sdpa_prepare");
     }

