@@ -112,10 +112,8 @@ int sdpa_dev_shard_partial_f32(const float *Qf, int ldq, const float *Kf, int ld
     a.kv_splits = sdpa::pick_kv_splits(m, n_local, dk, dv);
     if (a.kv_splits > 1) {
         if (!workspace || workspace_bytes < sdpa::workspace_bytes(m, n_local, dk, dv)) return SDPA_EINVAL;
-        a.ws_ld = sdpa::dense_ld(dv);
-        a.ws_contrib = (float *)workspace;
-        a.ws_lmax = a.ws_contrib + (size_t)a.kv_splits * m * a.ws_ld;
-        a.ws_lsum = a.ws_lmax + (size_t)a.kv_splits * m;
+        if (misaligned16(workspace)) return SDPA_EINVAL;
+        sdpa::carve_workspace(a, workspace, sdpa::dense_ld(dv));
     }
     HIP_TRY(sdpa::launch_shard_partial(a, (hipStream_t)stream));
     return SDPA_OK;

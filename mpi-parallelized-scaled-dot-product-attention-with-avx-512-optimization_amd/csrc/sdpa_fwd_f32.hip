@@ -47,7 +47,10 @@
 
 #include <math.h>
 #include <algorithm>
+#include <atomic>
 #include <stdlib.h>
+#include <string.h>
+#include <time.h>
 
 #include <stdint.h>
 #include <type_traits>
@@ -446,17 +449,25 @@ __global__ __launch_bounds__(256, (DK + DV > 256) ? 1 : 2) void fused_pipelined_
     }
 
     f32x16 oacc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+    // Softmax state of this lane's query row, all in the exp2 domain:
+    //   m_ref   reference exponent the accumulators are relative to (the row max when it was
+    //           last moved; NOT moved for rises below `defer` -- fp32 has the headroom)
+    //   max_rel running (true row max - m_ref) >= 0, folded back in at the epilogue
+    //   l_run   this half-wave's share of sum exp2(score - m_ref)
+    // Deferring spends up to 2^kDeferLog2 of fp32's exponent range: weights reach 2^24 instead of 1,
+    // so for |V| * n_local beyond ~2^104 the un-normalised sums overflow where the reference's eager
+    // rescale (attention-mpi.c:179-182) stays finite.  The epilogue checks: a workgroup that finds a
+    // non-finite value in its triple runs its K/V range a second time with defer = 0 (every rise of a
+    // row max moves the reference, weights <= 1: the reference's own bound) -- pass 1 below.
+    constexpr float kDeferLog2 = 24.0f;
+    float defer = kDeferLog2;
+    float m_ref, max_rel, l_run;
     auto pin_o = [&]() __attribute__((always_inline)) {
         if constexpr (WIDE) {
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) asm volatile("" : "+a"(oacc[tt]));
         }
     };
-    pin_o();
     // one link of a score chain: sx += k * q over two contraction indices
     auto score_link = [&](f32x16 &sx, float kv, float qv) __attribute__((always_inline)) {
         if constexpr (WIDE) {
@@ -470,14 +481,6 @@ __global__ __launch_bounds__(256, (DK + DV > 256) ? 1 : 2) void fused_pipelined_
     auto score_fence = [&](f32x16 &sx) __attribute__((always_inline)) {
         if constexpr (WIDE) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(sx));
     };
-    // Softmax state of this lane's query row, all in the exp2 domain:
-    //   m_ref   reference exponent the accumulators are relative to (the row max when it was
-    //           last moved; NOT moved for rises below kDeferLog2 -- fp32 has the headroom)
-    //   max_rel running (true row max - m_ref) >= 0, folded back in at the epilogue
-    //   l_run   this half-wave's share of sum exp2(score - m_ref)
-    constexpr float kDeferLog2 = 24.0f;
-    float m_ref = 0.f, max_rel = 0.f, l_run = 0.f;
-
     // ---- LDS-DMA staging: per-lane source byte offsets inside a tile (loop invariant)
     unsigned koff[KPW], voff[VPW];
 #pragma unroll
@@ -573,12 +576,12 @@ __global__ __launch_bounds__(256, (DK + DV > 256) ? 1 : 2) void fused_pipelined_
         }
     };
     // Row max of a finished score tile (relative to m_ref).  Only a rise of more than
-    // 2^kDeferLog2 moves m_ref: O, l and the pending scores `sx` are then all brought to the
+    // 2^defer moves m_ref: O, l and the pending scores `sx` are then all brought to the
     // new reference exactly once.  (Rare: after the first tile it needs a key whose score beats
     // everything seen so far by > 16.6 in natural-log units.)
     auto absorb_rel = [&](float tmax, f32x16 &sx) __attribute__((always_inline)) {
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        if (__any(tmax > kDeferLog2)) {
+        if (__any(tmax > defer)) {
             const float jump = fmaxf(tmax, 0.f);
             const float alpha = fast_exp2(-jump);
             if constexpr (WIDE) {           // O stays in the accumulator file: read - scale - write back inside asm
@@ -703,6 +706,14 @@ __global__ __launch_bounds__(256, (DK + DV > 256) ? 1 : 2) void fused_pipelined_
         stage_fence();                        // drain this wave's DMAs, then barrier
     };
 
+    float l_tot = 0.f;
+    for (int pass = 0;; ++pass) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+    pin_o();
+    m_ref = 0.f; max_rel = 0.f; l_run = 0.f;
     f32x16 sA, sB;
     if (T > 0) {
         dma_k(0, 0);
@@ -750,35 +761,119 @@ __global__ __launch_bounds__(256, (DK + DV > 256) ? 1 : 2) void fused_pipelined_
     for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[tt][r] *= fold;
-    const float l_tot = (l_run + __shfl_xor(l_run, 32)) * fold;
-    float *out = a.contrib;
-    float *omax = a.lmax, *osum = a.lsum;
-    int ldo = a.ldo;
-    if (a.kv_splits > 1) {
-        ldo = a.ws_ld;
-        out = a.ws_contrib + (size_t)split * a.ws_rows * ldo;
-        omax = a.ws_lmax + (size_t)split * a.ws_rows;
-        osum = a.ws_lsum + (size_t)split * a.ws_rows;
-    }
-    if (qrow < a.m) {
-        float *orow = out + (size_t)qrow * ldo;
+    l_tot = (l_run + __shfl_xor(l_run, 32)) * fold;
+    if (pass != 0) break;
+    // range check of the deferred-rescale pass (see `defer` above).  The LDS tiles are dead here:
+    // every wave has passed the last step's barrier behind its last fragment read.
+    bool bad = !__builtin_isfinite(l_tot);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int col0 = NV * crow(r, hi);
-            if constexpr (NV == 4) {
+    for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-                for (int h = 0; h < NH; ++h)
-                    *reinterpret_cast<float4 *>(orow + 128 * h + col0) =
-                        make_float4(oacc[4 * h][r], oacc[4 * h + 1][r], oacc[4 * h + 2][r], oacc[4 * h + 3][r]);
-            } else {
-                *reinterpret_cast<float2 *>(orow + col0) = make_float2(oacc[0][r], oacc[1][r]);
+        for (int r = 0; r < 16; ++r) bad |= !__builtin_isfinite(oacc[tt][r]);
+    int *vote = reinterpret_cast<int *>(smem);
+    const int wave_bad = __any(bad) ? 1 : 0;
+    if (lane == 0) vote[wave] = wave_bad;
+    __syncthreads();
+    const int redo = __builtin_amdgcn_readfirstlane(vote[0] | vote[1] | vote[2] | vote[3]);
+    if (!redo) break;
+    __syncthreads();                          // the votes are read before pass 1's first DMA lands on them
+    defer = 0.f;
+    }   // pass
+
+    auto store_rows = [&](float *out, int ldo, float *omax, float *osum, const f32x16 (&o)[NT], float vmax,
+                          float vsum) __attribute__((always_inline)) {
+        if (qrow < a.m) {
+            float *orow = out + (size_t)qrow * ldo;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int col0 = NV * crow(r, hi);
+                if constexpr (NV == 4) {
+#pragma unroll
+                    for (int h = 0; h < NH; ++h)
+                        *reinterpret_cast<float4 *>(orow + 128 * h + col0) =
+                            make_float4(o[4 * h][r], o[4 * h + 1][r], o[4 * h + 2][r], o[4 * h + 3][r]);
+                } else {
+                    *reinterpret_cast<float2 *>(orow + col0) = make_float2(o[0][r], o[1][r]);
+                }
+            }
+            if (hi == 0) {
+                omax[qrow] = vmax;
+                osum[qrow] = vsum;
             }
         }
-        if (hi == 0) {
-            omax[qrow] = T > 0 ? (m_ref + max_rel) * 0.69314718055994530942f : -INFINITY;
-            osum[qrow] = l_tot;
+    };
+    const float my_max = T > 0 ? (m_ref + max_rel) * 0.69314718055994530942f : -INFINITY;
+    if (a.kv_splits <= 1) {
+        store_rows(a.contrib, a.ldo, a.lmax, a.lsum, oacc, my_max, l_tot);
+        return;
+    }
+    store_rows(a.ws_contrib + (size_t)split * a.ws_rows * a.ws_ld, a.ws_ld, a.ws_lmax + (size_t)split * a.ws_rows,
+               a.ws_lsum + (size_t)split * a.ws_rows, oacc, my_max, l_tot);
+    if (a.tickets == nullptr) return;         // the slots are merged by a later pass (split_merge_kernel)
+
+    // ---- in-kernel split merge: the LAST workgroup of this query block to arrive merges the block's
+    // kv_splits partial triples (attention-mpi.c:340-351 applied inside one GPU).  Placement-independent
+    // hand-off (the splits of a block run on different XCDs, whose L2s are not coherent): plain slab
+    // stores, every wave drains them, one lane releases at agent scope and takes a ticket; the last
+    // arriver acquires at agent scope and reads every slab -- its own included, in split order, so that
+    // the sums do not depend on who arrived last (bitwise the separate merge pass's result).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int *last_flag = reinterpret_cast<int *>(smem) + 8;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // restates the wait behind buffer_wbl2 where hipcc cannot drop it
+        unsigned long long *word = a.tickets + qblock;
+        unsigned long long seen = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned arrived;
+        for (;;) {       // a word of another generation (or never written) counts as zero arrivals
+            arrived = (seen >> 8) == a.ticket_tag ? (unsigned)(seen & 255u) : 0u;
+            const unsigned long long next = (a.ticket_tag << 8) | (unsigned long long)(arrived + 1u);
+            if (__hip_atomic_compare_exchange_strong(word, &seen, next, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT))
+                break;
+        }
+        const int last = arrived + 1u == (unsigned)a.kv_splits;
+        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *last_flag = last;
+    }
+    __syncthreads();
+    if (!__builtin_amdgcn_readfirstlane(*last_flag)) return;
+
+    f32x16 macc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) macc[t][r] = 0.f;
+    float gm = -INFINITY, tot = 0.f;
+    if (qrow < a.m) {
+        for (int sp = 0; sp < a.kv_splits; ++sp) gm = fmaxf(gm, a.ws_lmax[(size_t)sp * a.ws_rows + qrow]);
+        for (int sp = 0; sp < a.kv_splits; ++sp) {
+            const float lm = a.ws_lmax[(size_t)sp * a.ws_rows + qrow];
+            const float w = (lm == -INFINITY) ? 0.f : expf(lm - gm);
+            tot = fmaf(w, a.ws_lsum[(size_t)sp * a.ws_rows + qrow], tot);
+            const float *srow = a.ws_contrib + ((size_t)sp * a.ws_rows + qrow) * a.ws_ld;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int col0 = NV * crow(r, hi);
+                if constexpr (NV == 4) {
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) {
+                        const float4 o = *reinterpret_cast<const float4 *>(srow + 128 * h + col0);
+                        macc[4 * h][r] = fmaf(w, o.x, macc[4 * h][r]);
+                        macc[4 * h + 1][r] = fmaf(w, o.y, macc[4 * h + 1][r]);
+                        macc[4 * h + 2][r] = fmaf(w, o.z, macc[4 * h + 2][r]);
+                        macc[4 * h + 3][r] = fmaf(w, o.w, macc[4 * h + 3][r]);
+                    }
+                } else {
+                    const float2 o = *reinterpret_cast<const float2 *>(srow + col0);
+                    macc[0][r] = fmaf(w, o.x, macc[0][r]);
+                    macc[1][r] = fmaf(w, o.y, macc[1][r]);
+                }
+            }
         }
     }
+    store_rows(a.contrib, a.ldo, a.lmax, a.lsum, macc, gm, tot);
 }
 
 // ---------------------------------------------------------------------------
@@ -1294,11 +1389,12 @@ __global__ void split_merge_kernel(PartialArgs a) {
     for (int s = 0; s < a.kv_splits; ++s) {
         const float lm = a.ws_lmax[(size_t)s * a.ws_rows + row];
         const float w = (lm == -INFINITY) ? 0.f : expf(lm - gm);
-        tot += w * a.ws_lsum[(size_t)s * a.ws_rows + row];
+        tot = fmaf(w, a.ws_lsum[(size_t)s * a.ws_rows + row], tot);
         {
             const float4 o = *reinterpret_cast<const float4 *>(
                 a.ws_contrib + ((size_t)s * a.ws_rows + row) * a.ws_ld + 4 * c4);
-            acc.x += w * o.x; acc.y += w * o.y; acc.z += w * o.z; acc.w += w * o.w;
+            acc.x = fmaf(w, o.x, acc.x); acc.y = fmaf(w, o.y, acc.y);
+            acc.z = fmaf(w, o.z, acc.z); acc.w = fmaf(w, o.w, acc.w);
         }
     }
     *reinterpret_cast<float4 *>(a.contrib + (size_t)row * a.ldo + 4 * c4) = acc;
@@ -1314,6 +1410,7 @@ __global__ void split_merge_kernel(PartialArgs a) {
 // correctness path for shapes the MFMA kernel does not cover in fp32; slow.
 // ---------------------------------------------------------------------------
 constexpr int kGenericMaxCols = 16;   // dv <= 64 * 16
+static const int kGenericMaxColsAnchor = 0;   // (an address of this library's own image: see next_ticket_tag)
 
 __global__ __launch_bounds__(256) void generic_partial_kernel(PartialArgs a, float scale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1426,7 +1523,28 @@ size_t workspace_bytes(int m, int n_local, int dk, int dv) {
     const int s = pick_kv_splits(m, n_local, dk, dv);
     if (s <= 1) return 0;
     const size_t ws_ld = (size_t)dense_ld(dv);         // the padded kernels write whole 64/128/256-column rows
-    return (size_t)s * (size_t)m * (ws_ld + 2) * sizeof(float);
+    const size_t tickets = (size_t)((m + kQRowsPerBlock - 1) / kQRowsPerBlock) * sizeof(unsigned long long);
+    return (size_t)s * (size_t)m * (ws_ld + 2) * sizeof(float) + tickets;
+}
+
+void carve_workspace(PartialArgs &a, void *ws, int ws_ld) {
+    a.ws_ld = ws_ld;
+    a.ws_contrib = (float *)ws;
+    a.ws_lmax = a.ws_contrib + (size_t)a.kv_splits * a.m * ws_ld;
+    a.ws_lsum = a.ws_lmax + (size_t)a.kv_splits * a.m;
+    // (ws_ld + 2) is even, so the arrival words are 8-byte aligned whenever the area is
+    a.tickets = reinterpret_cast<unsigned long long *>(a.ws_lsum + (size_t)a.kv_splits * a.m);
+}
+
+// Generation of a launch's arrival words (PartialArgs::ticket_tag): 56 bits, never zero, never repeated
+// within a process, and started from a per-process value so that two copies of this library in one
+// process (tools/ A/B runs) do not hand the same numbers to launches that share a scratch area.
+static unsigned long long next_ticket_tag() {
+    static std::atomic<unsigned long long> gen{
+        ((unsigned long long)time(nullptr) << 24) ^ ((unsigned long long)(uintptr_t)&kGenericMaxColsAnchor << 4)};
+    unsigned long long t;
+    do t = gen.fetch_add(1, std::memory_order_relaxed) & ((1ull << 56) - 1); while (t == 0);
+    return t;
 }
 
 hipError_t launch_split_merge(const PartialArgs &a_in, hipStream_t s) {
@@ -1534,11 +1652,21 @@ static hipError_t launch_pipelined(const PartialArgs &a, hipStream_t s) {
         attr_done[dev] = true;
     }
     const float scale = 1.0f / sqrtf((float)a.dk);   // attention-mpi.c:208
-    hipLaunchKernelGGL((fused_pipelined_kernel<DK, DV, ABL>), dim3(nqb * a.kv_splits), dim3(256), lds, s,
-                       a, kv_per_split, nqb, scale);
+    // kv_splits > 1: the kernel merges its splits itself when it was given arrival words (the last
+    // workgroup of a query block to arrive does it); without them a separate pass does
+    // ($SDPA_SPLIT_MERGE=pass, read per launch: the separate pass also here -- same sums in the same
+    //  order, so an A/B of the two forms must agree bit for bit: tests/test_gpu_parity.py)
+    PartialArgs k = a;
+    const char *form = getenv("SDPA_SPLIT_MERGE");
+    if (k.kv_splits <= 1 || k.defer_merge || (reinterpret_cast<uintptr_t>(k.tickets) & 7) != 0 ||
+        (form && strcmp(form, "pass") == 0))
+        k.tickets = nullptr;
+    if (k.tickets) k.ticket_tag = next_ticket_tag();
+    hipLaunchKernelGGL((fused_pipelined_kernel<DK, DV, ABL>), dim3(nqb * k.kv_splits), dim3(256), lds, s,
+                       k, kv_per_split, nqb, scale);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (a.kv_splits > 1 && !a.defer_merge) e = launch_split_merge(a, s);
+    if (k.kv_splits > 1 && !k.defer_merge && !k.tickets) e = launch_split_merge(k, s);
     return e;
 }
 

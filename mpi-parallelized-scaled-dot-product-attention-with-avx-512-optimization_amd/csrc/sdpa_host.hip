@@ -434,10 +434,7 @@ int launch_fused(const Plan &pl, Rank &rk, const RankPlan &rp, int s, int bs, in
                 a.ws_contrib = sl_c; a.ws_lmax = sl_m; a.ws_lsum = sl_s;
                 a.ws_ld = pl.ldo; a.ws_rows = bs; a.defer_merge = 1;
             } else if (a.kv_splits > 1) {
-                a.ws_ld = pl.ldo;
-                a.ws_contrib = (float *)rk.ws.p;
-                a.ws_lmax = a.ws_contrib + (size_t)a.kv_splits * jr * a.ws_ld;
-                a.ws_lsum = a.ws_lmax + (size_t)a.kv_splits * jr;
+                sdpa::carve_workspace(a, rk.ws.p, pl.ldo);
             }
         }
         HIP_TRY(sdpa::launch_shard_partial(a, rk.s_run));

@@ -41,6 +41,11 @@ struct PartialArgs {
                                    // sub-range of rows write into the slots of a larger batch
     int defer_merge;               // 1 = leave the kv_splits partial triples in the ws slots (the host
                                    // pipeline merges the slots of all its K/V chunks in one pass)
+    unsigned long long *tickets;   // [query blocks of 128 rows] arrival words of the IN-KERNEL split merge (pipelined
+                                   // fp32 kernels with kv_splits > 1 and no defer_merge): the last workgroup of a
+                                   // query block to arrive merges its splits.  nullptr = separate merge pass
+    unsigned long long ticket_tag; // this launch's generation (set by the launcher): a word counts only when its
+                                   // upper 56 bits equal it, so nothing has to be cleared between launches
     int tune;                      // -DSDPA_ABLATIONS builds only ($SDPA_TUNE): 4 = register-staged kernel
                                    // instead of the pipelined one, 16/32/64 = timing-only ablations
 };
@@ -94,6 +99,9 @@ hipError_t launch_split_merge(const PartialArgs &a, hipStream_t s);
 
 int  pick_kv_splits(int m, int n_local, int dk, int dv);
 size_t workspace_bytes(int m, int n_local, int dk, int dv);
+// Point a.ws_* (and a.tickets) into a scratch area of workspace_bytes(a.m, ...) bytes: kv_splits slabs of
+// a.m rows x ws_ld floats, the two statistics arrays, the arrival words.  Needs a.m, a.kv_splits.
+void carve_workspace(PartialArgs &a, void *ws, int ws_ld);
 
 // Enqueue the fused kernel (+ the split merge when kv_splits > 1).
 hipError_t launch_shard_partial(const PartialArgs &a, hipStream_t s);

@@ -416,26 +416,109 @@ def test_error_ratio_vs_reference_fp32_pipeline(pkg, be, orc, O):
 
 
 def test_race_screen_repeatability(pkg, be, orc, O):
-    """The pipelined kernel hands K/V tiles between waves through LDS-DMA + barriers; a missing
-    wait shows up as rare wrong tiles.  Screen: 25 launches each of three shapes (with in-GPU
-    splits, ragged tails, both MFMA kernels) must be BITWISE identical to the first, which is
-    checked against the oracle."""
-    for (m, n, dk, dv, dist) in [(640, 6000, 128, 128, "D2"), (513, 3333, 64, 64, "D3"), (300, 2500, 96, 72, "D2")]:
+    """The pipelined kernel hands K/V tiles between waves through LDS-DMA + barriers, and the partial
+    triples of its in-GPU K/V splits between WORKGROUPS (different XCDs, non-coherent L2s) through an
+    agent-scope release / ticket / acquire; a missing wait or a stale line shows up as rare wrong
+    tiles.  Screen: 100 launches each of three shapes (in-GPU splits merged inside the kernel, ragged
+    tails, both MFMA kernels) must be BITWISE identical to the first, which is checked against the
+    oracle.  All shapes share one scratch area, so every launch finds the previous shape's arrival
+    words in it (another generation: they must count as zero)."""
+    shapes = [(640, 6000, 128, 128, "D2"), (513, 3333, 64, 64, "D3"), (300, 2500, 96, 72, "D2")]
+    runs = []
+    for (m, n, dk, dv, dist) in shapes:
+        assert pkg.load().sdpa_dev_kv_splits(m, n, dk, dv) > 1
         Q, K, V = O.make_inputs(m, n, dk, dv, dist, seed=77)
         sa = pkg.ShardedAttention(be)
         sa.load_kv_from_root(K, V, n, dk, dv)
         qf = sa.convert_q(torch.from_numpy(Q).cuda())
-        first = None
-        for it in range(25):
-            contrib, lmax, lsum = sa.batch_partial(qf)
-            cur = (contrib.clone(), lmax.clone(), lsum.clone())
-            if first is None:
-                first = cur
-                got = be.finish_f64(contrib, lsum, dv).cpu().numpy()
-                check(got, orc.attention_f64(Q, K, V), V, "first launch")
-            else:
-                assert all(torch.equal(a_[:, :dv] if a_.dim() == 2 else a_, b_[:, :dv] if b_.dim() == 2 else b_)
-                           for a_, b_ in zip(cur, first)), "launch %d differs from launch 0" % it
+        contrib, lmax, lsum = sa.batch_partial(qf)
+        first = (contrib.clone(), lmax.clone(), lsum.clone())
+        check(be.finish_f64(contrib, lsum, dv).cpu().numpy(), orc.attention_f64(Q, K, V), V, "first launch")
+        runs.append((sa, qf, dv, first))
+    for it in range(1, 100):
+        for sa, qf, dv, first in runs:                 # interleaved: the scratch area changes hands every launch
+            cur = sa.batch_partial(qf)
+            assert all(torch.equal(a_[:, :dv] if a_.dim() == 2 else a_, b_[:, :dv] if b_.dim() == 2 else b_)
+                       for a_, b_ in zip(cur, first)), "launch %d differs from launch 0" % it
+
+
+@pytest.mark.parametrize("m,n,dk,dv", [(8192, 8192, 128, 128),      # BASELINE config 2: 64 query blocks x 8 splits
+                                        (640, 6000, 128, 128), (513, 3333, 64, 64), (300, 2500, 96, 72),
+                                        (1000, 20000, 256, 256),     # one wave per SIMD variant
+                                        (4096, 8192, 128, 64), (700, 9000, 64, 128), (900, 7000, 250, 120)])
+def test_in_kernel_split_merge_equals_the_separate_pass_bitwise(m, n, dk, dv, pkg, be, O, monkeypatch):
+    """kv_splits > 1 on the pipelined kernels: the last workgroup of a query block to arrive merges the
+    block's partial triples inside the fused launch (one launch per step).  $SDPA_SPLIT_MERGE=pass runs
+    the separate split_merge_kernel instead: same weights, same sums in the same split order -- the two
+    forms must agree bit for bit, 20 launches each (under load from the neighbouring query blocks)."""
+    assert pkg.load().sdpa_dev_kv_splits(m, n, dk, dv) > 1
+    Q, K, V = O.make_inputs(m, n, dk, dv, "D2", seed=5)
+    sa = pkg.ShardedAttention(be)
+    sa.load_kv_from_root(K, V, n, dk, dv)
+    qf = sa.convert_q(torch.from_numpy(Q).cuda())
+    monkeypatch.setenv("SDPA_SPLIT_MERGE", "pass")
+    want = tuple(t.clone() for t in sa.batch_partial(qf))
+    monkeypatch.delenv("SDPA_SPLIT_MERGE")
+    for it in range(20):
+        got = sa.batch_partial(qf)
+        for name, g, w in zip(("contrib", "lmax", "lsum"), got, want):
+            g, w = (g[:, :dv], w[:, :dv]) if g.dim() == 2 else (g, w)
+            assert torch.equal(g, w), "launch %d: %s of the in-kernel merge differs from the separate pass" % (it, name)
+    assert np.isfinite(be.finish_f64(got[0], got[2], dv).cpu().numpy()).all()
+
+
+def steep_late_rise_inputs(m, n, d, vscale, seed=3, first=32, rise_nats=15.0):
+    """Keys [0, first) score `rise_nats` BELOW all the others for every query, and every V entry is
+    ~ +vscale: a kernel that defers its accumulator rescale (rise < 2^24) carries weights of e^15
+    on n - first keys -- beyond fp32 for vscale * n * e^15 > 3.4e38 -- where the reference's eager
+    rescale (attention-mpi.c:179-182) keeps every weight <= 1."""
+    rng = np.random.default_rng(seed)
+    u = rng.standard_normal(d)
+    u /= np.linalg.norm(u)
+    ab = rise_nats * np.sqrt(d) / 2.0
+    a = b = np.sqrt(ab)
+    Q = a * u[None, :] + 0.01 * rng.standard_normal((m, d))
+    K = b * u[None, :] + 0.01 * rng.standard_normal((n, d))
+    K[:first] = -b * u[None, :] + 0.01 * rng.standard_normal((first, d))
+    V = vscale * (1.0 + 0.1 * rng.random((n, d)))
+    return Q, K, V
+
+
+@pytest.mark.parametrize("m,n,d,vscale", [(256, 65536, 128, 1e30),     # the verdict's case: |V| ~ 1e30, n = 65536, d = 128
+                                           (2048, 16384, 128, 1e31),    # fewer splits per query block
+                                           (256, 8192, 256, 1e32),      # one wave per SIMD variant
+                                           (300, 8000, 64, 1e32)])
+def test_fp32_range_where_the_deferred_rescale_would_overflow(m, n, d, vscale, pkg, be, orc, O):
+    """attention-mpi.c:179-182 rescales on every new maximum, so its un-normalised sums stay below
+    n * max|V|.  The pipelined kernels defer the rescale (weights up to 2^24): on these inputs their
+    first pass overflows, the epilogue's range check sees it and the workgroup redoes its K/V range
+    with an eager rescale.  Device level and boundary, against the fp64 oracle at the fp32 tolerance;
+    the reference's own fp32 pipeline (oracle_attention_sharded_f32) is finite on the same inputs."""
+    Q, K, V = steep_late_rise_inputs(m, n, d, vscale)
+    want = O.numpy_attention_f64(Q, K, V)
+    if m * n <= 256 * 65536:
+        ref32 = orc.attention_sharded_f32(Q, K, V, 1)
+        assert np.isfinite(ref32).all() and np.abs(ref32 - want).max() <= fp32_tol(V)
+    # lazily rescaled weights alone would overflow: e^15 * (keys of split 0 beyond the first tile) * vscale
+    sa = pkg.ShardedAttention(be)
+    sa.load_kv_from_root(K, V, n, d, d)
+    contrib, lmax, lsum = sa.batch_partial(sa.convert_q(torch.from_numpy(Q).cuda()))
+    assert torch.isfinite(contrib).all() and torch.isfinite(lsum).all()
+    check(be.finish_f64(contrib, lsum, d).cpu().numpy(), want, V, "device level")
+    check(pkg.attention(Q, K, V), want, V, "boundary")
+    # and as 4 loopback-free K/V shards merged with the reference's algebra (the shard holding the low keys redoes)
+    parts = 4
+    triples = []
+    qf = be.cvt_d2f(torch.from_numpy(Q).cuda())
+    for r in range(parts):
+        c, dsp = pkg.owner_count(n, parts, r), pkg.owner_disp(n, parts, r)
+        sh = pkg.ShardedAttention(be)
+        sh.load_kv_from_root(K[dsp:dsp + c], V[dsp:dsp + c], c, d, d)
+        triples.append(sh.batch_partial(qf))
+    stats = torch.stack([torch.stack((t[1], t[2])) for t in triples]).contiguous()
+    for r, (c_, _, _) in enumerate(triples):
+        be.merge_gathered(c_, stats, r, d)
+    check(be.cvt_f2d(torch.stack([t[0] for t in triples]).sum(dim=0), d).cpu().numpy(), want, V, "4 shards merged")
 
 
 def test_gathered_merge_equals_two_phase(pkg, be, orc, O):

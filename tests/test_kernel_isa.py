@@ -33,8 +33,16 @@ def kernel_lines(lines, name_re):
 
 
 def main_loop_mix(k):
-    """instruction histogram of the backward-branch loop of a kernel that holds the most MFMAs"""
+    """instruction histogram of the INNERMOST backward-branch loop of a kernel that holds the most MFMAs
+    (a loop that contains another backward branch is an outer loop: the fp32 kernels' second pass
+    around the whole K/V walk, for instance)"""
     labels = {m.group(1): i for i, l in enumerate(k) if (m := re.match(r"^(\.LBB\d+_\d+):", l))}
+    back = []                                          # (target line, branch line) of every backward branch
+    for i, l in enumerate(k):
+        m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            back.append((labels[m.group(1)], i))
+
     def mix(lo, hi):
         c = Counter()
         for l in k[lo:hi + 1]:
@@ -44,14 +52,13 @@ def main_loop_mix(k):
         return c
 
     best = None
-    for i, l in enumerate(k):
-        m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", l)
-        if m and m.group(1) in labels and labels[m.group(1)] < i:
-            c = mix(labels[m.group(1)], i)
-            n = sum(v for name, v in c.items() if name.startswith("v_mfma"))
-            # innermost loop with the most MFMAs: ties go to the shorter span
-            if best is None or n > best[0] or (n == best[0] and i - labels[m.group(1)] < best[1]):
-                best = (n, i - labels[m.group(1)], c)
+    for lo, hi in back:
+        if any((lo2, hi2) != (lo, hi) and lo <= lo2 and hi2 <= hi for lo2, hi2 in back):
+            continue                                   # contains another loop
+        c = mix(lo, hi)
+        n = sum(v for name, v in c.items() if name.startswith("v_mfma"))
+        if best is None or n > best[0] or (n == best[0] and hi - lo < best[1]):
+            best = (n, hi - lo, c)
     assert best is not None, "no loop found"
     return best[2]
 
