@@ -103,7 +103,7 @@ def test_argument_validation_precedes_device_use(pkg):
     assert lib.sdpa_dev_kv_splits(512, 512, 64, 64) == 4
     assert lib.sdpa_dev_kv_splits(8192, 8192, 512, 512) == 2      # dk-split kernel: 128 workgroups of 64 rows
     assert lib.sdpa_dev_kv_splits(8192, 8192, 600, 64) == 1       # dk > 512: VALU kernel, no splits
-    assert lib.sdpa_dev_workspace_bytes(32768, 65536, 128, 128) == 2 * 32768 * 130 * 4
+    assert lib.sdpa_dev_workspace_bytes(32768, 65536, 128, 128) == 2 * 32768 * 130 * 4 + 256 * 8   # + one arrival word per query block
     assert lib.sdpa_dev_workspace_bytes(100000, 64, 128, 128) == 0
 
 
