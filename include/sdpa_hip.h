@@ -58,7 +58,10 @@ extern "C" {
 #define SDPA_F_MERGE_ALLREDUCE 8   /* K/V plan: the reference's literal two-phase merge,        */
                                    /* all-reduce(MAX) + all-reduce(SUM) (attention-mpi.c:342,   */
                                    /* :354); also $SDPA_MERGE=allreduce.  Default: ONE          */
-                                   /* all-gather of the (lmax,lsum) pairs -- same algebra       */
+                                   /* all-gather of the (lmax,lsum) pairs -- same algebra.      */
+                                   /* Either way the merged rows are reduce-SCATTERED, every    */
+                                   /* rank copies its share home ($SDPA_EGRESS=root: the        */
+                                   /* reference's reduce to rank 0, attention-mpi.c:380)        */
 
 /* Breakdown of the last sdpa_attention_f64(), microseconds.  The call only ENQUEUES work and
  * waits once at the end, so the stage figures are device-side intervals (HIP events on GPU 0)
@@ -81,6 +84,17 @@ struct sdpa_timing {
     int    plan;          /* 0 = K/V rows sharded, 1 = query rows sharded                       */
     int    merge;         /* 0 = none (one rank), 1 = all-gather, 2 = two all-reduces           */
     int    virtual_ranks; /* 1 = the ranks are loopback ranks on one device                     */
+    /* -- fields added in 0.3 (appended) ------------------------------------------------------ */
+    double enqueue_total_us;            /* entry -> every rank's work and every collective tail   */
+                                        /* is enqueued (host clock; the GPUs are long at work)    */
+    double enqueue_first_kernel_us[16]; /* entry -> rank r's FIRST fused launch is enqueued (host */
+                                        /* clock).  With P > 1 every rank has its own enqueue     */
+                                        /* thread: the spread over ranks is thread wake-up skew,  */
+                                        /* not one rank's whole batch of API calls per rank       */
+    int    egress;        /* how finished rows go home: 0 = from the rank that computed them,    */
+                          /* 1 = reduce to the root (attention-mpi.c:380), 2 = reduce-scatter,   */
+                          /* every rank widens and copies its rows over its own PCIe link        */
+    int    enqueue_threads; /* host threads that enqueued (1 = the calling thread only)          */
 };
 
 /* ---- lifecycle ---------------------------------------------------------- */

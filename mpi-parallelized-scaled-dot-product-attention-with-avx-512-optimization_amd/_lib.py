@@ -28,7 +28,9 @@ class SdpaTiming(ctypes.Structure):
                 ("n_gpus", _c_int), ("q_batches", _c_int), ("kv_splits", _c_int),
                 ("register_us", ctypes.c_double), ("head_us", ctypes.c_double), ("tail_us", ctypes.c_double),
                 ("kv_chunks", _c_int), ("fused_launches", _c_int), ("plan", _c_int), ("merge", _c_int),
-                ("virtual_ranks", _c_int)]
+                ("virtual_ranks", _c_int),
+                ("enqueue_total_us", ctypes.c_double), ("enqueue_first_kernel_us", ctypes.c_double * 16),
+                ("egress", _c_int), ("enqueue_threads", _c_int)]
 
 
 class SdpaError(RuntimeError):

@@ -38,6 +38,11 @@ public:
     // recv_root[i] = sum_p send[p][i] on rank 0 only (attention-mpi.c:380).
     virtual int reduce_sum_to_root(float *const *send, float *recv_root, size_t count,
                                    hipStream_t const *streams) = 0;
+    // recv[r][i] = sum_p send[p][r * count + i], i < count, on every rank r: rank r keeps the r-th of P equal
+    // shares of the sum (send buffers hold P * count elements).  The parallel form of the reference's
+    // reduce to the root: every rank then sends ITS rows home.
+    virtual int reduce_scatter_sum(float *const *send, float *const *recv, size_t count,
+                                   hipStream_t const *streams) = 0;
     // last error text of the underlying library ("" when none)
     virtual const char *last_error() const { return ""; }
 

@@ -31,6 +31,7 @@ struct RcclApi {
     int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     int (*Reduce)(const void *, void *, size_t, int, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*ReduceScatter)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 };
 
@@ -59,6 +60,7 @@ bool load_rccl(RcclApi &r) {
            bind(r.handle, "ncclAllReduce", r.AllReduce) &&
            bind(r.handle, "ncclAllGather", r.AllGather) &&
            bind(r.handle, "ncclReduce", r.Reduce) &&
+           bind(r.handle, "ncclReduceScatter", r.ReduceScatter) &&
            bind(r.handle, "ncclGetErrorString", r.GetErrorString);
 }
 
@@ -109,6 +111,13 @@ public:
                              comms_[r], streams[r]);
         return finish(rc, "ncclReduce");
     }
+    int reduce_scatter_sum(float *const *send, float *const *recv, size_t count,
+                           hipStream_t const *streams) override {
+        int rc = api_.GroupStart();
+        for (int r = 0; r < P_ && rc == kNcclSuccess; ++r)
+            rc = api_.ReduceScatter(send[r], recv[r], count, kNcclFloat, kNcclSum, comms_[r], streams[r]);
+        return finish(rc, "ncclReduceScatter");
+    }
 
 private:
     void note(int rc, const char *what) {
@@ -147,6 +156,17 @@ __global__ void loop_reduce_kernel(PtrPack in, PtrPack out, int P, int n_out, si
             acc = is_max ? fmaxf(acc, v) : acc + v;
         }
         for (int r = 0; r < n_out; ++r) out.p[r][i] = acc;
+    }
+}
+
+// out[r][i] = sum over ranks (rank order, as loop_reduce_kernel) of in[p][r * count + i]
+__global__ void loop_reduce_scatter_kernel(PtrPack in, PtrPack out, int P, size_t count) {
+    const size_t total = (size_t)P * count;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        float acc = in.p[0][i];
+        for (int p = 1; p < P; ++p) acc += in.p[p][i];
+        out.p[i / count][i % count] = acc;
     }
 }
 
@@ -193,6 +213,10 @@ public:
         float *recv[1] = {recv_root};
         return run(send, recv, 1, count, streams, 0, false);
     }
+    int reduce_scatter_sum(float *const *send, float *const *recv, size_t count,
+                           hipStream_t const *streams) override {
+        return run(send, recv, P_, count, streams, 2, false);
+    }
 
 private:
     int fail(hipError_t e, const char *what) {
@@ -214,11 +238,13 @@ private:
             if ((e = hipStreamWaitEvent(hub_, arrive_[r], 0)) != hipSuccess) return fail(e, "hipStreamWaitEvent");
         }
         if (count > 0) {
-            const size_t work = gather ? count * P_ : count;
+            const size_t work = (gather || is_max == 2) ? count * P_ : count;
             size_t grid = (work + 255) / 256;
             if (grid > 2048) grid = 2048;
             if (gather)
                 hipLaunchKernelGGL(loop_gather_kernel, dim3((unsigned)grid), dim3(256), 0, hub_, in, out, P_, count);
+            else if (is_max == 2)        // (mode 2 = reduce-scatter)
+                hipLaunchKernelGGL(loop_reduce_scatter_kernel, dim3((unsigned)grid), dim3(256), 0, hub_, in, out, P_, count);
             else
                 hipLaunchKernelGGL(loop_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, hub_, in, out, P_,
                                    n_out, count, is_max);

@@ -55,6 +55,12 @@
 #include <stdint.h>
 #include <type_traits>
 
+// -DSDPA_RANGE_REDO=0 builds the fp32 pipelined kernels without their range check and second pass
+// (tools/build_variant.sh: an A/B of what the check costs; never the shipped library)
+#ifndef SDPA_RANGE_REDO
+#define SDPA_RANGE_REDO 1
+#endif
+
 namespace sdpa {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -707,7 +713,9 @@ __global__ __launch_bounds__(256, (DK + DV > 256) ? 1 : 2) void fused_pipelined_
     };
 
     float l_tot = 0.f;
-    for (int pass = 0;; ++pass) {
+    // one walk over the split's K/V range; instantiated twice (straight-line, no loop around the hot
+    // loop: its register allocation stays what it was), the second copy only runs after a failed range check
+    auto run_pass = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -762,23 +770,29 @@ __global__ __launch_bounds__(256, (DK + DV > 256) ? 1 : 2) void fused_pipelined_
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[tt][r] *= fold;
     l_tot = (l_run + __shfl_xor(l_run, 32)) * fold;
-    if (pass != 0) break;
-    // range check of the deferred-rescale pass (see `defer` above).  The LDS tiles are dead here:
-    // every wave has passed the last step's barrier behind its last fragment read.
-    bool bad = !__builtin_isfinite(l_tot);
+    };  // run_pass
+
+    run_pass();
+#if SDPA_RANGE_REDO
+    {   // range check of the deferred-rescale pass (see `defer` above).  The LDS tiles are dead here:
+        // every wave has passed the last step's barrier behind its last fragment read.
+        bool bad = !__builtin_isfinite(l_tot);
 #pragma unroll
-    for (int tt = 0; tt < NT; ++tt)
+        for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bad |= !__builtin_isfinite(oacc[tt][r]);
-    int *vote = reinterpret_cast<int *>(smem);
-    const int wave_bad = __any(bad) ? 1 : 0;
-    if (lane == 0) vote[wave] = wave_bad;
-    __syncthreads();
-    const int redo = __builtin_amdgcn_readfirstlane(vote[0] | vote[1] | vote[2] | vote[3]);
-    if (!redo) break;
-    __syncthreads();                          // the votes are read before pass 1's first DMA lands on them
-    defer = 0.f;
-    }   // pass
+            for (int r = 0; r < 16; ++r) bad |= !__builtin_isfinite(oacc[tt][r]);
+        int *vote = reinterpret_cast<int *>(smem);
+        const int wave_bad = __any(bad) ? 1 : 0;
+        if (lane == 0) vote[wave] = wave_bad;
+        __syncthreads();
+        const int redo = __builtin_amdgcn_readfirstlane(vote[0] | vote[1] | vote[2] | vote[3]);
+        if (redo) {
+            __syncthreads();                  // the votes are read before the second pass's first DMA lands on them
+            defer = 0.f;
+            run_pass();
+        }
+    }
+#endif
 
     auto store_rows = [&](float *out, int ldo, float *omax, float *osum, const f32x16 (&o)[NT], float vmax,
                           float vsum) __attribute__((always_inline)) {
@@ -1652,14 +1666,16 @@ static hipError_t launch_pipelined(const PartialArgs &a, hipStream_t s) {
         attr_done[dev] = true;
     }
     const float scale = 1.0f / sqrtf((float)a.dk);   // attention-mpi.c:208
-    // kv_splits > 1: the kernel merges its splits itself when it was given arrival words (the last
-    // workgroup of a query block to arrive does it); without them a separate pass does
-    // ($SDPA_SPLIT_MERGE=pass, read per launch: the separate pass also here -- same sums in the same
-    //  order, so an A/B of the two forms must agree bit for bit: tests/test_gpu_parity.py)
+    // kv_splits > 1: the partial triples are merged by split_merge_kernel right behind.  The kernel can
+    // also merge them itself ($SDPA_SPLIT_MERGE=kernel, read per launch: the last workgroup of a query
+    // block to arrive does it, one launch per step) -- same sums in the same order, bit for bit
+    // (tests/test_gpu_parity.py) -- but measured SLOWER on MI355X (profiles/r03/split_merge_forms_ab.log:
+    // config 2 0.301 vs 0.273 ms per step, a 1/8 rank share 1.013 vs 0.993): the separate pass spreads
+    // the 34 MB of slab reads over every CU, the last arrivers are 64 workgroups in a latency-bound tail.
     PartialArgs k = a;
     const char *form = getenv("SDPA_SPLIT_MERGE");
     if (k.kv_splits <= 1 || k.defer_merge || (reinterpret_cast<uintptr_t>(k.tickets) & 7) != 0 ||
-        (form && strcmp(form, "pass") == 0))
+        !(form && strcmp(form, "kernel") == 0))
         k.tickets = nullptr;
     if (k.tickets) k.ticket_tag = next_ticket_tag();
     hipLaunchKernelGGL((fused_pipelined_kernel<DK, DV, ABL>), dim3(nqb * k.kv_splits), dim3(256), lds, s,

@@ -21,7 +21,13 @@
 //                                                            out stream (the last batch in pieces so
 //                                                            that only a fraction of it is exposed)
 //
-// One host thread enqueues everything and waits once at the end; ordering is by HIP events.
+// The call only ENQUEUES and waits once at the end; ordering on the devices is by HIP events.  With one
+// rank the calling thread enqueues everything.  With P > 1 every rank has its own enqueue thread (a
+// pool created with the engine): all ranks' first copies and kernels are issued at the same time, not
+// rank after rank; the calling thread page-locks the caller's arrays in the order the copies need them
+// and enqueues the per-batch merge collectives on the ranks' COMM streams, so that batch b's
+// all-gather / reduce / writeback run under batch b+1's fused kernels (the reference's
+// MPI_Ireduce ... next batch ... MPI_Wait, attention-mpi.c:364-380).
 #include "sdpa_coll.h"
 #include "sdpa_errors.h"
 #include "sdpa_internal.h"
@@ -32,8 +38,12 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -67,13 +77,16 @@ struct Rank {
     // s_cp: host->device copies only (never waits for a kernel: PCIe stays busy while the fused
     // kernel holds every CU); s_in: the fp64->operand converts (high priority: they slip into the
     // gap between two fused launches); s_run: fused kernels, merges, collectives; s_out: D2H
-    hipStream_t s_cp = nullptr, s_in = nullptr, s_run = nullptr, s_out = nullptr;
+    // s_comm: the merge of a batch over the ranks (collectives, merge kernels, fp32->fp64) -- its own
+    // stream, so that the NEXT batch's fused kernels on s_run do not queue behind it
+    hipStream_t s_cp = nullptr, s_in = nullptr, s_run = nullptr, s_out = nullptr, s_comm = nullptr;
     DevBuf k64, v64;                     // fp64 staging of the WHOLE shard (a copy never waits for a convert)
     DevBuf kf, vf;                       // operand image of the whole shard
     DevBuf ws;                           // the fused kernel's own scratch (splits of a direct launch, redo flags)
     DevBuf slots;                        // partial triples of the streamed batch: [slot][row][ldo] + 2 x [slot][row]
     DevBuf q64[2], qf[2], contrib[2], stat[2], gstat[2], red[2], out64[2];
     hipEvent_t ev_q[2] = {}, ev_run[2] = {}, ev_out[2] = {};
+    hipEvent_t ev_comm[2] = {};          // the collective tail of the batch in slot s is done with contrib[s]/stat[s]
     hipEvent_t ev_sub[2][kMaxSub] = {};
     hipEvent_t ev_qh[kMaxSub] = {}, ev_qp[kMaxSub] = {};   // Q piece j: copied / converted
     std::vector<hipEvent_t> ev_h2d;      // [2c] K rows, [2c+1] V rows of chunk c have crossed PCIe
@@ -82,12 +95,76 @@ struct Rank {
     hipEvent_t ev_t0 = nullptr, ev_kv_done = nullptr, ev_end = nullptr;
 };
 
+// One enqueue thread per rank (P > 1 only).  A job is a function of the rank index; run() hands it to
+// every thread and returns, wait() blocks until all of them are done with it.
+struct Pool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    int (*fn)(void *, int) = nullptr;
+    void *arg = nullptr;
+    unsigned long gen = 0;
+    int pending = 0;
+    bool stop = false;
+
+    void start(int n, const std::vector<int> &devs) {
+        for (int i = 0; i < n; ++i)
+            th.emplace_back([this, i, dev = devs[i]] {
+                if (hipSetDevice(dev) != hipSuccess) (void)hipGetLastError();
+                unsigned long seen = 0;
+                for (;;) {
+                    int (*f)(void *, int);
+                    void *a;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv_job.wait(lk, [&] { return stop || gen != seen; });
+                        if (stop) return;
+                        seen = gen;
+                        f = fn;
+                        a = arg;
+                    }
+                    (void)f(a, i);
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        if (--pending == 0) cv_done.notify_all();
+                    }
+                }
+            });
+    }
+    void run(int (*f)(void *, int), void *a) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            fn = f;
+            arg = a;
+            pending = (int)th.size();
+            ++gen;
+        }
+        cv_job.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+    void shutdown() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv_job.notify_all();
+        for (std::thread &t : th) t.join();
+        th.clear();
+        stop = false;
+        pending = 0;
+    }
+};
+
 struct Engine {
     bool up = false;
     int n = 0;                           // ranks
     bool virtual_ranks = false;
     std::vector<Rank> r;
     Collectives *coll = nullptr;
+    Pool pool;                           // enqueue threads, one per rank (empty with one rank)
     sdpa_timing last = {};
 };
 // Heap-allocated and never destroyed on purpose: at process exit the order in which this library's
@@ -111,43 +188,48 @@ int env_int(const char *name, int dflt) {
 // RAII page-locking of caller-owned host arrays (best effort: a range that cannot be registered,
 // e.g. because the caller already allocated it page-locked, is simply left as it is).
 struct HostPins {
-    void *ptr[8];
-    int n = 0;
+    std::vector<void *> ptr;
     double us = 0.0;                                        // host time spent registering
     void add(const void *p, size_t bytes) {
-        if (bytes < (1u << 20) || n >= 8) return;          // small arrays: not worth the call
+        if (bytes < (1u << 20)) return;                     // small ranges: not worth the call
         const double t0 = now_us();
         if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) == hipSuccess)
-            ptr[n++] = const_cast<void *>(p);
+            ptr.push_back(const_cast<void *>(p));
         else
             (void)hipGetLastError();
         us += now_us() - t0;
     }
     ~HostPins() {
-        for (int i = 0; i < n; ++i)
-            if (hipHostUnregister(ptr[i]) != hipSuccess) (void)hipGetLastError();
+        for (void *q : ptr)
+            if (hipHostUnregister(q) != hipSuccess) (void)hipGetLastError();
     }
 };
 
-// Where a caller array is cut in two for registration in two goes (progressive pinning, see
-// sdpa_attention_f64): a page boundary, so that the two registered ranges share no page.  A copy
-// that straddles the cut is issued in two parts -- the runtime only treats a host range as
-// page-locked when it lies inside ONE registration.
+// Progressive page-locking registers a caller array in several goes (see sdpa_attention_f64), each a
+// range between two page boundaries, so that no two registrations share a page.  A copy that
+// straddles such a boundary is issued in parts -- the runtime only treats a host range as
+// page-locked when it lies inside ONE registration.  `cuts` = the boundaries inside the array, sorted.
+hipError_t copy_h2d_cuts(void *dst, const void *src, size_t bytes, const std::vector<const char *> &cuts,
+                         hipStream_t st) {
+    const char *s0 = (const char *)src, *end = s0 + bytes;
+    char *d0 = (char *)dst;
+    for (const char *cut : cuts) {
+        if (cut <= s0) continue;
+        if (cut >= end) break;
+        const size_t head = (size_t)(cut - s0);
+        hipError_t e = hipMemcpyAsync(d0, s0, head, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return e;
+        d0 += head;
+        s0 = cut;
+    }
+    return hipMemcpyAsync(d0, s0, (size_t)(end - s0), hipMemcpyHostToDevice, st);
+}
+
+// the registration boundaries of the call in flight (set before any copy is enqueued, read-only after)
 struct PinCuts {
-    const char *k = nullptr, *v = nullptr;
+    std::vector<const char *> k, v;
 };
 PinCuts &CUT = *new PinCuts;
-
-hipError_t copy_h2d_cut(void *dst, const void *src, size_t bytes, const char *cut, hipStream_t st) {
-    const char *s0 = (const char *)src;
-    if (cut && s0 < cut && cut < s0 + bytes) {
-        const size_t head = (size_t)(cut - s0);
-        hipError_t e = hipMemcpyAsync(dst, s0, head, hipMemcpyHostToDevice, st);
-        if (e != hipSuccess) return e;
-        return hipMemcpyAsync((char *)dst + head, cut, bytes - head, hipMemcpyHostToDevice, st);
-    }
-    return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
-}
 
 // Whatever path leaves sdpa_attention_f64 -- also an error in the middle of the pipeline -- no
 // queued copy, kernel or collective may still reference the caller's arrays when they are
@@ -197,6 +279,9 @@ struct RankPlan {
 struct Plan {
     int m, n, dk, dv;
     bool bf16, qrows, collectives, merge_allreduce;
+    bool egress_scatter;              // collectives: reduce-SCATTER the merged contributions, every rank widens and
+                                      // sends its rows of the batch home over its own PCIe link;
+                                      // false: the reference's reduce to the root (attention-mpi.c:380), $SDPA_EGRESS=root
     int P;
     int B, nb;                        // rows per Q batch, batches (over the largest row range)
     int row_pieces, piece_min_rows;   // row pieces of the first / last batch (1 = off)
@@ -268,6 +353,8 @@ void make_plan(Plan &pl, int m, int n, int dk, int dv, int flags, int ranks = 0)
     if (const char *v = getenv("SDPA_MERGE")) pl.merge_allreduce = pl.merge_allreduce || strcmp(v, "allreduce") == 0;
     const bool force = getenv("SDPA_FORCE_COLLECTIVES") && atoi(getenv("SDPA_FORCE_COLLECTIVES")) != 0;
     pl.collectives = !pl.qrows && (pl.P > 1 || force) && (ranks > 0 || E.coll != nullptr);
+    const char *egress = getenv("SDPA_EGRESS");
+    pl.egress_scatter = pl.collectives && pl.P > 1 && !(egress && strcmp(egress, "root") == 0);
 
     pl.ldo = round4(dv);
     if (pl.bf16) {
@@ -370,17 +457,21 @@ int ensure_buffers(const Plan &pl) {
         SDPA_TRY(ensure(rk.ws, rp.ws_bytes));
         const size_t B = (size_t)pl.B;
         if (rp.n_slots > 1) SDPA_TRY(ensure(rk.slots, (size_t)rp.n_slots * B * (pl.ldo + 2) * sizeof(float)));
-        const bool finisher = !pl.collectives || g == 0;
+        // rows of a batch a rank sends home: all of them (it finishes its own rows, or it is the root of
+        // the reduce), or its 1/P share of the reduce-scatter
+        const size_t share = (B + pl.P - 1) / pl.P;
+        const size_t out_rows = !pl.collectives ? B : pl.egress_scatter ? share : (g == 0 ? B : 0);
         for (int s = 0; s < 2; ++s) {
             SDPA_TRY(ensure(rk.q64[s], B * pl.dk * sizeof(double)));
             SDPA_TRY(ensure(rk.qf[s], B * pl.ldq * pl.q_elem));
-            SDPA_TRY(ensure(rk.contrib[s], B * pl.ldo * sizeof(float)));
+            // (+P rows: the reduce-scatter sends P equal shares, the last ones padded past the batch)
+            SDPA_TRY(ensure(rk.contrib[s], (B + pl.P) * pl.ldo * sizeof(float)));
             SDPA_TRY(ensure(rk.stat[s], 2 * B * sizeof(float)));
             if (pl.collectives) {
                 SDPA_TRY(ensure(rk.gstat[s], (pl.merge_allreduce ? 2 : 2 * (size_t)pl.P) * B * sizeof(float)));
-                if (g == 0) SDPA_TRY(ensure(rk.red[s], B * pl.ldo * sizeof(float)));
+                if (out_rows) SDPA_TRY(ensure(rk.red[s], out_rows * pl.ldo * sizeof(float)));
             }
-            if (finisher) SDPA_TRY(ensure(rk.out64[s], B * pl.dv * sizeof(double)));
+            if (out_rows) SDPA_TRY(ensure(rk.out64[s], out_rows * pl.dv * sizeof(double)));
         }
         while (rk.ev_kv.size() < rp.chunks.size() + 1) {
             hipEvent_t e;
@@ -488,8 +579,8 @@ int stage_half(const Plan &pl, Rank &rk, const RankPlan &rp, const double *src, 
     const int cols = is_v ? pl.dv : pl.dk;
     double *stage = (double *)(is_v ? rk.v64.p : rk.k64.p) + (size_t)ch.k0 * cols;
     hipEvent_t copied = rk.ev_h2d[2 * c + (is_v ? 1 : 0)];
-    HIP_TRY(copy_h2d_cut(stage, src + row0 * cols, (size_t)ch.keys * cols * sizeof(double), is_v ? CUT.v : CUT.k,
-                         rk.s_cp));
+    HIP_TRY(copy_h2d_cuts(stage, src + row0 * cols, (size_t)ch.keys * cols * sizeof(double), is_v ? CUT.v : CUT.k,
+                          rk.s_cp));
     HIP_TRY(hipEventRecord(copied, rk.s_cp));
     HIP_TRY(hipStreamWaitEvent(rk.s_in, copied, 0));
     if (!is_v) {
@@ -556,6 +647,372 @@ int coll_fail() {
     return SDPA_ERCCL;
 }
 
+// ---- one sdpa_attention_f64 call ---------------------------------------------------------------
+void cpu_relax() {
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+}
+
+struct Call {
+    const double *Q = nullptr, *K = nullptr, *V = nullptr;
+    double *result = nullptr;
+    int m = 0, n = 0, dk = 0, dv = 0;
+    Plan pl;
+    double t_enter = 0.0;
+    HostPins pins;
+    bool do_pin = true, progressive = false, threaded = false;
+    size_t k_bytes = 0, v_bytes = 0;
+    // progressive page-locking: what the first copies of every rank need (stage 0) and the rest of K/V (stage 2)
+    std::vector<std::pair<const char *, size_t>> pin0, pin2;
+    std::atomic<int> pin_done{-1};                 // highest registration stage completed (0..3)
+    std::atomic<int> enq[sdpa::kMaxRanks];         // batches rank g has completely enqueued
+    std::atomic<int> tails{0};                     // batches whose collective tail is enqueued
+    std::atomic<int> failed{0};                    // first error of any thread
+    double first_kernel_us[sdpa::kMaxRanks] = {};  // entry -> rank g's first fused launch enqueued (host clock)
+    int n_brackets = 0, last_splits = 1;           // rank 0's enqueue thread only
+    Call() { for (auto &e : enq) e.store(0); }
+    int fail(int code) {
+        int none = 0;
+        failed.compare_exchange_strong(none, code);
+        return code;
+    }
+};
+
+// Page-lock the caller's arrays for the duration of the call.  Copies from pages the driver has never
+// seen run at ~11 GB/s on this platform (tools/probes/h2d_probe.cpp); registered ones at ~57 GB/s and
+// truly asynchronously, which the enqueue-then-wait structure relies on for its overlap (it stays
+// correct without).  Registering costs ~3.8 us per MiB of host time, so it is done PROGRESSIVELY, in
+// the order the copies need it: stage 0 = the first K/V chunk of every rank (page-aligned hulls),
+// 1 = Q, 2 = the K/V remainders, 3 = `result` (whose pages a caller has typically never touched:
+// registering faults them in).  One rank: the calling thread registers each stage right behind the
+// enqueue of the work it does not gate -- the GPU works while the host registers.  P ranks: the calling
+// thread registers stage after stage while the ranks' threads enqueue; a thread waits for a stage only
+// in front of the copies that need it.  Nothing stays registered after the call.
+void pin_stage(Call &c, int stage) {
+    if (c.do_pin) {
+        if (!c.progressive) {
+            if (stage == 0) {
+                c.pins.add(c.K, c.k_bytes);
+                c.pins.add(c.V, c.v_bytes);
+                c.pins.add(c.Q, (size_t)c.m * c.dk * sizeof(double));
+                c.pins.add(c.result, (size_t)c.m * c.dv * sizeof(double));
+            }
+        } else {
+            switch (stage) {
+                case 0: for (auto &r : c.pin0) c.pins.add(r.first, r.second); break;
+                case 1: c.pins.add(c.Q, (size_t)c.m * c.dk * sizeof(double)); break;
+                case 2: for (auto &r : c.pin2) c.pins.add(r.first, r.second); break;
+                default: c.pins.add(c.result, (size_t)c.m * c.dv * sizeof(double)); break;
+            }
+        }
+    }
+    c.pin_done.store(stage, std::memory_order_release);
+}
+
+// in front of the copies that need registration stage `stage`
+void need_pin(Call &c, int stage) {
+    if (!c.threaded) {
+        for (int st = c.pin_done.load(std::memory_order_relaxed) + 1; st <= stage; ++st) pin_stage(c, st);
+        return;
+    }
+    while (c.pin_done.load(std::memory_order_acquire) < stage && !c.failed.load(std::memory_order_relaxed)) cpu_relax();
+}
+
+// The registration plan of a K/V-sharded call: per array, the page-aligned hull of every rank's first
+// chunk (stage 0), the gaps between the hulls (stage 2) and the boundaries a copy must be split at.
+bool plan_progressive_pins(Call &c) {
+    const Plan &pl = c.pl;
+    if (pl.qrows) return false;
+    auto one = [&](const double *base, int cols, size_t total, std::vector<const char *> &cuts) -> bool {
+        const uintptr_t b0 = (uintptr_t)base, end = b0 + total;
+        uintptr_t prev_hi = b0;
+        bool first = true;
+        for (int g = 0; g < pl.P; ++g) {
+            const RankPlan &rp = pl.r[g];
+            if (rp.key_cnt <= 0) continue;
+            if (rp.chunks.size() < 2) return false;            // nothing to stream behind: register up front
+            const size_t row = (size_t)cols * sizeof(double);
+            uintptr_t lo = first ? b0 : ((b0 + (size_t)rp.key_off * row) & ~(uintptr_t)4095);
+            uintptr_t hi = (b0 + ((size_t)rp.key_off + rp.chunks[0].keys) * row + 4095) & ~(uintptr_t)4095;
+            if (hi > end) hi = end;
+            if (lo < prev_hi) lo = prev_hi;
+            if (hi <= lo) return false;
+            if (lo > prev_hi) c.pin2.push_back({(const char *)prev_hi, (size_t)(lo - prev_hi)});
+            c.pin0.push_back({(const char *)lo, (size_t)(hi - lo)});
+            if (lo > b0) cuts.push_back((const char *)lo);
+            if (hi < end) cuts.push_back((const char *)hi);
+            prev_hi = hi;
+            first = false;
+        }
+        if (first) return false;
+        if (prev_hi < end) c.pin2.push_back({(const char *)prev_hi, (size_t)(end - prev_hi)});
+        return true;
+    };
+    std::vector<const char *> kc, vc;
+    if (!one(c.K, c.dk, c.k_bytes, kc) || !one(c.V, c.dv, c.v_bytes, vc)) {
+        c.pin0.clear();
+        c.pin2.clear();
+        return false;
+    }
+    CUT.k = kc;
+    CUT.v = vc;
+    return true;
+}
+
+// Everything rank g enqueues for Q batch b: its inputs (K/V chunks with the first batch), the fused
+// launches, and -- when it finishes its rows itself (no merge collective) -- finish + D2H.
+int rank_batch(Call &c, int g, int b) {
+    const Plan &pl = c.pl;
+    Rank &rk = E.r[g];
+    Rank &root = E.r[0];
+    const RankPlan &rp = pl.r[g];
+    const int s = b & 1, dv = c.dv;
+    const int j_lo = b * pl.B;
+    if (j_lo >= rp.row_cnt) return SDPA_OK;                  // this rank has no rows left
+    const int bs = std::min(pl.B, rp.row_cnt - j_lo);
+    const size_t i0 = (size_t)rp.row_off + j_lo;             // first global query row
+    const int C = (int)rp.chunks.size();
+    HIP_TRY(hipSetDevice(rk.dev));
+
+    auto bracket = [&]() -> int {              // timing event on rank 0's compute stream
+        if (g != 0) return SDPA_OK;
+        if ((int)root.ev_k.size() <= c.n_brackets) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            root.ev_k.push_back(e);
+        }
+        HIP_TRY(hipEventRecord(root.ev_k[c.n_brackets++], root.s_run));
+        return SDPA_OK;
+    };
+
+    const bool finisher = !pl.collectives;               // finishes its own rows on this rank
+    const bool last_batch = j_lo + pl.B >= rp.row_cnt;   // of this rank
+    const bool head_pieces = b == 0;                     // Q arrives in row pieces
+    const bool tail_pieces = last_batch && finisher;     // rows leave in row pieces
+    const int pr = (head_pieces || tail_pieces) ? piece_rows_of(pl, bs) : bs;
+    const int pieces = (bs + pr - 1) / pr;
+
+    // copy + convert streams: K/V chunk 0, then the Q batch (in pieces for batch 0).  q64[s] was last
+    // read by the convert of batch b-2 (ev_q[s]); qf[s] by its kernels (ev_run[s]).
+    if (b == 0 && C > 0) {
+        need_pin(c, 0);
+        SDPA_TRY(stage_chunk(pl, rk, rp, g, c.K, c.V, 0));
+    }
+    need_pin(c, 1);
+    if (b >= 2) {
+        HIP_TRY(hipStreamWaitEvent(rk.s_cp, rk.ev_q[s], 0));
+        HIP_TRY(hipStreamWaitEvent(rk.s_in, rk.ev_run[s], 0));
+    }
+    if (head_pieces) {
+        for (int j = 0; j < pieces; ++j)
+            SDPA_TRY(stage_q_rows(pl, rk, c.Q, s, i0, j * pr, std::min(pr, bs - j * pr), rk.ev_qh[j], rk.ev_qp[j]));
+        HIP_TRY(hipEventRecord(rk.ev_q[s], rk.s_in));
+    } else {
+        SDPA_TRY(stage_q_rows(pl, rk, c.Q, s, i0, 0, bs, rk.ev_qh[0], rk.ev_q[s]));
+    }
+    // the chunks behind the first: enqueued AFTER chunk 0's launches (see below), so that a rank's first
+    // kernel is issued before the host spends time on the K/V remainders' registration
+    bool rest_staged = b != 0;
+    auto stage_rest = [&]() -> int {
+        if (rest_staged) return SDPA_OK;
+        rest_staged = true;
+        need_pin(c, 2);
+        for (int ch = 1; ch < C; ++ch) SDPA_TRY(stage_chunk(pl, rk, rp, g, c.K, c.V, ch));
+        if (g == 0) HIP_TRY(hipEventRecord(rk.ev_kv_done, rk.s_in));
+        return SDPA_OK;
+    };
+
+    // compute stream.  contrib[s] / stat[s] / out64[s] were last used by batch b-2: by its finish + D2H
+    // (ev_out[s]) when this rank finishes its rows itself, by its collective tail on the comm stream
+    // (ev_comm[s], recorded by the calling thread: wait until that tail has been ENQUEUED) otherwise.
+    if (b >= 2) {
+        if (finisher) {
+            HIP_TRY(hipStreamWaitEvent(rk.s_run, rk.ev_out[s], 0));
+        } else {
+            while (c.tails.load(std::memory_order_acquire) < b - 1) {
+                if (c.failed.load(std::memory_order_relaxed)) return SDPA_EHIP;
+                cpu_relax();
+            }
+            HIP_TRY(hipStreamWaitEvent(rk.s_run, rk.ev_comm[s], 0));
+        }
+    }
+    const bool streamed = b == 0 && rp.n_slots > 1;
+    bool have_all_q = false;
+    auto need_all_q = [&]() -> int {
+        if (!have_all_q) HIP_TRY(hipStreamWaitEvent(rk.s_run, rk.ev_q[s], 0));
+        have_all_q = true;
+        return SDPA_OK;
+    };
+    // rows [j0, j0+jr) are complete in contrib[s]/stat[s]: step 5 with gsum = lsum fused with the
+    // fp64 writeback (attention-mpi.c:358-362, :373), then they go home
+    auto finish_rows = [&](int ev, int j0, int jr) -> int {
+        need_pin(c, 3);                  // behind the enqueue of (nearly) all of the batch's kernels
+        HIP_TRY(sdpa::launch_finish_f64((const float *)rk.contrib[s].p + (size_t)j0 * pl.ldo, pl.ldo,
+                                        (const float *)rk.stat[s].p + bs + j0,
+                                        (double *)rk.out64[s].p + (size_t)j0 * dv, jr, dv, rk.s_run));
+        HIP_TRY(hipEventRecord(rk.ev_sub[s][ev], rk.s_run));
+        HIP_TRY(hipStreamWaitEvent(rk.s_out, rk.ev_sub[s][ev], 0));
+        HIP_TRY(hipMemcpyAsync(c.result + (i0 + j0) * dv, (double *)rk.out64[s].p + (size_t)j0 * dv,
+                               (size_t)jr * dv * sizeof(double), hipMemcpyDeviceToHost, rk.s_out));
+        return SDPA_OK;
+    };
+
+    const int n_launch_chunks = streamed ? C : 1;
+    for (int ch = 0; ch < n_launch_chunks; ++ch) {
+        const bool first = ch == 0, last = ch + 1 == n_launch_chunks;
+        const bool in_pieces = pieces > 1 && ((first && head_pieces) || (last && tail_pieces));
+        const int k0 = streamed ? rp.chunks[ch].k0 : 0;
+        const int keys = streamed ? rp.chunks[ch].keys : rp.key_cnt;
+        // a launch that needs chunks behind the first (a later chunk, or the whole shard at once)
+        if (!(streamed && first)) SDPA_TRY(stage_rest());
+        if (b == 0 && C > 0) HIP_TRY(hipStreamWaitEvent(rk.s_run, rk.ev_kv[streamed ? ch : C - 1], 0));
+        const int np = in_pieces ? pieces : 1;
+        for (int j = 0; j < np; ++j) {
+            const int j0 = in_pieces ? j * pr : 0, jr = in_pieces ? std::min(pr, bs - j0) : bs;
+            if (first && head_pieces && in_pieces)
+                HIP_TRY(hipStreamWaitEvent(rk.s_run, rk.ev_qp[j], 0));
+            else
+                SDPA_TRY(need_all_q());
+            int sp, slot0 = -1;
+            if (streamed) {
+                sp = rp.chunks[ch].splits;                // the slot count was planned for this launch shape
+                slot0 = rp.chunks[ch].slot0;
+            } else {
+                sp = keys > 0 ? pick_splits(pl, jr, keys) : 1;
+            }
+            SDPA_TRY(bracket());
+            SDPA_TRY(launch_fused(pl, rk, rp, s, bs, j0, jr, k0, keys, sp, slot0));
+            SDPA_TRY(bracket());
+            if (c.first_kernel_us[g] == 0.0) c.first_kernel_us[g] = now_us() - c.t_enter;
+            if (g == 0) c.last_splits = sp;
+            if (last) {
+                if (streamed) SDPA_TRY(merge_slots(pl, rk, rp, s, bs, j0, jr));
+                if (finisher) SDPA_TRY(finish_rows(in_pieces ? j : 0, j0, jr));
+            }
+        }
+    }
+    SDPA_TRY(stage_rest());
+    HIP_TRY(hipEventRecord(rk.ev_run[s], rk.s_run));
+    if (finisher) HIP_TRY(hipEventRecord(rk.ev_out[s], rk.s_out));
+    return SDPA_OK;
+}
+
+// K/V plan over P ranks: merge the shard-local triples of batch b (attention-mpi.c:340-380) on the
+// ranks' COMM streams -- batch b+1's fused kernels are already running on the compute streams, the
+// way the reference leaves its MPI_Ireduce in flight under the next batch (:364-380).
+int tail_batch(Call &c, int b) {
+    const Plan &pl = c.pl;
+    const int P = pl.P, s = b & 1, dv = c.dv;
+    Rank &root = E.r[0];
+    const int bs = std::min(pl.B, c.m - b * pl.B);
+    const size_t i0 = (size_t)b * pl.B;
+    std::vector<float *> send(P), recv(P);
+    std::vector<hipStream_t> comm(P);
+    for (int g = 0; g < P; ++g) {
+        Rank &rk = E.r[g];
+        comm[g] = rk.s_comm;
+        HIP_TRY(hipSetDevice(rk.dev));
+        HIP_TRY(hipStreamWaitEvent(rk.s_comm, rk.ev_run[s], 0));     // the rank's partial triple of batch b
+        if (b >= 2) HIP_TRY(hipStreamWaitEvent(rk.s_comm, rk.ev_out[s], 0));   // out64[s] of batch b-2 still leaving
+    }
+    if (pl.merge_allreduce) {
+        // :342 gmax = allreduce MAX(lmax); :346-351 rescale; :354 gsum = allreduce SUM(lsum);
+        // :358-362 normalise
+        for (int g = 0; g < P; ++g) {
+            send[g] = (float *)E.r[g].stat[s].p;
+            recv[g] = (float *)E.r[g].gstat[s].p;
+        }
+        if (E.coll->all_reduce(send.data(), recv.data(), bs, RedOp::Max, comm.data())) return coll_fail();
+        for (int g = 0; g < P; ++g) {
+            Rank &rk = E.r[g];
+            HIP_TRY(hipSetDevice(rk.dev));
+            HIP_TRY(sdpa::launch_merge_rescale((float *)rk.contrib[s].p, pl.ldo, (float *)rk.stat[s].p + bs,
+                                               (const float *)rk.stat[s].p, (const float *)rk.gstat[s].p, bs,
+                                               dv, rk.s_comm));
+            send[g] = (float *)rk.stat[s].p + bs;
+            recv[g] = (float *)rk.gstat[s].p + bs;
+        }
+        if (E.coll->all_reduce(send.data(), recv.data(), bs, RedOp::Sum, comm.data())) return coll_fail();
+        for (int g = 0; g < P; ++g) {
+            Rank &rk = E.r[g];
+            HIP_TRY(hipSetDevice(rk.dev));
+            HIP_TRY(sdpa::launch_merge_normalise((float *)rk.contrib[s].p, pl.ldo,
+                                                 (const float *)rk.gstat[s].p + bs, bs, dv, rk.s_comm));
+        }
+    } else {
+        // one all-gather of the (lmax, lsum) pairs, then steps 2-5 in one pass on every rank
+        for (int g = 0; g < P; ++g) {
+            send[g] = (float *)E.r[g].stat[s].p;
+            recv[g] = (float *)E.r[g].gstat[s].p;
+        }
+        if (E.coll->all_gather(send.data(), recv.data(), 2 * (size_t)bs, comm.data())) return coll_fail();
+        for (int g = 0; g < P; ++g) {
+            Rank &rk = E.r[g];
+            HIP_TRY(hipSetDevice(rk.dev));
+            HIP_TRY(sdpa::launch_merge_gathered((float *)rk.contrib[s].p, pl.ldo, (const float *)rk.gstat[s].p,
+                                                P, g, bs, dv, rk.s_comm));
+        }
+    }
+    need_pin(c, 3);
+    for (int g = 0; g < P; ++g) send[g] = (float *)E.r[g].contrib[s].p;
+    if (pl.egress_scatter) {
+        // sum of the normalised contributions, SCATTERED: rank r receives rows [r*share, (r+1)*share) of the
+        // batch, widens them (:373/:396) and sends them home over its own PCIe link -- P links instead of
+        // the root's one (the reference funnels to rank 0 because an MPI rank has no other way, :379-380)
+        const int share = (bs + P - 1) / P;
+        for (int g = 0; g < P; ++g) recv[g] = (float *)E.r[g].red[s].p;
+        if (E.coll->reduce_scatter_sum(send.data(), recv.data(), (size_t)share * pl.ldo, comm.data())) return coll_fail();
+        for (int g = 0; g < P; ++g) {
+            Rank &rk = E.r[g];
+            const int r0 = g * share, rows = std::min(share, bs - r0);
+            HIP_TRY(hipSetDevice(rk.dev));
+            if (rows > 0)
+                HIP_TRY(sdpa::launch_cvt_f2d((const float *)rk.red[s].p, pl.ldo, (double *)rk.out64[s].p, rows, dv,
+                                             rk.s_comm));
+            HIP_TRY(hipEventRecord(rk.ev_comm[s], rk.s_comm));
+            HIP_TRY(hipStreamWaitEvent(rk.s_out, rk.ev_comm[s], 0));
+            if (rows > 0)
+                HIP_TRY(hipMemcpyAsync(c.result + (i0 + r0) * dv, rk.out64[s].p, (size_t)rows * dv * sizeof(double),
+                                       hipMemcpyDeviceToHost, rk.s_out));
+            HIP_TRY(hipEventRecord(rk.ev_out[s], rk.s_out));
+        }
+    } else {
+        // :380 reduce(SUM) of the normalised contributions to rank 0, :373/:396 widen, D2H
+        if (E.coll->reduce_sum_to_root(send.data(), (float *)root.red[s].p, (size_t)bs * pl.ldo, comm.data()))
+            return coll_fail();
+        HIP_TRY(hipSetDevice(root.dev));
+        HIP_TRY(sdpa::launch_cvt_f2d((const float *)root.red[s].p, pl.ldo, (double *)root.out64[s].p, bs, dv,
+                                     root.s_comm));
+        for (int g = 0; g < P; ++g) {
+            HIP_TRY(hipSetDevice(E.r[g].dev));
+            HIP_TRY(hipEventRecord(E.r[g].ev_comm[s], E.r[g].s_comm));
+            HIP_TRY(hipEventRecord(E.r[g].ev_out[s], E.r[g].s_comm));      // (non-roots: nothing leaves)
+        }
+        HIP_TRY(hipSetDevice(root.dev));
+        HIP_TRY(hipStreamWaitEvent(root.s_out, root.ev_comm[s], 0));
+        HIP_TRY(hipMemcpyAsync(c.result + i0 * dv, root.out64[s].p, (size_t)bs * dv * sizeof(double),
+                               hipMemcpyDeviceToHost, root.s_out));
+        HIP_TRY(hipEventRecord(root.ev_out[s], root.s_out));
+    }
+    return SDPA_OK;
+}
+
+// one rank's enqueue thread: batch after batch, at most one batch ahead of the collective tails
+int rank_thread(void *arg, int g) {
+    Call &c = *(Call *)arg;
+    for (int b = 0; b < c.pl.nb; ++b) {
+        if (c.failed.load(std::memory_order_relaxed)) break;
+        const int rc = rank_batch(c, g, b);
+        if (rc != SDPA_OK) {
+            c.fail(rc);
+            break;
+        }
+        c.enq[g].store(b + 1, std::memory_order_release);
+    }
+    return SDPA_OK;
+}
+
 int lazy_init() {
     if (E.up) return SDPA_OK;
     int want = 1;                       // several GPUs from one process is opt-in
@@ -595,7 +1052,7 @@ void destroy_rank(Rank &g) {
     for (int s = 0; s < 2; ++s) {
         DevBuf *pair[] = {&g.q64[s], &g.qf[s], &g.contrib[s], &g.stat[s], &g.gstat[s], &g.red[s], &g.out64[s]};
         for (DevBuf *b : pair) if (b->p) (void)hipFree(b->p);
-        hipEvent_t evs[] = {g.ev_q[s], g.ev_run[s], g.ev_out[s]};
+        hipEvent_t evs[] = {g.ev_q[s], g.ev_run[s], g.ev_out[s], g.ev_comm[s]};
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : g.ev_sub[s]) if (e) (void)hipEventDestroy(e);
     }
@@ -610,6 +1067,7 @@ void destroy_rank(Rank &g) {
     if (g.s_in) (void)hipStreamDestroy(g.s_in);
     if (g.s_run) (void)hipStreamDestroy(g.s_run);
     if (g.s_out) (void)hipStreamDestroy(g.s_out);
+    if (g.s_comm) (void)hipStreamDestroy(g.s_comm);
     g = Rank();
 }
 
@@ -623,7 +1081,9 @@ int create_rank(Rank &g, int dev) {
     HIP_TRY(hipStreamCreateWithPriority(&g.s_in, hipStreamNonBlocking, hi));
     HIP_TRY(hipStreamCreateWithFlags(&g.s_run, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithPriority(&g.s_out, hipStreamNonBlocking, hi));
+    HIP_TRY(hipStreamCreateWithPriority(&g.s_comm, hipStreamNonBlocking, hi));
     for (int s = 0; s < 2; ++s) {
+        HIP_TRY(hipEventCreateWithFlags(&g.ev_comm[s], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&g.ev_q[s], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&g.ev_run[s], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&g.ev_out[s], hipEventDisableTiming));
@@ -685,6 +1145,11 @@ int init_impl(int n_gpus) {
         }
         if (!E.coll) return SDPA_ERCCL;
     }
+    if (want > 1 && !(getenv("SDPA_ENQUEUE_THREADS") && atoi(getenv("SDPA_ENQUEUE_THREADS")) == 0)) {
+        std::vector<int> devs(want);
+        for (int i = 0; i < want; ++i) devs[i] = E.r[i].dev;
+        E.pool.start(want, devs);
+    }
     E.n = want;
     E.up = true;
     return SDPA_OK;
@@ -700,6 +1165,7 @@ extern "C" {
 void sdpa_shutdown(void) {
     DeviceRestore restore;
     PF.reset();
+    E.pool.shutdown();
     for (Rank &g : E.r) destroy_rank(g);
     E.r.clear();
     delete E.coll;
@@ -714,6 +1180,7 @@ int sdpa_init(int n_gpus) {
     DeviceRestore restore;
     const int rc = init_impl(n_gpus);
     if (rc != SDPA_OK && !E.up) {        // a half-built engine is torn down, not leaked
+        E.pool.shutdown();
         for (Rank &g : E.r) destroy_rank(g);
         E.r.clear();
         delete E.coll;
@@ -739,7 +1206,11 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
     DeviceRestore restore;
     SDPA_TRY(lazy_init());
 
-    Plan pl;
+    Call c;
+    c.Q = Q; c.K = K; c.V = V; c.result = result;
+    c.m = m; c.n = n; c.dk = dk; c.dv = dv;
+    c.t_enter = t_enter;
+    Plan &pl = c.pl;
     make_plan(pl, m, n, dk, dv, flags);
     SDPA_TRY(check_plan(pl));
     SDPA_TRY(ensure_buffers(pl));
@@ -754,254 +1225,60 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
     }
     struct ClearPrefetch { ~ClearPrefetch() { PF.reset(); } } clear_prefetch;   // one-shot, also on errors
 
-    // Page-lock the caller's arrays for the duration of the call.  Copies from pages the driver
-    // has never seen run at ~11 GB/s on this platform (measured, tools/probes/h2d_probe.cpp);
-    // registered ones at ~57 GB/s and truly asynchronously, which the whole enqueue-then-wait
-    // structure below relies on for its overlap (it stays correct without).  Nothing stays
-    // registered after the call (no pointer is retained).
-    //
-    // Progressive pinning (one rank, streamed K/V): registering costs ~3.8 us per MiB of host time
-    // (0.85 ms for the metric shape's 224 MiB), so only what the FIRST copies need is registered up
-    // front -- K/V chunk 0 (cut at a page boundary) -- and the rest right behind the enqueue of the
-    // work it does not gate: Q behind chunk 0's copies, the K/V remainders behind Q's, `result` (whose
-    // pages a caller has typically never touched: registering it faults them in) right before the
-    // first rows go home, when the batch's kernels are already queued.  The GPU works while the host
-    // registers.
-    HostPins pins;
+    // Destruction order on every exit: first the ranks' enqueue threads are waited for (they use `c`),
+    // then every device is drained (no queued copy may still reference the caller's arrays), then
+    // c.pins unregisters them.
     DrainOnExit drain;
+    struct JoinThreads {
+        Call &c;
+        bool running = false;
+        ~JoinThreads() {
+            if (!running) return;
+            c.fail(SDPA_EHIP);               // (a no-op after a clean finish: everything is enqueued by then)
+            E.pool.wait();
+        }
+    } join{c};
     struct ClearCuts { ~ClearCuts() { CUT = PinCuts(); } } clear_cuts;
     CUT = PinCuts();
-    const bool do_pin = !getenv("SDPA_HOST_REGISTER") || atoi(getenv("SDPA_HOST_REGISTER")) != 0;
-    const size_t k_bytes = (size_t)n * dk * sizeof(double), v_bytes = (size_t)n * dv * sizeof(double);
-    bool progressive = false;
+    c.do_pin = !getenv("SDPA_HOST_REGISTER") || atoi(getenv("SDPA_HOST_REGISTER")) != 0;
+    c.k_bytes = (size_t)n * dk * sizeof(double);
+    c.v_bytes = (size_t)n * dv * sizeof(double);
     const bool want_progressive = !getenv("SDPA_PROGRESSIVE_PIN") || atoi(getenv("SDPA_PROGRESSIVE_PIN")) != 0;
-    if (do_pin && P == 1 && pl.r[0].chunks.size() > 1 && !PF.active && want_progressive) {
-        const size_t c0 = (size_t)pl.r[0].chunks[0].keys;
-        auto cut_of = [](const double *base, size_t head_bytes, size_t total) -> const char * {
-            const uintptr_t c = ((uintptr_t)base + head_bytes + 4095) & ~(uintptr_t)4095;
-            return c < (uintptr_t)base + total ? (const char *)c : nullptr;
-        };
-        CUT.k = cut_of(K, c0 * dk * sizeof(double), k_bytes);
-        CUT.v = cut_of(V, c0 * dv * sizeof(double), v_bytes);
-        progressive = CUT.k && CUT.v;
-        if (!progressive) CUT = PinCuts();
-    }
-    // stage 0: before the first copy is enqueued; 1: behind K/V chunk 0; 2: behind Q; 3: before the first D2H
-    auto pin_stage = [&](int stage) {
-        if (!do_pin) return;
-        if (!progressive) {
-            if (stage != 0) return;
-            pins.add(K, k_bytes);
-            pins.add(V, v_bytes);
-            pins.add(Q, (size_t)m * dk * sizeof(double));
-            pins.add(result, (size_t)m * dv * sizeof(double));
-            return;
-        }
-        switch (stage) {
-            case 0:
-                pins.add(K, (size_t)(CUT.k - (const char *)K));
-                pins.add(V, (size_t)(CUT.v - (const char *)V));
-                break;
-            case 1: pins.add(Q, (size_t)m * dk * sizeof(double)); break;
-            case 2:
-                pins.add(CUT.k, k_bytes - (size_t)(CUT.k - (const char *)K));
-                pins.add(CUT.v, v_bytes - (size_t)(CUT.v - (const char *)V));
-                break;
-            default: pins.add(result, (size_t)m * dv * sizeof(double)); break;
-        }
-    };
-    bool result_pinned = false;
-    pin_stage(0);
-    const double t_reg1 = now_us();
+    if (c.do_pin && !PF.active && want_progressive) c.progressive = plan_progressive_pins(c);
+    c.threaded = P > 1 && !E.pool.th.empty();
 
     Rank &root = E.r[0];
     HIP_TRY(hipSetDevice(root.dev));
+    if (!c.threaded) pin_stage(c, 0);
+    const double t_reg1 = now_us();
     HIP_TRY(hipEventRecord(root.ev_t0, root.s_cp));
-    int n_brackets = 0, last_splits = 1;
-    auto bracket = [&](Rank &rk) -> int {      // timing event on rank 0's compute stream
-        if (&rk != &root) return SDPA_OK;
-        if ((int)root.ev_k.size() <= n_brackets) {
-            hipEvent_t e;
-            HIP_TRY(hipEventCreate(&e));
-            root.ev_k.push_back(e);
+
+    if (c.threaded) {
+        // the ranks' threads enqueue; this thread registers the caller's arrays stage by stage, then
+        // enqueues each batch's collective tail as soon as every rank has enqueued the batch's kernels
+        join.running = true;
+        E.pool.run(rank_thread, &c);
+        for (int st = 0; st <= 3; ++st) pin_stage(c, st);
+        int rc = SDPA_OK;
+        for (int b = 0; b < pl.nb && rc == SDPA_OK; ++b) {
+            for (int g = 0; g < P; ++g)
+                while (c.enq[g].load(std::memory_order_acquire) <= b && !c.failed.load(std::memory_order_relaxed)) cpu_relax();
+            if (c.failed.load()) break;
+            if (pl.collectives) rc = tail_batch(c, b);
+            c.tails.store(b + 1, std::memory_order_release);
         }
-        HIP_TRY(hipEventRecord(root.ev_k[n_brackets++], root.s_run));
-        return SDPA_OK;
-    };
-
-    std::vector<float *> send(P), recv(P);
-    std::vector<hipStream_t> runs(P);
-    for (int g = 0; g < P; ++g) runs[g] = E.r[g].s_run;
-
-    for (int b = 0; b < pl.nb; ++b) {
-        const int s = b & 1;
-
-        // ---- per rank: inputs of this batch, then its fused launches --------------------
-        for (int g = 0; g < P; ++g) {
-            Rank &rk = E.r[g];
-            const RankPlan &rp = pl.r[g];
-            const int j_lo = b * pl.B;
-            if (j_lo >= rp.row_cnt) continue;                    // this rank has no rows left
-            const int bs = std::min(pl.B, rp.row_cnt - j_lo);
-            const size_t i0 = (size_t)rp.row_off + j_lo;         // first global query row
-            const int C = (int)rp.chunks.size();
-            HIP_TRY(hipSetDevice(rk.dev));
-
-            const bool finisher = !pl.collectives;               // finishes its own rows on this rank
-            const bool last_batch = j_lo + pl.B >= rp.row_cnt;   // of this rank
-            const bool head_pieces = b == 0;                     // Q arrives in row pieces
-            const bool tail_pieces = last_batch && finisher;     // rows leave in row pieces
-            const int pr = (head_pieces || tail_pieces) ? piece_rows_of(pl, bs) : bs;
-            const int pieces = (bs + pr - 1) / pr;
-
-            // copy + convert streams: K/V chunk 0, the Q batch (in pieces for batch 0), the remaining
-            // chunks.  q64[s] was last read by the convert of batch b-2 (ev_q[s]); qf[s] by its
-            // kernels (ev_run[s]).
-            if (b == 0 && C > 0) SDPA_TRY(stage_chunk(pl, rk, rp, g, K, V, 0));
-            if (b == 0) pin_stage(1);
-            if (b >= 2) {
-                HIP_TRY(hipStreamWaitEvent(rk.s_cp, rk.ev_q[s], 0));
-                HIP_TRY(hipStreamWaitEvent(rk.s_in, rk.ev_run[s], 0));
-            }
-            if (head_pieces) {
-                for (int j = 0; j < pieces; ++j)
-                    SDPA_TRY(stage_q_rows(pl, rk, Q, s, i0, j * pr, std::min(pr, bs - j * pr), rk.ev_qh[j], rk.ev_qp[j]));
-                HIP_TRY(hipEventRecord(rk.ev_q[s], rk.s_in));
-            } else {
-                SDPA_TRY(stage_q_rows(pl, rk, Q, s, i0, 0, bs, rk.ev_qh[0], rk.ev_q[s]));
-            }
-            if (b == 0) {
-                pin_stage(2);
-                for (int c = 1; c < C; ++c) SDPA_TRY(stage_chunk(pl, rk, rp, g, K, V, c));
-                if (g == 0) HIP_TRY(hipEventRecord(rk.ev_kv_done, rk.s_in));
-            }
-
-            // compute stream
-            if (b >= 2) HIP_TRY(hipStreamWaitEvent(rk.s_run, rk.ev_out[s], 0));   // out64[s] still leaving
-            const bool streamed = b == 0 && rp.n_slots > 1;
-            bool have_all_q = false;
-            auto need_all_q = [&]() -> int {
-                if (!have_all_q) HIP_TRY(hipStreamWaitEvent(rk.s_run, rk.ev_q[s], 0));
-                have_all_q = true;
-                return SDPA_OK;
-            };
-            // rows [j0, j0+jr) are complete in contrib[s]/stat[s]: step 5 with gsum = lsum fused with
-            // the fp64 writeback (attention-mpi.c:358-362, :373), then they go home
-            auto finish_rows = [&](int ev, int j0, int jr) -> int {
-                if (!result_pinned) {        // behind the enqueue of (nearly) all of the batch's kernels
-                    pin_stage(3);
-                    result_pinned = true;
-                }
-                HIP_TRY(sdpa::launch_finish_f64((const float *)rk.contrib[s].p + (size_t)j0 * pl.ldo, pl.ldo,
-                                                (const float *)rk.stat[s].p + bs + j0,
-                                                (double *)rk.out64[s].p + (size_t)j0 * dv, jr, dv, rk.s_run));
-                HIP_TRY(hipEventRecord(rk.ev_sub[s][ev], rk.s_run));
-                HIP_TRY(hipStreamWaitEvent(rk.s_out, rk.ev_sub[s][ev], 0));
-                HIP_TRY(hipMemcpyAsync(result + (i0 + j0) * dv, (double *)rk.out64[s].p + (size_t)j0 * dv,
-                                       (size_t)jr * dv * sizeof(double), hipMemcpyDeviceToHost, rk.s_out));
-                return SDPA_OK;
-            };
-
-            const int n_launch_chunks = streamed ? C : 1;
-            for (int c = 0; c < n_launch_chunks; ++c) {
-                const bool first = c == 0, last = c + 1 == n_launch_chunks;
-                const bool in_pieces = pieces > 1 && ((first && head_pieces) || (last && tail_pieces));
-                const int k0 = streamed ? rp.chunks[c].k0 : 0;
-                const int keys = streamed ? rp.chunks[c].keys : rp.key_cnt;
-                if (b == 0 && C > 0) HIP_TRY(hipStreamWaitEvent(rk.s_run, rk.ev_kv[streamed ? c : C - 1], 0));
-                const int np = in_pieces ? pieces : 1;
-                for (int j = 0; j < np; ++j) {
-                    const int j0 = in_pieces ? j * pr : 0, jr = in_pieces ? std::min(pr, bs - j0) : bs;
-                    if (first && head_pieces && in_pieces)
-                        HIP_TRY(hipStreamWaitEvent(rk.s_run, rk.ev_qp[j], 0));
-                    else
-                        SDPA_TRY(need_all_q());
-                    int sp, slot0 = -1;
-                    if (streamed) {
-                        sp = rp.chunks[c].splits;                 // the slot count was planned for this launch shape
-                        slot0 = rp.chunks[c].slot0;
-                    } else {
-                        sp = keys > 0 ? pick_splits(pl, jr, keys) : 1;
-                    }
-                    SDPA_TRY(bracket(rk));
-                    SDPA_TRY(launch_fused(pl, rk, rp, s, bs, j0, jr, k0, keys, sp, slot0));
-                    SDPA_TRY(bracket(rk));
-                    if (g == 0) last_splits = sp;
-                    if (last) {
-                        if (streamed) SDPA_TRY(merge_slots(pl, rk, rp, s, bs, j0, jr));
-                        if (finisher) SDPA_TRY(finish_rows(in_pieces ? j : 0, j0, jr));
-                    }
-                }
-            }
-            if (finisher) {
-                HIP_TRY(hipEventRecord(rk.ev_run[s], rk.s_run));
-                HIP_TRY(hipEventRecord(rk.ev_out[s], rk.s_out));
-            }
+        if (rc != SDPA_OK) c.fail(rc);
+        E.pool.wait();
+        join.running = false;
+        if (c.failed.load()) return c.failed.load();
+    } else {
+        for (int b = 0; b < pl.nb; ++b) {
+            for (int g = 0; g < P; ++g) SDPA_TRY(rank_batch(c, g, b));
+            if (pl.collectives) SDPA_TRY(tail_batch(c, b));
+            c.tails.store(b + 1, std::memory_order_release);
         }
-        if (!pl.collectives) continue;
-
-        // ---- K/V plan over P ranks: merge the shard-local triples (attention-mpi.c:340-380) ----
-        const int bs = std::min(pl.B, m - b * pl.B);
-        const int i0 = b * pl.B;
-        if (pl.merge_allreduce) {
-            // :342 gmax = allreduce MAX(lmax); :346-351 rescale; :354 gsum = allreduce SUM(lsum);
-            // :358-362 normalise
-            for (int g = 0; g < P; ++g) {
-                send[g] = (float *)E.r[g].stat[s].p;
-                recv[g] = (float *)E.r[g].gstat[s].p;
-            }
-            if (E.coll->all_reduce(send.data(), recv.data(), bs, RedOp::Max, runs.data())) return coll_fail();
-            for (int g = 0; g < P; ++g) {
-                Rank &rk = E.r[g];
-                HIP_TRY(hipSetDevice(rk.dev));
-                HIP_TRY(sdpa::launch_merge_rescale((float *)rk.contrib[s].p, pl.ldo, (float *)rk.stat[s].p + bs,
-                                                   (const float *)rk.stat[s].p, (const float *)rk.gstat[s].p, bs,
-                                                   dv, rk.s_run));
-                send[g] = (float *)rk.stat[s].p + bs;
-                recv[g] = (float *)rk.gstat[s].p + bs;
-            }
-            if (E.coll->all_reduce(send.data(), recv.data(), bs, RedOp::Sum, runs.data())) return coll_fail();
-            for (int g = 0; g < P; ++g) {
-                Rank &rk = E.r[g];
-                HIP_TRY(hipSetDevice(rk.dev));
-                HIP_TRY(sdpa::launch_merge_normalise((float *)rk.contrib[s].p, pl.ldo,
-                                                     (const float *)rk.gstat[s].p + bs, bs, dv, rk.s_run));
-            }
-        } else {
-            // one all-gather of the (lmax, lsum) pairs, then steps 2-5 in one pass on every rank
-            for (int g = 0; g < P; ++g) {
-                send[g] = (float *)E.r[g].stat[s].p;
-                recv[g] = (float *)E.r[g].gstat[s].p;
-            }
-            if (E.coll->all_gather(send.data(), recv.data(), 2 * (size_t)bs, runs.data())) return coll_fail();
-            for (int g = 0; g < P; ++g) {
-                Rank &rk = E.r[g];
-                HIP_TRY(hipSetDevice(rk.dev));
-                HIP_TRY(sdpa::launch_merge_gathered((float *)rk.contrib[s].p, pl.ldo, (const float *)rk.gstat[s].p,
-                                                    P, g, bs, dv, rk.s_run));
-            }
-        }
-        // :380 reduce(SUM) of the normalised contributions to rank 0, :373/:396 widen, D2H
-        for (int g = 0; g < P; ++g) send[g] = (float *)E.r[g].contrib[s].p;
-        if (E.coll->reduce_sum_to_root(send.data(), (float *)root.red[s].p, (size_t)bs * pl.ldo, runs.data()))
-            return coll_fail();
-        HIP_TRY(hipSetDevice(root.dev));
-        HIP_TRY(sdpa::launch_cvt_f2d((const float *)root.red[s].p, pl.ldo, (double *)root.out64[s].p, bs, dv,
-                                     root.s_run));
-        for (int g = 0; g < P; ++g) {
-            HIP_TRY(hipSetDevice(E.r[g].dev));
-            HIP_TRY(hipEventRecord(E.r[g].ev_run[s], E.r[g].s_run));
-        }
-        HIP_TRY(hipSetDevice(root.dev));
-        HIP_TRY(hipStreamWaitEvent(root.s_out, root.ev_run[s], 0));
-        if (!result_pinned) {            // (one rank with forced collectives: the rows leave here, not in finish_rows)
-            pin_stage(3);
-            result_pinned = true;
-        }
-        HIP_TRY(hipMemcpyAsync(result + (size_t)i0 * dv, root.out64[s].p, (size_t)bs * dv * sizeof(double),
-                               hipMemcpyDeviceToHost, root.s_out));
-        HIP_TRY(hipEventRecord(root.ev_out[s], root.s_out));
     }
+    const double t_enqueued = now_us();
 
     // ---- the one wait of the call ------------------------------------------------------------
     HIP_TRY(hipSetDevice(root.dev));
@@ -1010,6 +1287,7 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
     for (int g = 0; g < P; ++g) {
         HIP_TRY(hipSetDevice(E.r[g].dev));
         HIP_TRY(hipStreamSynchronize(E.r[g].s_run));
+        HIP_TRY(hipStreamSynchronize(E.r[g].s_comm));
         HIP_TRY(hipStreamSynchronize(E.r[g].s_out));
         HIP_TRY(hipStreamSynchronize(E.r[g].s_in));
         HIP_TRY(hipStreamSynchronize(E.r[g].s_cp));
@@ -1018,6 +1296,7 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
     const double t_exit = now_us();
 
     HIP_TRY(hipSetDevice(root.dev));
+    const int n_brackets = c.n_brackets;
     double kernel_ms = 0.0;
     float ms = 0.f;
     for (int i = 0; i + 1 < n_brackets; i += 2) {
@@ -1027,7 +1306,7 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
     sdpa_timing &T = E.last;
     T = sdpa_timing();
     T.total_us = t_exit - t_enter;
-    T.register_us = pins.us;
+    T.register_us = c.pins.us;
     T.kernel_us = kernel_ms * 1e3;
     if (n_brackets >= 2) {
         const int rank0_chunks = (int)pl.r[0].chunks.size();
@@ -1044,12 +1323,16 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
     }
     T.n_gpus = P;
     T.q_batches = pl.nb;
-    T.kv_splits = last_splits;
+    T.kv_splits = c.last_splits;
     T.kv_chunks = (int)pl.r[0].chunks.size();
     T.fused_launches = n_brackets / 2;
     T.plan = pl.qrows ? 1 : 0;
     T.merge = !pl.collectives ? 0 : (pl.merge_allreduce ? 2 : 1);
     T.virtual_ranks = E.virtual_ranks ? 1 : 0;
+    T.enqueue_total_us = t_enqueued - t_enter;
+    for (int g = 0; g < P && g < 16; ++g) T.enqueue_first_kernel_us[g] = c.first_kernel_us[g];
+    T.egress = !pl.collectives ? 0 : (pl.egress_scatter ? 2 : 1);
+    T.enqueue_threads = c.threaded ? P : 1;
     return SDPA_OK;
 }
 
@@ -1126,8 +1409,9 @@ int sdpa_plan_describe(int m, int n, int dk, int dv, int flags, int ranks, char 
     std::string o;
     char t[256];
     snprintf(t, sizeof t, "{\"ranks\": %d, \"bf16\": %d, \"qrows\": %d, \"collectives\": %d, \"merge_allreduce\": %d, "
-             "\"q_batch\": %d, \"q_batches\": %d, \"row_pieces\": %d, \"piece_min_rows\": %d, \"r\": [",
-             pl.P, pl.bf16 ? 1 : 0, pl.qrows ? 1 : 0, pl.collectives ? 1 : 0, pl.merge_allreduce ? 1 : 0, pl.B, pl.nb,
+             "\"egress\": \"%s\", \"q_batch\": %d, \"q_batches\": %d, \"row_pieces\": %d, \"piece_min_rows\": %d, \"r\": [",
+             pl.P, pl.bf16 ? 1 : 0, pl.qrows ? 1 : 0, pl.collectives ? 1 : 0, pl.merge_allreduce ? 1 : 0,
+             !pl.collectives ? "own rows" : pl.egress_scatter ? "reduce-scatter" : "root", pl.B, pl.nb,
              pl.row_pieces, pl.piece_min_rows);
     o += t;
     for (int g = 0; g < pl.P; ++g) {

@@ -106,7 +106,9 @@ def plan(m, n, dk, dv, flags=0, ranks=1):
 def last_timing():
     t = SdpaTiming()
     check(_lib.load().sdpa_last_timing(ctypes.byref(t)), "sdpa_last_timing")
-    return {k: getattr(t, k) for k, _ in SdpaTiming._fields_}
+    out = {k: getattr(t, k) for k, _ in SdpaTiming._fields_}
+    out["enqueue_first_kernel_us"] = list(out["enqueue_first_kernel_us"])[:max(1, out["n_gpus"])]
+    return out
 
 
 # --------------------------------------------------------------------------------------

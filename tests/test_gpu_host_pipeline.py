@@ -41,7 +41,8 @@ def engine(pkg, monkeypatch):
     def make(**env):
         pkg.shutdown()
         for k in ("SDPA_VIRTUAL_GPUS", "SDPA_FORCE_COLLECTIVES", "SDPA_QBATCH", "SDPA_KV_CHUNK_MIN",
-                  "SDPA_KV_CHUNK_MAX", "SDPA_ROW_PIECES", "SDPA_PIECE_MIN_ROWS", "SDPA_PLAN", "SDPA_MERGE", "SDPA_PRECISION"):
+                  "SDPA_KV_CHUNK_MAX", "SDPA_ROW_PIECES", "SDPA_PIECE_MIN_ROWS", "SDPA_PLAN", "SDPA_MERGE", "SDPA_PRECISION",
+                  "SDPA_EGRESS", "SDPA_ENQUEUE_THREADS", "SDPA_PROGRESSIVE_PIN"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, str(v))
@@ -249,3 +250,70 @@ def test_tune_env_cannot_change_the_shipped_library(engine, O, orc, monkeypatch)
     Q, K, V = O.make_inputs(130, 1000, 512, 512, "D1", seed=2)
     monkeypatch.setenv("SDPA_TUNE", str(15 << 8))
     check(pkg.attention(Q, K, V, precision="bf16"), orc.attention_f64(Q, K, V), V, "SDPA_TUNE bf16", 1e-2 * max(1.0, float(np.abs(V).max())))
+
+
+# ------------------------------------------------- P > 1: enqueue threads, comm streams, egress ---------
+@pytest.mark.parametrize("P,m,n,d,batch", [(2, 1500, 9000, 128, 512), (3, 700, 6000, 64, 256), (8, 2048, 40000, 128, 1024),
+                                           (8, 300, 5, 64, 128)])           # n < P: three ranks own no key at all
+def test_multi_rank_schedules_agree_bit_for_bit(P, m, n, d, batch, engine, orc, O):
+    """P loopback ranks, several Q batches.  The schedule of round 3 -- one enqueue thread per rank, the
+    per-batch collectives on the ranks' comm streams (batch b's merge under batch b+1's kernels,
+    attention-mpi.c:364-380), the merged rows reduce-SCATTERED so that every rank sends its share home --
+    against the schedule of round 2 (one thread, reduce to the root, $SDPA_EGRESS=root
+    $SDPA_ENQUEUE_THREADS=0): the loopback collectives sum in rank order either way, so the results must
+    be IDENTICAL bit for bit, both merges; and within tolerance of the fp64 oracle."""
+    Q, K, V = O.make_inputs(m, n, d, d, "D4", seed=P * 1000 + m)
+    want = orc.attention_f64(Q, K, V)
+    common = dict(SDPA_VIRTUAL_GPUS=P, SDPA_QBATCH=batch, SDPA_KV_CHUNK_MIN=1024, SDPA_KV_CHUNK_MAX=2048)
+    for merge in ("gather", "allreduce"):
+        pkg = engine(SDPA_EGRESS="root", SDPA_ENQUEUE_THREADS=0, SDPA_MERGE=merge, **common)
+        old = pkg.attention(Q, K, V)
+        t_old = pkg.last_timing()
+        assert t_old["enqueue_threads"] == 1 and t_old["egress"] == 1 and t_old["n_gpus"] == P, t_old
+        check(old, want, V, "round-2 schedule, %s" % merge)
+        for knobs in (dict(), dict(SDPA_EGRESS="root"), dict(SDPA_ENQUEUE_THREADS=0), dict(SDPA_PROGRESSIVE_PIN=0)):
+            pkg = engine(SDPA_MERGE=merge, **common, **knobs)
+            for rep in range(3):
+                new = pkg.attention(Q, K, V)
+                assert np.array_equal(new, old), "merge %s, knobs %r, call %d: differs from the one-thread / root-egress result" % (merge, knobs, rep)
+            t = pkg.last_timing()
+            assert t["enqueue_threads"] == (1 if knobs.get("SDPA_ENQUEUE_THREADS") == 0 else P), t
+            assert t["egress"] == (1 if knobs.get("SDPA_EGRESS") == "root" else 2), t
+            assert t["q_batches"] == -(-m // batch) and t["merge"] == (1 if merge == "gather" else 2), t
+            first = t["enqueue_first_kernel_us"]
+            assert len(first) == P and all(x > 0 for x in first), t
+
+
+def test_enqueue_threads_issue_every_ranks_first_kernel_together(engine, O):
+    """config 3's shape on 8 loopback ranks (n = 262144 sharded 8 ways, m reduced): with one enqueue thread per
+    rank, rank 7's first fused launch is ENQUEUED within a fraction of a millisecond of rank 0's (host clock,
+    hardware independent); with the single enqueue thread of round 2 it waited behind seven ranks' worth
+    of API calls.  Logged for profiles/; the bound asserted here is deliberately loose."""
+    m, n, d = 4096, 262144, 128
+    rng = np.random.default_rng(5)
+    Q, K, V = (rng.uniform(-1, 1, s) for s in ((m, d), (n, d), (n, d)))
+    spreads = {}
+    for threads in (0, 1):
+        pkg = engine(SDPA_VIRTUAL_GPUS=8, SDPA_ENQUEUE_THREADS=threads)
+        best = None
+        for _ in range(4):
+            pkg.attention(Q, K, V)
+            f = pkg.last_timing()["enqueue_first_kernel_us"]
+            sp = max(f) - min(f)
+            best = sp if best is None else min(best, sp)
+        spreads[threads] = best
+        print("first-kernel enqueue spread over 8 ranks, enqueue threads %s: %.0f us" % ("on" if threads else "off", best))
+    assert spreads[1] < 1000.0, spreads
+    assert spreads[1] < spreads[0], spreads
+
+
+def test_one_rank_forced_collectives_use_the_comm_stream(engine, orc, O):
+    """one rank with the collectives forced on (a one-rank RCCL communicator): the tail of each batch runs on
+    the comm stream behind the rank's kernels; 5 batches"""
+    pkg = engine(SDPA_FORCE_COLLECTIVES=1, SDPA_QBATCH=256)
+    Q, K, V = O.make_inputs(1200, 3000, 128, 128, "D2", seed=12)
+    for merge in ("gather", "allreduce"):
+        got = pkg.attention(Q, K, V, merge=merge)
+        t = pkg.last_timing()
+        assert t["q_batches"] == 5 and t["merge"] == (1 if merge == "gather" else 2) and t["egress"] == 1, t
+        check(got, orc.attention_f64(Q, K, V), V, "forced collectives, %s" % merge)

@@ -418,11 +418,12 @@ def test_error_ratio_vs_reference_fp32_pipeline(pkg, be, orc, O):
 def test_race_screen_repeatability(pkg, be, orc, O):
     """The pipelined kernel hands K/V tiles between waves through LDS-DMA + barriers, and the partial
     triples of its in-GPU K/V splits between WORKGROUPS (different XCDs, non-coherent L2s) through an
-    agent-scope release / ticket / acquire; a missing wait or a stale line shows up as rare wrong
-    tiles.  Screen: 100 launches each of three shapes (in-GPU splits merged inside the kernel, ragged
-    tails, both MFMA kernels) must be BITWISE identical to the first, which is checked against the
-    oracle.  All shapes share one scratch area, so every launch finds the previous shape's arrival
-    words in it (another generation: they must count as zero)."""
+    agent-scope release / ticket / acquire when the kernel merges them itself ($SDPA_SPLIT_MERGE=kernel,
+    the second half of this screen); a missing wait or a stale line shows up as rare wrong tiles.
+    Screen: 100 launches each of three shapes (in-GPU splits, ragged tails, both MFMA kernels) must be
+    BITWISE identical to the first, which is checked against the oracle.  All shapes share one scratch
+    area, so every launch finds the previous shape's arrival words in it (another generation: they
+    must count as zero)."""
     shapes = [(640, 6000, 128, 128, "D2"), (513, 3333, 64, 64, "D3"), (300, 2500, 96, 72, "D2")]
     runs = []
     for (m, n, dk, dv, dist) in shapes:
@@ -436,10 +437,13 @@ def test_race_screen_repeatability(pkg, be, orc, O):
         check(be.finish_f64(contrib, lsum, dv).cpu().numpy(), orc.attention_f64(Q, K, V), V, "first launch")
         runs.append((sa, qf, dv, first))
     for it in range(1, 100):
+        if it == 50:
+            os.environ["SDPA_SPLIT_MERGE"] = "kernel"
         for sa, qf, dv, first in runs:                 # interleaved: the scratch area changes hands every launch
             cur = sa.batch_partial(qf)
             assert all(torch.equal(a_[:, :dv] if a_.dim() == 2 else a_, b_[:, :dv] if b_.dim() == 2 else b_)
                        for a_, b_ in zip(cur, first)), "launch %d differs from launch 0" % it
+    os.environ.pop("SDPA_SPLIT_MERGE", None)
 
 
 @pytest.mark.parametrize("m,n,dk,dv", [(8192, 8192, 128, 128),      # BASELINE config 2: 64 query blocks x 8 splits
@@ -447,18 +451,19 @@ def test_race_screen_repeatability(pkg, be, orc, O):
                                         (1000, 20000, 256, 256),     # one wave per SIMD variant
                                         (4096, 8192, 128, 64), (700, 9000, 64, 128), (900, 7000, 250, 120)])
 def test_in_kernel_split_merge_equals_the_separate_pass_bitwise(m, n, dk, dv, pkg, be, O, monkeypatch):
-    """kv_splits > 1 on the pipelined kernels: the last workgroup of a query block to arrive merges the
-    block's partial triples inside the fused launch (one launch per step).  $SDPA_SPLIT_MERGE=pass runs
-    the separate split_merge_kernel instead: same weights, same sums in the same split order -- the two
-    forms must agree bit for bit, 20 launches each (under load from the neighbouring query blocks)."""
+    """kv_splits > 1 on the pipelined kernels: split_merge_kernel merges the partial triples right behind
+    the fused launch (the default: measured faster).  With $SDPA_SPLIT_MERGE=kernel the last workgroup
+    of a query block to arrive merges the block's triples inside the fused launch (one launch per step):
+    same weights, same sums in the same split order -- the two forms must agree bit for bit, 20 launches
+    (under load from the neighbouring query blocks)."""
     assert pkg.load().sdpa_dev_kv_splits(m, n, dk, dv) > 1
     Q, K, V = O.make_inputs(m, n, dk, dv, "D2", seed=5)
     sa = pkg.ShardedAttention(be)
     sa.load_kv_from_root(K, V, n, dk, dv)
     qf = sa.convert_q(torch.from_numpy(Q).cuda())
-    monkeypatch.setenv("SDPA_SPLIT_MERGE", "pass")
+    monkeypatch.delenv("SDPA_SPLIT_MERGE", raising=False)
     want = tuple(t.clone() for t in sa.batch_partial(qf))
-    monkeypatch.delenv("SDPA_SPLIT_MERGE")
+    monkeypatch.setenv("SDPA_SPLIT_MERGE", "kernel")
     for it in range(20):
         got = sa.batch_partial(qf)
         for name, g, w in zip(("contrib", "lmax", "lsum"), got, want):

@@ -1,0 +1,25 @@
+"""From a rocprofv3 --kernel-trace of a multi-batch P > 1 run on loopback ranks: for every collective
+kernel (loop_reduce* / loop_gather*) the fused kernels that were running on the device at the same time.
+    python tools/summarize_overlap.py <dir with *_kernel_trace.csv>
+Shows that batch b's merge collectives run UNDER batch b+1's fused kernels (attention-mpi.c:364-380)."""
+import csv, glob, os, sys
+rows = []
+for f in glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        rows.append((r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Stream_Id", "?")))
+rows.sort(key=lambda r: r[1])
+fused = [r for r in rows if "fused_" in r[0]]
+coll = [r for r in rows if "loop_reduce" in r[0] or "loop_gather" in r[0]]
+t0 = rows[0][1] if rows else 0
+print("%d dispatches, %d fused launches, %d collective kernels" % (len(rows), len(fused), len(coll)))
+n_over = 0
+tail = coll[-12:] if len(coll) > 48 else coll
+for name, a, b, st in coll:
+    over = [(fa, fb, fs) for _, fa, fb, fs in fused if fa < b and fb > a]
+    n_over += 1 if over else 0
+    if (name, a, b, st) in tail:
+        short = name.split("(")[0].split("::")[-1]
+        print("%-28s stream %-4s %9.1f .. %9.1f us (%6.1f us)  concurrent fused launches: %s" % (
+            short, st, (a - t0) / 1e3, (b - t0) / 1e3, (b - a) / 1e3,
+            ", ".join("stream %s %.0f..%.0f us" % (fs, (fa - t0) / 1e3, (fb - t0) / 1e3) for fa, fb, fs in over) or "none"))
+print("collective kernels that ran while a fused kernel was running: %d of %d" % (n_over, len(coll)))
