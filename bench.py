@@ -153,13 +153,30 @@ def cpu_baseline(m, n, d, budget_rows=8192):
                 tflops=flop / dt / 1e12, cpu=model, build="oracle/sdpa_oracle.c, gcc -O2 -fopenmp")
 
 
-def kernel_source_stamp():
-    """identifies the build a profile of the fp32 fused kernel was taken from: sha256 over the
+def kernel_source_stamp(precision="f32"):
+    """identifies the build a profile of the fused kernel was taken from: sha256 over the
     sources that define it (git is not available on the GPU box)"""
     h = hashlib.sha256()
-    for f in ("sdpa_fwd_f32.hip", "sdpa_internal.h"):
+    for f in ("sdpa_fwd_bf16.hip" if precision == "bf16" else "sdpa_fwd_f32.hip", "sdpa_internal.h"):
         h.update(open(os.path.join(ROOT, PKG, "csrc", f), "rb").read())
     return h.hexdigest()[:16]
+
+
+def pmc_stamp(workload, precision):
+    """PMC-derived figures of the dominant kernel for this workload (tools/gpu_profile.sh ->
+    profiles/traffic_latest.json): HBM-side bytes per launch, HBM-side GB/s, MFMA utilisation.  A figure
+    is only quoted for the kernel sources it was measured on; otherwise every field is null."""
+    none = {"traffic": None, "hbm_gbps": None, "mfma_util": None}
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+        e = tj.get("entries", {}).get("%s/%s" % (workload, precision))
+        if e is None and "per_launch_bytes" in tj and (workload, precision) == ("headline", "f32"):
+            e = tj                                           # round-1/2 layout: one entry, the headline's
+        if e is None or e.get("kernel_src_sha16") != kernel_source_stamp(precision):
+            return none
+        return {"traffic": e.get("per_launch_bytes"), "hbm_gbps": e.get("hbm_gbps"), "mfma_util": e.get("mfma_util")}
+    except Exception:  # noqa: BLE001
+        return none
 
 
 def prewarm_step_count(rows, keys, d, precision, prewarm_ms):
@@ -583,14 +600,7 @@ def main():
         else:
             kernel_name = "sdpa::fused_partial_kernel / generic_partial_kernel"
         total_flop = 4.0 * m * n * d
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath) and world == 1 and args.workload == "headline" and args.precision == "f32":
-            try:      # a PMC figure is only quoted for the build it was measured on
-                tj = json.load(open(tpath))
-                traffic = tj["per_launch_bytes"] if tj.get("kernel_src_sha16") == kernel_source_stamp() else None
-            except Exception:  # noqa: BLE001
-                traffic = None
+        pmc = pmc_stamp(args.workload, args.precision) if world == 1 else {"traffic": None, "hbm_gbps": None, "mfma_util": None}
         line = {
             "metric": ("DRY RUN of 1 of %d ranks, not a result: " % args.emulate_ranks if args.emulate_ranks > 1 else "") +
                       ("DRY RUN (%s%s), not a result: " % ("gloo, host-staged collectives" if gloo else "rccl",
@@ -622,7 +632,10 @@ def main():
             "parity": "%d random rows of the last timed step vs fp64 numpy restatement of attention.c:20-75" % len(prow),
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": traffic,
+                         "traffic": pmc["traffic"],
+                         # from the committed rocprofv3 PMC passes of THIS kernel build (null otherwise):
+                         # HBM-side GB/s (8 TB/s peak) and SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs)
+                         "hbm_gbps": pmc["hbm_gbps"], "mfma_util": pmc["mfma_util"],
                          "kernel": kernel_name,
                          "kernel_ms_avg": avg_ms, "launches": len(k_ms),
                          "flop_per_launch": flop_per_launch},

@@ -90,14 +90,23 @@ def test_traffic_stamp_names_the_shipped_kernel_sources():
     sys.path.insert(0, ROOT)
     import bench
     stamp = bench.kernel_source_stamp()
-    assert len(stamp) == 16 and int(stamp, 16) >= 0
+    assert len(stamp) == 16 and int(stamp, 16) >= 0 and bench.kernel_source_stamp("bf16") != stamp
     tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
-    # a PMC figure is only quoted for the kernel sources it was measured on (else bench prints traffic: null)
-    if tj["kernel_src_sha16"] != stamp:
+    entries = tj.get("entries") or {"headline/f32": tj}
+    for key, e in entries.items():
+        assert e["per_launch_bytes"] == pytest.approx(e["fetch_size_kib"] * 1024 * 2 + e["write_size_kib"] * 1024, rel=1e-9)
+        if "hbm_gbps" in e:
+            assert e["hbm_gbps"] == pytest.approx(e["per_launch_bytes"] / (e["steady_avg_ms"] * 1e-3) / 1e9, rel=1e-6)
+            assert 0.0 < e["mfma_util"] <= 1.0
+    # a PMC figure is only quoted for the kernel sources it was measured on (else bench prints null)
+    head = entries.get("headline/f32")
+    got = bench.pmc_stamp("headline", "f32")
+    if head is None or head["kernel_src_sha16"] != stamp:
+        assert got == {"traffic": None, "hbm_gbps": None, "mfma_util": None}
         pytest.skip("profiles/traffic_latest.json was measured on older kernel sources: bench.py prints "
                     "traffic: null until tools/gpu_profile.sh has been re-run")
-    assert tj["per_launch_bytes"] == pytest.approx(
-        tj["fetch_size_kib"] * 1024 * 2 + tj["write_size_kib"] * 1024, rel=1e-9)
+    assert got["traffic"] == head["per_launch_bytes"]
+    assert bench.pmc_stamp("config1", "f32")["traffic"] is None          # never profiled: never quoted
 
 
 def test_clock_prewarm_count_is_a_function_of_the_shape_only():

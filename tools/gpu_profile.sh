@@ -9,10 +9,14 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # --no-boundary: every fused launch in the process is then a timed-step launch, so rocprofv3's
 # per-kernel AVERAGE is the full-launch duration bench.py reports
-BENCH="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-boundary ${BENCH_ARGS:-}"
+# (bench.py runs its clock pre-warm -- ~60 ms of untimed steps -- before the W warmup steps, so the K timed
+#  launches are the LAST K dispatches of the fused kernel in the trace and sit on the clock's plateau:
+#  summarize_prof.py quotes their average next to the all-dispatch average)
+STEPS=${PROF_STEPS:-10}
+BENCH="python $R/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-boundary ${BENCH_ARGS:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $BENCH > $OUT/trace.log 2>&1
 echo "trace rc=$?" >> $OUT/trace.log
-BENCH2="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-boundary ${BENCH_ARGS:-}"
+BENCH2="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-boundary ${BENCH_ARGS:-}"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- $BENCH2 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- $BENCH2 > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -o bench -- $BENCH2 > $OUT/pmc_sq.log 2>&1
@@ -21,5 +25,5 @@ rocprofv3 -L > $OUT/counters_list.txt 2>&1
 find $OUT -name "*.csv" | head -50 > $OUT/files.txt
 # keep the merge-back small: drop the big per-dispatch traces except the stats
 du -sh $OUT >> $OUT/files.txt
-python $R/tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
-cat $OUT/summary.txt | head -60
+PROF_STEPS=$STEPS PROF_PMC_STEPS=3 BENCH_ARGS="${BENCH_ARGS:-}" python $R/tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
+grep -A14 "== dominant kernel" $OUT/summary.txt

@@ -40,34 +40,90 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
         for c, v in cs.items():
             print("   %-70s %-28s n=%d mean=%.6g" % (name, c, len(v), sum(v) / len(v)))
 
-# ---- HBM-side traffic of the fused kernel per launch, for bench.py's roofline.traffic.
-# Collected as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes,
-# units are KiB, and on gfx950 FETCH_SIZE reports half the bytes of wide (16 B/lane) streaming
-# reads, so it is doubled; WRITE_SIZE is taken as is (uncalibrated).
+# ---- the dominant fused kernel against its roofline, from the profile alone -----------------------
+# steady-state average (the K timed launches = the last K dispatches, behind bench.py's clock pre-warm),
+# fraction of the MFMA peak, MFMA utilisation, HBM-side traffic and rate (north_star: "rocprof HBM GB/s
+# and MFMA utilisation reported against gfx950 peak").  Traffic as MI355X_MICROARCH.md prescribes:
+# FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes, units KiB, FETCH_SIZE doubled (on gfx950 it
+# reports half the bytes of wide 16 B/lane streaming reads), WRITE_SIZE as is (uncalibrated).
+import hashlib
 import json
+import re
 
+WORKLOADS = {"headline": (32768, 65536, 128), "config2": (8192, 8192, 128), "config3": (32768, 262144, 128),
+             "config1": (512, 512, 64), "config4": (131072, 65536, 128), "config5": (32768, 65536, 512),
+             "d256": (32768, 65536, 256), "d64": (32768, 65536, 64)}
+bench_args = os.environ.get("BENCH_ARGS", "")
+mw = re.search(r"--workload\s+(\w+)", bench_args)
+workload = mw.group(1) if mw else "headline"
+precision = "bf16" if re.search(r"--precision\s+bf16", bench_args) else "f32"
+K = int(os.environ.get("PROF_STEPS", "10"))
+K2 = int(os.environ.get("PROF_PMC_STEPS", "3"))
+m, n, d = WORKLOADS[workload]
+flop = 4.0 * m * n * d
+peak = 2500e12 if precision == "bf16" else 157.3e12
 
-def fused_mean(d, counter):
-    vals = []
-    for p in glob.glob(os.path.join(out, d, "**", "*counter_collection.csv"), recursive=True):
-        for r in rows(p):
-            if "fused_" in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
-                vals.append(float(r["Counter_Value"]))
-    return sum(vals) / len(vals) if vals else None
+disp = defaultdict(list)
+for p in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    for r in rows(p):
+        if "fused_" in r.get("Kernel_Name", ""):
+            disp[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+if disp:
+    dom = max(disp, key=lambda k: sum(x[1] for x in disp[k]))
+    durs = [x[1] for x in sorted(disp[dom])]
+    steady = durs[-K:] if len(durs) >= K else durs
+    avg_all, avg_steady = sum(durs) / len(durs), sum(steady) / len(steady)
 
+    def pmc_mean(dname, counter):
+        """mean over the last K2 dispatches (the timed steps of the PMC run) of the dominant kernel"""
+        vals = []
+        for p in glob.glob(os.path.join(out, dname, "**", "*counter_collection.csv"), recursive=True):
+            for r in rows(p):
+                if r.get("Kernel_Name") == dom and r.get("Counter_Name") == counter:
+                    vals.append((int(r.get("Dispatch_Id", 0)), float(r["Counter_Value"])))
+        vals = [v for _, v in sorted(vals)][-K2:]
+        return sum(vals) / len(vals) if vals else None
 
-f, w = fused_mean("pmc_fetch", "FETCH_SIZE"), fused_mean("pmc_write", "WRITE_SIZE")
-if f is not None and w is not None:
-    import hashlib
+    f, w = pmc_mean("pmc_fetch", "FETCH_SIZE"), pmc_mean("pmc_write", "WRITE_SIZE")
+    busy, gui = pmc_mean("pmc_sq", "SQ_VALU_MFMA_BUSY_CYCLES"), pmc_mean("pmc_sq", "GRBM_GUI_ACTIVE")
+    insts = pmc_mean("pmc_lds", "SQ_INSTS_MFMA")
+    conflicts = pmc_mean("pmc_lds", "SQ_LDS_BANK_CONFLICT")
+    achieved = flop / (avg_steady * 1e-9)
+    print()
+    print("== dominant kernel vs its roofline (%s, %s) ==" % (workload, precision))
+    print("kernel                     %s" % dom[:100])
+    print("dispatches                 %d (all-dispatch avg %.4f ms incl. the clock ramp of the first ones)" % (len(durs), avg_all / 1e6))
+    print("steady-state avg           %.4f ms over the last %d dispatches (the timed steps)" % (avg_steady / 1e6, len(steady)))
+    print("algorithmic flop / launch  %.4e  ->  %.1f TFLOP/s = %.3f of the %s MFMA peak (%.1f TFLOP/s)" % (
+        flop, achieved / 1e12, achieved / peak, precision, peak / 1e12))
+    entry = {"workload": workload, "precision": precision, "kernel": dom, "steady_avg_ms": avg_steady / 1e6,
+             "dispatches": len(durs), "frac_of_mfma_peak": achieved / peak}
+    if busy is not None and gui:
+        # GRBM_GUI_ACTIVE sums the 8 XCDs' active cycles; 1024 SIMDs each with one matrix pipe
+        util = busy / (gui / 8.0 * 1024.0)
+        entry["mfma_util"] = util
+        print("MFMA utilisation           %.3f  (SQ_VALU_MFMA_BUSY_CYCLES %.4g / (GRBM_GUI_ACTIVE %.4g / 8 XCD x 1024 SIMD))" % (util, busy, gui))
+    if insts is not None:
+        per = 4096.0 if precision == "f32" else 32768.0
+        print("SQ_INSTS_MFMA              %.4g  (algorithmic flop / %d flop per MFMA = %.4g)" % (insts, per, flop / per))
+    if conflicts is not None:
+        print("SQ_LDS_BANK_CONFLICT       %.4g cycles" % conflicts)
+    if f is not None and w is not None:
+        traffic = f * 1024 * 2 + w * 1024
+        algo = (4.0 if precision == "f32" else 2.0) * (2.0 * n * d + m * d) + 4.0 * m * d
+        gbps = traffic / (avg_steady * 1e-9) / 1e9
+        entry.update({"per_launch_bytes": traffic, "fetch_size_kib": f, "write_size_kib": w, "hbm_gbps": gbps,
+                      "hbm_frac_of_8TBps": gbps / 8000.0, "traffic_over_algorithmic": traffic / algo})
+        print("HBM-side traffic / launch  %.1f MB (FETCH_SIZE %.0f KiB x 2 + WRITE_SIZE %.0f KiB) = %.2f x the algorithmic %.1f MB" % (
+            traffic / 1e6, f, w, traffic / algo, algo / 1e6))
+        print("HBM-side rate              %.1f GB/s = %.2f %% of the 8 TB/s peak" % (gbps, gbps / 80.0))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    for fn in ("sdpa_fwd_f32.hip", "sdpa_internal.h"):       # the fp32 fused kernel's sources (bench.py checks this)
+    src = "sdpa_fwd_bf16.hip" if precision == "bf16" else "sdpa_fwd_f32.hip"
+    for fn in (src, "sdpa_internal.h"):       # the fused kernel's sources (bench.py quotes the figures only for this build)
         h.update(open(os.path.join(root, "mpi-parallelized-scaled-dot-product-attention-with-avx-512-optimization_amd", "csrc", fn), "rb").read())
-    t = {"per_launch_bytes": f * 1024 * 2 + w * 1024, "fetch_size_kib": f, "write_size_kib": w,
-         "kernel_src_sha16": h.hexdigest()[:16],      # bench.py quotes the figure only for this build
-         "correction": "FETCH_SIZE KiB x1024 x2 (gfx950 wide-read under-count) + WRITE_SIZE KiB x1024",
-         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python bench.py --steps 2 --warmup 1 --no-boundary"}
-    json.dump(t, open(os.path.join(out, "traffic.json"), "w"), indent=1)
-    print()
-    print("== fused kernel HBM-side traffic per launch ==")
-    print(json.dumps(t))
+    entry["kernel_src_sha16"] = h.hexdigest()[:16]
+    entry["correction"] = "FETCH_SIZE KiB x1024 x2 (gfx950 wide-read under-count) + WRITE_SIZE KiB x1024"
+    entry["source"] = "tools/gpu_profile.sh: rocprofv3 --kernel-trace --stats (steady avg), --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes; python bench.py --no-boundary %s" % bench_args
+    json.dump(entry, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+    print(json.dumps(entry))
