@@ -364,6 +364,11 @@ def main():
                     help="untimed steps run BEFORE the W warmup steps until about this much GPU work has been "
                          "issued, so that the core clock has finished ramping when the timed region starts "
                          "(0 = off; see the DVFS note in main())")
+    ap.add_argument("--reserve-cus", type=int, default=0,
+                    help="launch the fused kernels on a stream that leaves this many compute units (multiple of 8) to "
+                         "other streams, so that RCCL's kernels of step k can run UNDER step k+1's fused kernel instead "
+                         "of waiting for its last workgroup (a fused launch otherwise holds every wave slot of the chip); "
+                         "0 = off (default): it costs the fused kernel reserve/256 of its rate")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
                     help="operand precision of the fused kernel (the headline metric is f32)")
     args = ap.parse_args()
@@ -534,20 +539,29 @@ def main():
     rows_est = pkg.owner_count(m, world, 0) if qrows else m
     keys_est = n if qrows else (cnt if args.emulate_ranks > 1 else pkg.owner_count(n, world, 0))
     prewarm_steps = prewarm_step_count(rows_est, keys_est, d, args.precision, args.prewarm_ms)
-    for _ in range(prewarm_steps):
-        run(False)
-    for _ in range(args.warmup):
-        run(False)
-    if not qrows:
-        flush()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = run(True)
-    if not qrows:
-        res = flush()
-    fence()
-    elapsed = time.perf_counter() - t0
+    import contextlib
+    compute = contextlib.nullcontext()
+    if args.reserve_cus > 0:
+        import ctypes
+        sp = ctypes.c_void_p()
+        pkg._lib.check(pkg.load().sdpa_dev_stream_create(args.reserve_cus, ctypes.byref(sp)), "sdpa_dev_stream_create")
+        torch.cuda.synchronize()                   # the inputs were drawn on the default stream
+        compute = torch.cuda.stream(torch.cuda.ExternalStream(sp.value, device=dev))
+    with compute:
+        for _ in range(prewarm_steps):
+            run(False)
+        for _ in range(args.warmup):
+            run(False)
+        if not qrows:
+            flush()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = run(True)
+        if not qrows:
+            res = flush()
+        fence()
+        elapsed = time.perf_counter() - t0
     if dist is not None:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -619,7 +633,7 @@ def main():
             "data": "synthetic U(-1,1) fp64 Q/K/V resident in HBM (%s)" %
                     ("Q row-sharded, K/V replicated" if qrows else "Q replicated, K/V row-sharded"),
             "config": {"workload": "%s: m=%d n=%d dk=dv=%d, %s compute / fp64 in-out" % (args.workload, m, n, d, args.precision),
-                       "q_batch": B, "q_batches": nb,
+                       "q_batch": B, "q_batches": nb, **({"reserve_cus": args.reserve_cus} if args.reserve_cus else {}),
                        "kv_rows_per_gpu": cnt,
                        "kv_splits_in_gpu": (pkg.load().sdpa_dev_kv_splits_bf16 if args.precision == "bf16"
                                             else pkg.load().sdpa_dev_kv_splits)(min(B, m), cnt, d, d),

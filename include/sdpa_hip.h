@@ -195,6 +195,16 @@ SDPA_API int sdpa_owner_disp(int n, int size, int rank);
  * sdpa_dev_shard_partial_f32 must be zero (sdpa_dev_cvt_d2f writes them so).
  * Operand base pointers must be 16-byte aligned (SDPA_EINVAL otherwise).        */
 
+/* A stream for the fused kernels that leaves `reserve_cus` compute units (rounded up to a multiple of
+ * the 8 XCDs, the same number from each) to other streams' kernels; 0 = an ordinary non-blocking
+ * stream.  Why: a fused launch holds every wave slot of every CU until its last workgroup ends, so a
+ * collective (RCCL) or merge kernel that becomes ready while it runs cannot start -- whatever its
+ * stream or priority.  A host that wants batch b's reduce to run UNDER batch b+1's fused kernel
+ * (attention-mpi.c:364-380) launches the fused kernels on such a stream (the C host: $SDPA_COMM_CUS;
+ * bench.py: --reserve-cus).  Opt-in: it costs the fused kernel reserve_cus/256 of the chip.          */
+SDPA_API int sdpa_dev_stream_create(int reserve_cus, void **stream);
+SDPA_API int sdpa_dev_stream_destroy(void *stream);
+
 /* The leading dimension to give the fp32 images of a matrix with d columns (and the contrib rows
  * of a dv-column result): d in (32, 256] padded to 64 / 128 / 256, otherwise d rounded up to 4.
  * Images of those widths run the LDS-DMA pipelined kernels whatever the head dims are; any other

@@ -54,6 +54,8 @@ _PROTOS = {
     "sdpa_host_free": (None, [_c_void_p]),
     "sdpa_owner_count": (_c_int, [_c_int] * 3),
     "sdpa_owner_disp": (_c_int, [_c_int] * 3),
+    "sdpa_dev_stream_create": (_c_int, [_c_int, ctypes.POINTER(_c_void_p)]),
+    "sdpa_dev_stream_destroy": (_c_int, [_c_void_p]),
     "sdpa_dev_dense_ld": (_c_int, [_c_int]),
     "sdpa_dev_cvt_d2f": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p]),
     "sdpa_dev_cvt_f2d": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_long, _c_int, _c_void_p]),

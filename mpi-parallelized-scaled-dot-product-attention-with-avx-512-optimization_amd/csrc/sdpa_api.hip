@@ -119,6 +119,21 @@ int sdpa_dev_shard_partial_f32(const float *Qf, int ldq, const float *Kf, int ld
     return SDPA_OK;
 }
 
+int sdpa_dev_stream_create(int reserve_cus, void **stream) {
+    if (!stream || reserve_cus < 0) return SDPA_EINVAL;
+    SDPA_TRY(require_device());
+    hipStream_t st = nullptr;
+    SDPA_TRY(sdpa::create_masked_stream(&st, reserve_cus));
+    *stream = (void *)st;
+    return SDPA_OK;
+}
+
+int sdpa_dev_stream_destroy(void *stream) {
+    if (!stream) return SDPA_EINVAL;
+    HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return SDPA_OK;
+}
+
 int sdpa_dev_dense_ld(int d) { return d < 1 ? 0 : sdpa::dense_ld(d); }
 
 int sdpa_dev_merge_rescale(float *contrib, int ldo, float *lsum, const float *lmax, const float *gmax,

@@ -25,6 +25,27 @@ namespace sdpa {
 
 inline int round4(int x) { return (x + 3) / 4 * 4; }
 
+// A stream whose kernels may use all but `reserve_cus` compute units of the current device (rounded up
+// to a multiple of the XCD count, the same number taken from every XCD: the mask's bits are dealt
+// round-robin over the XCDs, bit i -> XCD i % 8).  reserve_cus <= 0: an ordinary non-blocking stream.
+inline int create_masked_stream(hipStream_t *out, int reserve_cus) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    const int cus = prop.multiProcessorCount, xcds = 8;
+    if (reserve_cus <= 0 || cus < 2 * xcds || cus > 1024) {
+        HIP_TRY(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+        return SDPA_OK;
+    }
+    int r = (reserve_cus + xcds - 1) / xcds * xcds;
+    if (r > cus / 2) r = cus / 2 / xcds * xcds;
+    unsigned mask[32] = {0};
+    for (int i = 0; i < cus - r; ++i) mask[i / 32] |= 1u << (i % 32);
+    HIP_TRY(hipExtStreamCreateWithCUMask(out, (unsigned)((cus + 31) / 32), mask));
+    return SDPA_OK;
+}
+
 inline int require_device() {
     int cnt = 0;
     if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) {

@@ -489,16 +489,18 @@ __global__ __launch_bounds__(256, (DK + DV > 256) ? 1 : 2) void fused_pipelined_
     };
     // ---- LDS-DMA staging: per-lane source byte offsets inside a tile (loop invariant)
     unsigned koff[KPW], voff[VPW];
+    {   // (loop invariant, shared by both passes: re-deriving them per pass costs the hot loop two scratch reloads)
 #pragma unroll
-    for (int j = 0; j < KPW; ++j) {
-        const int row = (wave * KPW + j) * (64 / KCH) + lane / KCH;
-        const int cpos = lane % KCH;
-        koff[j] = (unsigned)(row * DK * 4 + ((cpos ^ (row & 15)) << 4));
-    }
+        for (int j = 0; j < KPW; ++j) {
+            const int row = (wave * KPW + j) * (64 / KCH) + lane / KCH;
+            const int cpos = lane % KCH;
+            koff[j] = (unsigned)(row * DK * 4 + ((cpos ^ (row & 15)) << 4));
+        }
 #pragma unroll
-    for (int j = 0; j < VPW; ++j) {
-        const int row = (wave * VPW + j) * (64 / VCH) + lane / VCH;
-        voff[j] = (unsigned)(row * DV * 4 + ((lane % VCH) << 4));
+        for (int j = 0; j < VPW; ++j) {
+            const int row = (wave * VPW + j) * (64 / VCH) + lane / VCH;
+            voff[j] = (unsigned)(row * DV * 4 + ((lane % VCH) << 4));
+        }
     }
     // The DMA is issued from inline asm on purpose: hipcc treats the builtin as a pending LDS
     // write and drains vmcnt(0) before the next ds_read, which would serialise the stream.
@@ -772,28 +774,6 @@ __global__ __launch_bounds__(256, (DK + DV > 256) ? 1 : 2) void fused_pipelined_
     l_tot = (l_run + __shfl_xor(l_run, 32)) * fold;
     };  // run_pass
 
-    run_pass();
-#if SDPA_RANGE_REDO
-    {   // range check of the deferred-rescale pass (see `defer` above).  The LDS tiles are dead here:
-        // every wave has passed the last step's barrier behind its last fragment read.
-        bool bad = !__builtin_isfinite(l_tot);
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) bad |= !__builtin_isfinite(oacc[tt][r]);
-        int *vote = reinterpret_cast<int *>(smem);
-        const int wave_bad = __any(bad) ? 1 : 0;
-        if (lane == 0) vote[wave] = wave_bad;
-        __syncthreads();
-        const int redo = __builtin_amdgcn_readfirstlane(vote[0] | vote[1] | vote[2] | vote[3]);
-        if (redo) {
-            __syncthreads();                  // the votes are read before the second pass's first DMA lands on them
-            defer = 0.f;
-            run_pass();
-        }
-    }
-#endif
-
     auto store_rows = [&](float *out, int ldo, float *omax, float *osum, const f32x16 (&o)[NT], float vmax,
                           float vsum) __attribute__((always_inline)) {
         if (qrow < a.m) {
@@ -816,13 +796,43 @@ __global__ __launch_bounds__(256, (DK + DV > 256) ? 1 : 2) void fused_pipelined_
             }
         }
     };
-    const float my_max = T > 0 ? (m_ref + max_rel) * 0.69314718055994530942f : -INFINITY;
-    if (a.kv_splits <= 1) {
-        store_rows(a.contrib, a.ldo, a.lmax, a.lsum, oacc, my_max, l_tot);
-        return;
+    // this workgroup's triple: the rows of the result, or its slab of the split scratch
+    auto store_mine = [&]() __attribute__((always_inline)) {
+        const float my_max = T > 0 ? (m_ref + max_rel) * 0.69314718055994530942f : -INFINITY;
+        if (a.kv_splits <= 1)
+            store_rows(a.contrib, a.ldo, a.lmax, a.lsum, oacc, my_max, l_tot);
+        else
+            store_rows(a.ws_contrib + (size_t)split * a.ws_rows * a.ws_ld, a.ws_ld, a.ws_lmax + (size_t)split * a.ws_rows,
+                       a.ws_lsum + (size_t)split * a.ws_rows, oacc, my_max, l_tot);
+    };
+
+    // (Q, the DMA offsets and the check-then-store order below are arranged so that the FIRST pass's hot
+    //  loop is instruction for instruction the loop of the kernel without a second pass -- hipcc's
+    //  allocation of these full-register-file kernels shifts with any liveness change around the loop;
+    //  tests/test_kernel_isa.py holds it in place)
+    run_pass();
+#if SDPA_RANGE_REDO
+    {   // range check of the deferred-rescale pass (see `defer` above).  The LDS tiles are dead here:
+        // every wave has passed the last step's barrier behind its last fragment read.
+        bool bad = !__builtin_isfinite(l_tot);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bad |= !__builtin_isfinite(oacc[tt][r]);
+        int *vote = reinterpret_cast<int *>(smem);
+        const int wave_bad = __any(bad) ? 1 : 0;
+        if (lane == 0) vote[wave] = wave_bad;
+        __syncthreads();
+        const int redo = __builtin_amdgcn_readfirstlane(vote[0] | vote[1] | vote[2] | vote[3]);
+        if (redo) {
+            __syncthreads();                  // the votes are read before the second pass's first DMA lands on them
+            defer = 0.f;
+            run_pass();
+        }
     }
-    store_rows(a.ws_contrib + (size_t)split * a.ws_rows * a.ws_ld, a.ws_ld, a.ws_lmax + (size_t)split * a.ws_rows,
-               a.ws_lsum + (size_t)split * a.ws_rows, oacc, my_max, l_tot);
+#endif
+    store_mine();
+    if (a.kv_splits <= 1) return;
     if (a.tickets == nullptr) return;         // the slots are merged by a later pass (split_merge_kernel)
 
     // ---- in-kernel split merge: the LAST workgroup of this query block to arrive merges the block's

@@ -108,10 +108,12 @@ struct Pool {
     bool stop = false;
 
     void start(int n, const std::vector<int> &devs) {
+        // (a thread only answers to jobs posted after it was created: `gen` survives a shutdown)
+        const unsigned long gen0 = gen;
         for (int i = 0; i < n; ++i)
-            th.emplace_back([this, i, dev = devs[i]] {
+            th.emplace_back([this, i, dev = devs[i], gen0] {
                 if (hipSetDevice(dev) != hipSuccess) (void)hipGetLastError();
-                unsigned long seen = 0;
+                unsigned long seen = gen0;
                 for (;;) {
                     int (*f)(void *, int);
                     void *a;
@@ -1079,7 +1081,17 @@ int create_rank(Rank &g, int dev) {
     HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
     HIP_TRY(hipStreamCreateWithFlags(&g.s_cp, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithPriority(&g.s_in, hipStreamNonBlocking, hi));
-    HIP_TRY(hipStreamCreateWithFlags(&g.s_run, hipStreamNonBlocking));
+    // $SDPA_COMM_CUS=R (opt-in): the compute stream leaves R compute units (rounded up to whole
+    // multiples of the 8 XCDs) to everything else.  A fused launch otherwise holds every wave slot of
+    // every CU until it ends (two 64 KiB workgroups and the whole register file per CU), so a merge
+    // collective, an RCCL kernel or a convert that becomes ready while it runs waits for its last
+    // workgroup -- streams and priorities do not help a kernel that finds no CU (profiles/r03/).
+    const int reserve = env_int("SDPA_COMM_CUS", 0);
+    if (reserve > 0) {
+        SDPA_TRY(sdpa::create_masked_stream(&g.s_run, reserve));
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&g.s_run, hipStreamNonBlocking));
+    }
     HIP_TRY(hipStreamCreateWithPriority(&g.s_out, hipStreamNonBlocking, hi));
     HIP_TRY(hipStreamCreateWithPriority(&g.s_comm, hipStreamNonBlocking, hi));
     for (int s = 0; s < 2; ++s) {

@@ -57,7 +57,10 @@ def main_loop_mix(k):
             continue                                   # contains another loop
         c = mix(lo, hi)
         n = sum(v for name, v in c.items() if name.startswith("v_mfma"))
-        if best is None or n > best[0] or (n == best[0] and hi - lo < best[1]):
+        # ties go to the FIRST loop in program order: the fp32 pipelined kernels carry their K/V walk
+        # twice (straight-line), and the second copy is the rare eager-rescale pass behind a failed
+        # range check -- it may spill, the first one may not
+        if best is None or n > best[0]:
             best = (n, hi - lo, c)
     assert best is not None, "no loop found"
     return best[2]
