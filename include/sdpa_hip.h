@@ -95,6 +95,8 @@ struct sdpa_timing {
                           /* 1 = reduce to the root (attention-mpi.c:380), 2 = reduce-scatter,   */
                           /* every rank widens and copies its rows over its own PCIe link        */
     int    enqueue_threads; /* host threads that enqueued (1 = the calling thread only)          */
+    int    host_convert_threads; /* $SDPA_HOST_CVT=1: host threads that converted fp64 -> operand  */
+                          /* images (attention-mpi.c:224-225's placement); 0 = the device converts */
 };
 
 /* ---- lifecycle ---------------------------------------------------------- */

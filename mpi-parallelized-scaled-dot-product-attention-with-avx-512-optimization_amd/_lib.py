@@ -30,7 +30,7 @@ class SdpaTiming(ctypes.Structure):
                 ("kv_chunks", _c_int), ("fused_launches", _c_int), ("plan", _c_int), ("merge", _c_int),
                 ("virtual_ranks", _c_int),
                 ("enqueue_total_us", ctypes.c_double), ("enqueue_first_kernel_us", ctypes.c_double * 16),
-                ("egress", _c_int), ("enqueue_threads", _c_int)]
+                ("egress", _c_int), ("enqueue_threads", _c_int), ("host_convert_threads", _c_int)]
 
 
 class SdpaError(RuntimeError):

@@ -1375,7 +1375,11 @@ __global__ void cvt_d2bf_kernel(const double *__restrict__ src, unsigned short *
 // dst[cidx * ldt + kvpos(r)] = bf16(src[r * cols + cidx]) for r < rows, 0 for rows <= r < ldt;
 // rows of dst beyond `cols` (up to cols_pad) are zero.  32x32 tiles through LDS so both sides
 // coalesce (kvpos permutes inside 16-element groups, ldt is a multiple of 32).
-__global__ void cvt_d2bf_t_kernel(const double *__restrict__ src, unsigned short *__restrict__ dst,
+__device__ __forceinline__ unsigned short to_bf16_elem(double x) { return (unsigned short)f32_to_bf16_rne(__double2float_rn(x)); }
+__device__ __forceinline__ unsigned short to_bf16_elem(unsigned short x) { return x; }      // rounded by the host already
+
+template <typename SRC>
+__global__ void cvt_d2bf_t_kernel(const SRC *__restrict__ src, unsigned short *__restrict__ dst,
                                   long rows, long rows_pad, int cols, int cols_pad, long ldt) {
     __shared__ unsigned short tile[32][33];
     const long r0 = (long)blockIdx.x * 32;
@@ -1384,8 +1388,7 @@ __global__ void cvt_d2bf_t_kernel(const double *__restrict__ src, unsigned short
     for (int k = ty; k < 32; k += 8) {
         const long r = r0 + k;
         const int cc = c0 + tx;
-        tile[k][tx] = (r < rows && cc < cols)
-                          ? (unsigned short)f32_to_bf16_rne(__double2float_rn(src[r * cols + cc])) : 0;
+        tile[k][tx] = (r < rows && cc < cols) ? to_bf16_elem(src[r * cols + cc]) : (unsigned short)0;
     }
     __syncthreads();
     for (int k = ty; k < 32; k += 8) {
@@ -1637,8 +1640,17 @@ hipError_t launch_cvt_d2bf_t_part(const double *src, unsigned short *dst, long r
                                   int cols_pad, long ldt, hipStream_t s) {
     if (rows_pad <= 0 || cols_pad <= 0) return hipSuccess;
     const unsigned gx = (unsigned)((rows_pad + 31) / 32), gy = (unsigned)((cols_pad + 31) / 32);
-    hipLaunchKernelGGL(cvt_d2bf_t_kernel, dim3(gx, gy), dim3(256), 0, s, src, dst, rows, rows_pad, cols,
+    hipLaunchKernelGGL(cvt_d2bf_t_kernel<double>, dim3(gx, gy), dim3(256), 0, s, src, dst, rows, rows_pad, cols,
                        cols_pad, ldt);
+    return hipGetLastError();
+}
+
+hipError_t launch_cvt_bf_t_part(const unsigned short *src, unsigned short *dst, long rows, long rows_pad, int cols,
+                                int cols_pad, long ldt, hipStream_t s) {
+    if (rows_pad <= 0 || cols_pad <= 0) return hipSuccess;
+    const unsigned gx = (unsigned)((rows_pad + 31) / 32), gy = (unsigned)((cols_pad + 31) / 32);
+    hipLaunchKernelGGL(cvt_d2bf_t_kernel<unsigned short>, dim3(gx, gy), dim3(256), 0, s, src, dst, rows, rows_pad,
+                       cols, cols_pad, ldt);
     return hipGetLastError();
 }
 

@@ -30,6 +30,7 @@
 // MPI_Ireduce ... next batch ... MPI_Wait, attention-mpi.c:364-380).
 #include "sdpa_coll.h"
 #include "sdpa_errors.h"
+#include "sdpa_hostcvt.h"
 #include "sdpa_internal.h"
 
 #include <math.h>
@@ -167,6 +168,7 @@ struct Engine {
     std::vector<Rank> r;
     Collectives *coll = nullptr;
     Pool pool;                           // enqueue threads, one per rank (empty with one rank)
+    sdpa::HostConverter *hc = nullptr;   // $SDPA_HOST_CVT=1: fp64 -> operand images on host threads (sdpa_hostcvt.h)
     sdpa_timing last = {};
 };
 // Heap-allocated and never destroyed on purpose: at process exit the order in which this library's
@@ -575,12 +577,50 @@ int merge_slots(const Plan &pl, Rank &rk, const RankPlan &rp, int s, int bs, int
 // K rows (is_v = false) or V rows (true) of chunk c of the rank's shard: host -> device into the
 // fp64 staging image on the copy stream, then the convert into the operand image
 // (attention-mpi.c:224-225 / :248-249 and the Scatterv of :258-264) on the convert stream.
-int stage_half(const Plan &pl, Rank &rk, const RankPlan &rp, const double *src, int c, bool is_v) {
+// $SDPA_HOST_CVT: the operand images of the call in flight as host threads write them (page-locked
+// staging, whole-problem layout: row r of K / V / Q at r * ld elements) and the conversion task that
+// fills each piece; a copy waits for its task on the host, then moves the finished image rows.
+struct HostImages {
+    sdpa::HostConverter *cv = nullptr;
+    char *k = nullptr, *v = nullptr, *q = nullptr;
+    int ldv_host = 0;                                      // row stride of the host V image (bf16: dense dv)
+    std::vector<std::vector<int>> k_task, v_task;          // [rank][chunk]
+    std::vector<std::vector<std::vector<int>>> q_task;     // [rank][batch][row piece]
+};
+HostImages &HI = *new HostImages;                          // (valid while a call with host converts is in flight)
+
+int stage_half(const Plan &pl, Rank &rk, const RankPlan &rp, const double *src, int c, bool is_v, int g = -1) {
     const Chunk &ch = rp.chunks[c];
     const size_t row0 = (size_t)rp.key_off + ch.k0;
     const int cols = is_v ? pl.dv : pl.dk;
-    double *stage = (double *)(is_v ? rk.v64.p : rk.k64.p) + (size_t)ch.k0 * cols;
     hipEvent_t copied = rk.ev_h2d[2 * c + (is_v ? 1 : 0)];
+    if (HI.cv && g >= 0) {
+        // the host threads have written (or are writing) this chunk's rows of the operand image
+        HI.cv->wait(is_v ? HI.v_task[g][c] : HI.k_task[g][c]);
+        if (!is_v || !pl.bf16) {
+            const int ld = is_v ? pl.ldv : pl.ldk;
+            const size_t el = is_v ? sizeof(float) : pl.kv_elem;
+            char *img = (char *)(is_v ? rk.vf.p : rk.kf.p) + (size_t)ch.k0 * ld * el;
+            HIP_TRY(hipMemcpyAsync(img, (is_v ? HI.v : HI.k) + row0 * ld * el, (size_t)ch.keys * ld * el,
+                                   hipMemcpyHostToDevice, rk.s_cp));
+            HIP_TRY(hipEventRecord(copied, rk.s_cp));
+            HIP_TRY(hipStreamWaitEvent(rk.s_in, copied, 0));
+            return SDPA_OK;
+        }
+        // bf16 V: the rows travel as dense bf16, the device transposes them into the Vt image
+        unsigned short *rows16 = (unsigned short *)rk.v64.p + (size_t)ch.k0 * pl.dv;
+        HIP_TRY(hipMemcpyAsync(rows16, HI.v + row0 * pl.dv * sizeof(unsigned short),
+                               (size_t)ch.keys * pl.dv * sizeof(unsigned short), hipMemcpyHostToDevice, rk.s_cp));
+        HIP_TRY(hipEventRecord(copied, rk.s_cp));
+        HIP_TRY(hipStreamWaitEvent(rk.s_in, copied, 0));
+        const long ldn = sdpa::bf16_pad_n(rp.key_cnt);
+        const bool last = ch.k0 + ch.keys == rp.key_cnt;
+        const long pad = last ? ldn - ch.k0 : ch.keys;
+        HIP_TRY(sdpa::launch_cvt_bf_t_part(rows16, (unsigned short *)rk.vf.p + ch.k0, ch.keys, pad, pl.dv,
+                                           sdpa::bf16_pad_dv(pl.dv), ldn, rk.s_in));
+        return SDPA_OK;
+    }
+    double *stage = (double *)(is_v ? rk.v64.p : rk.k64.p) + (size_t)ch.k0 * cols;
     HIP_TRY(copy_h2d_cuts(stage, src + row0 * cols, (size_t)ch.keys * cols * sizeof(double), is_v ? CUT.v : CUT.k,
                           rk.s_cp));
     HIP_TRY(hipEventRecord(copied, rk.s_cp));
@@ -621,15 +661,24 @@ Prefetched &PF = *new Prefetched;
 // Both halves of chunk c (skipping what a prefetch already moved), then the chunk's ready event.
 int stage_chunk(const Plan &pl, Rank &rk, const RankPlan &rp, int g, const double *K, const double *V, int c) {
     const bool have_k = PF.active && PF.k_done[g][c], have_v = PF.active && PF.v_done[g][c];
-    if (!have_k) SDPA_TRY(stage_half(pl, rk, rp, K, c, false));
-    if (!have_v) SDPA_TRY(stage_half(pl, rk, rp, V, c, true));
+    if (!have_k) SDPA_TRY(stage_half(pl, rk, rp, K, c, false, g));
+    if (!have_v) SDPA_TRY(stage_half(pl, rk, rp, V, c, true, g));
     HIP_TRY(hipEventRecord(rk.ev_kv[c], rk.s_in));
     return SDPA_OK;
 }
 
 // Rows [j0, j0+jr) of a Q batch: copy, convert into slot s of qf (attention-mpi.c:303,:325).
 int stage_q_rows(const Plan &pl, Rank &rk, const double *Q, int s, size_t i0, int j0, int jr, hipEvent_t copied,
-                 hipEvent_t converted) {
+                 hipEvent_t converted, int task = -1) {
+    if (HI.cv && task >= 0) {
+        HI.cv->wait(task);
+        HIP_TRY(hipMemcpyAsync((char *)rk.qf[s].p + (size_t)j0 * pl.ldq * pl.q_elem, HI.q + (i0 + j0) * pl.ldq * pl.q_elem,
+                               (size_t)jr * pl.ldq * pl.q_elem, hipMemcpyHostToDevice, rk.s_cp));
+        HIP_TRY(hipEventRecord(copied, rk.s_cp));
+        HIP_TRY(hipStreamWaitEvent(rk.s_in, copied, 0));
+        HIP_TRY(hipEventRecord(converted, rk.s_in));
+        return SDPA_OK;
+    }
     double *q64 = (double *)rk.q64[s].p + (size_t)j0 * pl.dk;
     HIP_TRY(hipMemcpyAsync(q64, Q + (i0 + j0) * pl.dk, (size_t)jr * pl.dk * sizeof(double), hipMemcpyHostToDevice,
                            rk.s_cp));
@@ -664,6 +713,7 @@ struct Call {
     double t_enter = 0.0;
     HostPins pins;
     bool do_pin = true, progressive = false, threaded = false;
+    bool hostcvt = false;              // K, V, Q are read by the host's convert threads: only `result` is page-locked
     size_t k_bytes = 0, v_bytes = 0;
     // progressive page-locking: what the first copies of every rank need (stage 0) and the rest of K/V (stage 2)
     std::vector<std::pair<const char *, size_t>> pin0, pin2;
@@ -693,7 +743,9 @@ struct Call {
 // in front of the copies that need it.  Nothing stays registered after the call.
 void pin_stage(Call &c, int stage) {
     if (c.do_pin) {
-        if (!c.progressive) {
+        if (c.hostcvt) {
+            if (stage == 3) c.pins.add(c.result, (size_t)c.m * c.dv * sizeof(double));
+        } else if (!c.progressive) {
             if (stage == 0) {
                 c.pins.add(c.K, c.k_bytes);
                 c.pins.add(c.V, c.v_bytes);
@@ -808,10 +860,11 @@ int rank_batch(Call &c, int g, int b) {
     }
     if (head_pieces) {
         for (int j = 0; j < pieces; ++j)
-            SDPA_TRY(stage_q_rows(pl, rk, c.Q, s, i0, j * pr, std::min(pr, bs - j * pr), rk.ev_qh[j], rk.ev_qp[j]));
+            SDPA_TRY(stage_q_rows(pl, rk, c.Q, s, i0, j * pr, std::min(pr, bs - j * pr), rk.ev_qh[j], rk.ev_qp[j],
+                                  HI.cv ? HI.q_task[g][b][j] : -1));
         HIP_TRY(hipEventRecord(rk.ev_q[s], rk.s_in));
     } else {
-        SDPA_TRY(stage_q_rows(pl, rk, c.Q, s, i0, 0, bs, rk.ev_qh[0], rk.ev_q[s]));
+        SDPA_TRY(stage_q_rows(pl, rk, c.Q, s, i0, 0, bs, rk.ev_qh[0], rk.ev_q[s], HI.cv ? HI.q_task[g][b][0] : -1));
     }
     // the chunks behind the first: enqueued AFTER chunk 0's launches (see below), so that a rank's first
     // kernel is issued before the host spends time on the K/V remainders' registration
@@ -1129,7 +1182,8 @@ int init_impl(int n_gpus) {
         return SDPA_ENODEV;
     }
     if (want > sdpa::kMaxRanks) return SDPA_EINVAL;
-    if (E.up && E.n == want && E.virtual_ranks == (virt > 0)) return SDPA_OK;
+    if (E.up && E.n == want && E.virtual_ranks == (virt > 0) && (E.hc != nullptr) == (env_int("SDPA_HOST_CVT", 0) > 0))
+        return SDPA_OK;
     if (E.up) sdpa_shutdown();
 
     E.r.assign(want, Rank());
@@ -1157,6 +1211,12 @@ int init_impl(int n_gpus) {
         }
         if (!E.coll) return SDPA_ERCCL;
     }
+    if (env_int("SDPA_HOST_CVT", 0) > 0) {
+        const int hw = (int)std::thread::hardware_concurrency();
+        const int dflt = std::max(1, std::min(32, hw > 4 ? hw - 2 : 1));
+        E.hc = sdpa::HostConverter::create(env_int("SDPA_HOST_CVT_THREADS", dflt));
+        if (!E.hc) return SDPA_ENOMEM;
+    }
     if (want > 1 && !(getenv("SDPA_ENQUEUE_THREADS") && atoi(getenv("SDPA_ENQUEUE_THREADS")) == 0)) {
         std::vector<int> devs(want);
         for (int i = 0; i < want; ++i) devs[i] = E.r[i].dev;
@@ -1178,6 +1238,8 @@ void sdpa_shutdown(void) {
     DeviceRestore restore;
     PF.reset();
     E.pool.shutdown();
+    delete E.hc;                         // (its page-locked staging goes with it: before the ranks' devices are released)
+    E.hc = nullptr;
     for (Rank &g : E.r) destroy_rank(g);
     E.r.clear();
     delete E.coll;
@@ -1193,6 +1255,8 @@ int sdpa_init(int n_gpus) {
     const int rc = init_impl(n_gpus);
     if (rc != SDPA_OK && !E.up) {        // a half-built engine is torn down, not leaked
         E.pool.shutdown();
+        delete E.hc;
+        E.hc = nullptr;
         for (Rank &g : E.r) destroy_rank(g);
         E.r.clear();
         delete E.coll;
@@ -1258,6 +1322,76 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
     const bool want_progressive = !getenv("SDPA_PROGRESSIVE_PIN") || atoi(getenv("SDPA_PROGRESSIVE_PIN")) != 0;
     if (c.do_pin && !PF.active && want_progressive) c.progressive = plan_progressive_pins(c);
     c.threaded = P > 1 && !E.pool.th.empty();
+
+    // $SDPA_HOST_CVT=1: host threads write the operand images; submit every conversion now, in the order
+    // the copies will ask for them (every rank's chunk 0, the first Q batch, the other chunks, the other
+    // batches), and let the enqueue code wait for each piece right before it copies it
+    struct EndHostCvt {
+        ~EndHostCvt() {
+            if (HI.cv) HI.cv->finish();          // no thread reads the caller's arrays once we return
+            HI = HostImages();
+        }
+    } end_hostcvt;
+    HI = HostImages();
+    if (E.hc && !PF.active) {
+        const size_t kel = pl.kv_elem, qel = pl.q_elem;
+        const int ldv_h = pl.bf16 ? dv : pl.ldv;
+        const size_t vel = pl.bf16 ? sizeof(unsigned short) : sizeof(float);
+        char *hk = (char *)E.hc->staging(0, (size_t)n * pl.ldk * kel);
+        char *hv = (char *)E.hc->staging(1, (size_t)n * ldv_h * vel);
+        char *hq = (char *)E.hc->staging(2, (size_t)m * pl.ldq * qel);
+        if (hk && hv && hq) {
+            c.hostcvt = true;
+            c.progressive = false;
+            CUT = PinCuts();
+            HI.cv = E.hc;
+            HI.k = hk; HI.v = hv; HI.q = hq;
+            HI.ldv_host = ldv_h;
+            E.hc->begin();
+            const sdpa::CvtKind kind = pl.bf16 ? sdpa::kCvtBf16 : sdpa::kCvtF32;
+            const double qmult = pl.bf16 ? (double)(1.44269504088896340736f * (1.0f / sqrtf((float)dk))) : 1.0;
+            HI.k_task.assign(P, {});
+            HI.v_task.assign(P, {});
+            HI.q_task.assign(P, {});
+            auto submit_chunk = [&](int g, int ch) {
+                const RankPlan &rp = pl.r[g];
+                const size_t row0 = (size_t)rp.key_off + rp.chunks[ch].k0;
+                HI.k_task[g].push_back(E.hc->submit(K + row0 * dk, hk + row0 * pl.ldk * kel, rp.chunks[ch].keys, dk,
+                                                     pl.ldk, kind, 1.0));
+                HI.v_task[g].push_back(E.hc->submit(V + row0 * dv, hv + row0 * ldv_h * vel, rp.chunks[ch].keys, dv,
+                                                     ldv_h, kind, 1.0));
+            };
+            auto submit_q = [&](int g, int b) {
+                const RankPlan &rp = pl.r[g];
+                HI.q_task[g].emplace_back();
+                const int j_lo = b * pl.B;
+                if (j_lo >= rp.row_cnt) return;
+                const int bs = std::min(pl.B, rp.row_cnt - j_lo);
+                const bool last_batch = j_lo + pl.B >= rp.row_cnt;
+                const int pr = (b == 0 || (last_batch && !pl.collectives)) ? piece_rows_of(pl, bs) : bs;
+                const int np = b == 0 ? (bs + pr - 1) / pr : 1;           // Q arrives in pieces with batch 0 only
+                const size_t i0 = (size_t)rp.row_off + j_lo;
+                for (int j = 0; j < np; ++j) {
+                    const int j0 = b == 0 ? j * pr : 0, jr = b == 0 ? std::min(pr, bs - j0) : bs;
+                    HI.q_task[g][b].push_back(E.hc->submit(Q + (i0 + j0) * dk, hq + (i0 + j0) * pl.ldq * qel, jr, dk,
+                                                            pl.ldq, kind, qmult));
+                }
+            };
+            const int q_ranks = pl.qrows ? P : 1;                          // K/V plan: every rank reads the same Q rows
+            for (int g = 0; g < P; ++g)
+                if (!pl.r[g].chunks.empty()) submit_chunk(g, 0);
+            for (int g = 0; g < q_ranks; ++g) submit_q(g, 0);
+            size_t max_chunks = 0;
+            for (int g = 0; g < P; ++g) max_chunks = std::max(max_chunks, pl.r[g].chunks.size());
+            for (size_t ch = 1; ch < max_chunks; ++ch)
+                for (int g = 0; g < P; ++g)
+                    if (ch < pl.r[g].chunks.size()) submit_chunk(g, (int)ch);
+            for (int b = 1; b < pl.nb; ++b)
+                for (int g = 0; g < q_ranks; ++g) submit_q(g, b);
+            for (int g = q_ranks; g < P; ++g) HI.q_task[g] = HI.q_task[0];
+            E.hc->kick();
+        }
+    }
 
     Rank &root = E.r[0];
     HIP_TRY(hipSetDevice(root.dev));
@@ -1345,6 +1479,7 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
     for (int g = 0; g < P && g < 16; ++g) T.enqueue_first_kernel_us[g] = c.first_kernel_us[g];
     T.egress = !pl.collectives ? 0 : (pl.egress_scatter ? 2 : 1);
     T.enqueue_threads = c.threaded ? P : 1;
+    T.host_convert_threads = c.hostcvt ? E.hc->threads() : 0;
     return SDPA_OK;
 }
 
@@ -1354,6 +1489,7 @@ int sdpa_kv_prefetch(const double *K, const double *V, int m, int n, int dk, int
     if (k_rows_final < 0 || v_rows_final < 0 || k_rows_final > n || v_rows_final > n) return SDPA_EINVAL;
     DeviceRestore restore;
     SDPA_TRY(lazy_init());
+    if (E.hc) return SDPA_OK;           // host converts read the caller's arrays inside the compute call: nothing to stage ahead
     Plan pl;
     make_plan(pl, m, n, dk, dv, flags);
     SDPA_TRY(check_plan(pl));
@@ -1454,6 +1590,12 @@ int sdpa_prepare(int m, int n, int dk, int dv, int flags) {
     make_plan(pl, m, n, dk, dv, flags);
     SDPA_TRY(check_plan(pl));
     SDPA_TRY(ensure_buffers(pl));
+    if (E.hc) {      // and the page-locked staging of the host converts (hundreds of MB: not inside a timed call)
+        const size_t vrow = pl.bf16 ? (size_t)dv * sizeof(unsigned short) : (size_t)pl.ldv * sizeof(float);
+        if (!E.hc->staging(0, (size_t)n * pl.ldk * pl.kv_elem) || !E.hc->staging(1, (size_t)n * vrow) ||
+            !E.hc->staging(2, (size_t)m * pl.ldq * pl.q_elem))
+            return SDPA_ENOMEM;
+    }
     // 2. one small call through the same code path: loads the code objects, sets the kernel
     //    attributes, creates the timing events (the kernel variants depend on dk, dv only)
     const int m0 = m < 256 ? m : 256, n0 = n < 2048 ? n : 2048;

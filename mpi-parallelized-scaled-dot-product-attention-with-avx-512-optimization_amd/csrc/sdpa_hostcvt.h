@@ -1,0 +1,37 @@
+// sdpa_hostcvt.h -- fp64 -> operand-image conversion on HOST threads (internal; $SDPA_HOST_CVT=1).
+//
+// The reference converts K, V and every Q batch on the host before they travel
+// (cvt_d2f_avx512, attention-mpi.c:31-64, called at :224-225, :248-249, :303, :325).  The default
+// here is the opposite -- fp64 crosses PCIe and the device converts -- because one rank's 8 MPI-era
+// cores are no match for HBM.  But a boundary call on short problems is bound by the PCIe bytes, and
+// the GPU box's host has a hundred cores: this is the reference's own placement, multi-threaded,
+// writing the operand images (fp32: half the bytes, bf16: a quarter) into page-locked staging that
+// goes over the link as it is.  Bit for bit the device converters' results (same roundings).
+#pragma once
+#include <stddef.h>
+
+namespace sdpa {
+
+enum CvtKind {
+    kCvtF32 = 0,      // float image, rows padded with zero columns to ld floats (cvt_d2f_kernel)
+    kCvtBf16 = 1,     // bf16 image, rows padded to ld, values bf16((float)(x * mult)) (cvt_d2bf_kernel)
+};
+
+class HostConverter {
+public:
+    static HostConverter *create(int threads);      // nullptr on failure
+    virtual ~HostConverter() {}
+    virtual int threads() const = 0;
+    // page-locked staging area `which` (0 = K image, 1 = V image, 2 = Q image), grown to `bytes`
+    virtual void *staging(int which, size_t bytes) = 0;
+    // one call: begin(), submit() every conversion in the order the copies will need them, kick();
+    // wait(task) in front of the copy that reads the task's output; finish() before the caller's arrays
+    // are handed back (also on error paths)
+    virtual void begin() = 0;
+    virtual int submit(const double *src, void *dst, long rows, int cols, int ld, CvtKind kind, double mult) = 0;
+    virtual void kick() = 0;
+    virtual void wait(int task) = 0;
+    virtual void finish() = 0;
+};
+
+}  // namespace sdpa

@@ -1,0 +1,212 @@
+// sdpa_hostcvt.hip -- see sdpa_hostcvt.h.  Host code only (no kernel in this translation unit).
+#include "sdpa_hostcvt.h"
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace sdpa {
+namespace {
+
+inline void relax() {
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+}
+
+// (float)double under the default rounding mode is round-to-nearest-even: what __double2float_rn and
+// _mm512_cvtpd_ps (attention-mpi.c:31-64) do.
+inline void rows_to_f32(const double *src, float *dst, long rows, int cols, int ld) {
+    for (long r = 0; r < rows; ++r) {
+        const double *s = src + r * cols;
+        float *d = dst + r * ld;
+        for (int c = 0; c < cols; ++c) d[c] = (float)s[c];
+        for (int c = cols; c < ld; ++c) d[c] = 0.f;
+    }
+}
+
+// the device converter's two roundings: fp64 -> fp32 (RNE), fp32 -> bf16 (RNE on the bit pattern)
+inline unsigned short to_bf16(double x) {
+    const float f = (float)x;
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+inline void rows_to_bf16(const double *src, unsigned short *dst, long rows, int cols, int ld, double mult) {
+    for (long r = 0; r < rows; ++r) {
+        const double *s = src + r * cols;
+        unsigned short *d = dst + r * ld;
+        if (mult == 1.0)
+            for (int c = 0; c < cols; ++c) d[c] = to_bf16(s[c]);
+        else
+            for (int c = 0; c < cols; ++c) d[c] = to_bf16(s[c] * mult);
+        for (int c = cols; c < ld; ++c) d[c] = 0;
+    }
+}
+
+struct Task {
+    const double *src;
+    void *dst;
+    int cols, ld;
+    CvtKind kind;
+    double mult;
+    std::atomic<long> remaining;
+    Task(const double *s, void *d, int c, int l, CvtKind k, double mu, long items)
+        : src(s), dst(d), cols(c), ld(l), kind(k), mult(mu), remaining(items) {}
+};
+
+struct Item {
+    int task;
+    long row0, rows;
+};
+
+// everything one call converts: the worker threads take a reference when they wake up, so a thread that
+// wakes late for a finished call finds an exhausted work list instead of the next call's half-built one
+struct Batch {
+    std::deque<Task> tasks;            // (deque: a Task holds an atomic and never moves)
+    std::vector<Item> items;
+    std::atomic<long> next{0};
+};
+
+class Pool final : public HostConverter {
+public:
+    ~Pool() override {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (std::thread &t : th_) t.join();
+        for (Buf &b : buf_)
+            if (b.p && hipHostFree(b.p) != hipSuccess) (void)hipGetLastError();
+    }
+    bool start(int n) {
+        for (int i = 0; i < n; ++i) th_.emplace_back([this] { loop(); });
+        return true;
+    }
+    int threads() const override { return (int)th_.size(); }
+
+    void *staging(int which, size_t bytes) override {
+        if (which < 0 || which > 2) return nullptr;
+        Buf &b = buf_[which];
+        if (b.cap >= bytes && b.p) return b.p;
+        if (b.p && hipHostFree(b.p) != hipSuccess) (void)hipGetLastError();
+        b.p = nullptr;
+        b.cap = 0;
+        const size_t want = bytes + bytes / 8 + 4096;      // some slack: the next problem is often a bit larger
+        if (hipHostMalloc(&b.p, want, hipHostMallocPortable) != hipSuccess) {
+            (void)hipGetLastError();
+            b.p = nullptr;
+            return nullptr;
+        }
+        b.cap = want;
+        return b.p;
+    }
+
+    void begin() override {
+        finish();
+        mine_ = std::make_shared<Batch>();
+    }
+    int submit(const double *src, void *dst, long rows, int cols, int ld, CvtKind kind, double mult) override {
+        if (!mine_) mine_ = std::make_shared<Batch>();
+        // items of ~64 KiB of source: small enough to balance, large enough to stream
+        long per = 8192 / (cols > 0 ? cols : 1);
+        if (per < 1) per = 1;
+        const long n_items = rows > 0 ? (rows + per - 1) / per : 0;
+        const int id = (int)mine_->tasks.size();
+        mine_->tasks.emplace_back(src, dst, cols, ld, kind, mult, n_items);
+        for (long r = 0; r < rows; r += per) mine_->items.push_back({id, r, rows - r < per ? rows - r : per});
+        return id;
+    }
+    void kick() override {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            cur_ = mine_;               // complete: nothing is added to a batch after this
+            ++gen_;
+        }
+        cv_.notify_all();
+    }
+    void wait(int task) override {
+        if (!mine_ || task < 0 || task >= (int)mine_->tasks.size()) return;
+        while (mine_->tasks[task].remaining.load(std::memory_order_acquire) > 0) relax();
+    }
+    // every item of the batch has been converted: no thread reads the caller's arrays any more
+    void finish() override {
+        if (!mine_) return;
+        bool kicked;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            kicked = cur_ == mine_;
+        }
+        if (kicked)
+            for (Task &t : mine_->tasks)
+                while (t.remaining.load(std::memory_order_acquire) > 0) relax();
+        mine_.reset();
+    }
+
+private:
+    struct Buf {
+        void *p = nullptr;
+        size_t cap = 0;
+    };
+    void loop() {
+        unsigned long seen = 0;
+        for (;;) {
+            std::shared_ptr<Batch> b;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+                b = cur_;
+            }
+            if (!b) continue;
+            const long total = (long)b->items.size();
+            for (;;) {
+                const long i = b->next.fetch_add(1, std::memory_order_relaxed);
+                if (i >= total) break;
+                const Item &it = b->items[i];
+                Task &t = b->tasks[it.task];
+                const double *s = t.src + it.row0 * t.cols;
+                if (t.kind == kCvtF32)
+                    rows_to_f32(s, (float *)t.dst + it.row0 * t.ld, it.rows, t.cols, t.ld);
+                else
+                    rows_to_bf16(s, (unsigned short *)t.dst + it.row0 * t.ld, it.rows, t.cols, t.ld, t.mult);
+                t.remaining.fetch_sub(1, std::memory_order_release);
+            }
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    bool stop_ = false;
+    unsigned long gen_ = 0;
+    std::shared_ptr<Batch> cur_;       // what the threads work on (guarded by mu_)
+    std::shared_ptr<Batch> mine_;      // the calling thread's handle on the batch it is building / waiting for
+    Buf buf_[3];
+};
+
+}  // namespace
+
+HostConverter *HostConverter::create(int threads) {
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    Pool *p = new Pool;
+    if (!p->start(threads)) {
+        delete p;
+        return nullptr;
+    }
+    return p;
+}
+
+}  // namespace sdpa

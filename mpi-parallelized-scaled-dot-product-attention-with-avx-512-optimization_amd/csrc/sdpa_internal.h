@@ -95,6 +95,9 @@ hipError_t launch_cvt_d2bf_t(const double *src, unsigned short *dst, long rows, 
 // ldt): zero-fills key positions [rows, rows_pad) only
 hipError_t launch_cvt_d2bf_t_part(const double *src, unsigned short *dst, long rows, long rows_pad, int cols,
                                   int cols_pad, long ldt, hipStream_t s);
+// the same from rows that are bf16 already (dense, row stride = cols): $SDPA_HOST_CVT, where the host rounds
+hipError_t launch_cvt_bf_t_part(const unsigned short *src, unsigned short *dst, long rows, long rows_pad, int cols,
+                                int cols_pad, long ldt, hipStream_t s);
 hipError_t launch_split_merge(const PartialArgs &a, hipStream_t s);
 
 int  pick_kv_splits(int m, int n_local, int dk, int dv);

@@ -42,7 +42,8 @@ def engine(pkg, monkeypatch):
         pkg.shutdown()
         for k in ("SDPA_VIRTUAL_GPUS", "SDPA_FORCE_COLLECTIVES", "SDPA_QBATCH", "SDPA_KV_CHUNK_MIN",
                   "SDPA_KV_CHUNK_MAX", "SDPA_ROW_PIECES", "SDPA_PIECE_MIN_ROWS", "SDPA_PLAN", "SDPA_MERGE", "SDPA_PRECISION",
-                  "SDPA_EGRESS", "SDPA_ENQUEUE_THREADS", "SDPA_PROGRESSIVE_PIN"):
+                  "SDPA_EGRESS", "SDPA_ENQUEUE_THREADS", "SDPA_PROGRESSIVE_PIN", "SDPA_HOST_CVT", "SDPA_HOST_CVT_THREADS",
+                  "SDPA_COMM_CUS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, str(v))
@@ -317,3 +318,36 @@ def test_one_rank_forced_collectives_use_the_comm_stream(engine, orc, O):
         t = pkg.last_timing()
         assert t["q_batches"] == 5 and t["merge"] == (1 if merge == "gather" else 2) and t["egress"] == 1, t
         check(got, orc.attention_f64(Q, K, V), V, "forced collectives, %s" % merge)
+
+
+# ------------------------------------------------- $SDPA_HOST_CVT: the reference's own convert placement -----
+@pytest.mark.parametrize("m,n,dk,dv,prec,env", [
+    (700, 9000, 128, 128, None, {}),                                   # dense fp32 images, streamed chunks
+    (300, 5000, 72, 40, None, {}),                                     # padded fp32 images (ld 128 / 64)
+    (200, 6000, 300, 96, None, {"SDPA_QBATCH": 64}),                   # dk-split kernel, 4 Q batches
+    (700, 9000, 128, 128, "bf16", {}),                                 # bf16: K/Q images from the host, V rows transposed on the device
+    (260, 5000, 512, 512, "bf16", {}),                                 # bf16 wide kernel
+    (300, 5000, 100, 200, "bf16", {"SDPA_QBATCH": 128}),               # bf16 padded dims, 3 batches
+    (1500, 9000, 128, 128, None, {"SDPA_VIRTUAL_GPUS": 3, "SDPA_QBATCH": 512}),                      # 3 loopback ranks, 3 batches
+    (900, 7000, 64, 64, None, {"SDPA_VIRTUAL_GPUS": 2, "SDPA_PLAN": "qrows"}),                       # query rows sharded: every rank converts its own Q rows
+    (300, 5, 64, 64, None, {"SDPA_VIRTUAL_GPUS": 4}),                                                # n < P: empty shards
+])
+def test_host_side_convert_gives_the_device_converts_result_bit_for_bit(m, n, dk, dv, prec, env, engine, orc, O):
+    """$SDPA_HOST_CVT=1: host threads convert fp64 -> fp32 / bf16 operand images into page-locked staging (the
+    reference converts on the host too, cvt_d2f_avx512 at attention-mpi.c:224-225, :303) and half / a quarter
+    of the bytes cross PCIe.  Same roundings as the device converters, so the SAME images and the same
+    result bit for bit; checked against the fp64 oracle as well."""
+    Q, K, V = O.make_inputs(m, n, dk, dv, "D2", seed=m + dk)
+    common = dict(SDPA_KV_CHUNK_MIN=1024, SDPA_KV_CHUNK_MAX=2048, SDPA_PIECE_MIN_ROWS=128, **env)
+    pkg = engine(**common)
+    want = pkg.attention(Q, K, V, precision=prec)
+    assert pkg.last_timing()["host_convert_threads"] == 0
+    tol = 1e-2 * max(1.0, float(np.abs(V).max())) if prec == "bf16" else None
+    check(want, orc.attention_f64(Q, K, V), V, "device converts", tol)
+    for threads in (3, 16):
+        pkg = engine(SDPA_HOST_CVT=1, SDPA_HOST_CVT_THREADS=threads, **common)
+        for rep in range(2):
+            got = pkg.attention(Q, K, V, precision=prec)
+            assert np.array_equal(got, want), "host converts (%d threads, call %d) differ from the device converts" % (threads, rep)
+        t = pkg.last_timing()
+        assert t["host_convert_threads"] == threads and t["register_us"] >= 0, t

@@ -14,6 +14,9 @@ sweep = "--sweep" in sys.argv
 pinned = "--pinned" in sys.argv
 lib = pkg.load()
 pkg.init(1)
+# --hostcvt: A/B of the convert placement -- each shape first with the device converts, then with
+# $SDPA_HOST_CVT=1 at several thread counts (the engine is re-created for each)
+hostcvt = "--hostcvt" in sys.argv
 KNOBS = ("SDPA_QBATCH", "SDPA_KV_CHUNK_MIN", "SDPA_KV_CHUNK_MAX", "SDPA_ROW_PIECES", "SDPA_PIECE_MIN_ROWS", "SDPA_HOST_REGISTER",
          "SDPA_PROGRESSIVE_PIN")
 SWEEP = [{},
@@ -50,11 +53,17 @@ for name in args or ["headline", "config2", "config1"]:
     (Q, pq), (K, pk), (V, pv) = hostbuf(Q), hostbuf(K), hostbuf(V)
     R, pr = hostbuf(np.zeros((m, d)))
     flags = 2 if prec else 0
-    for knobs in (SWEEP if sweep else [{}]):
-        for k in KNOBS:
+    CVT = [{}] + ([{"SDPA_HOST_CVT": 1, "SDPA_HOST_CVT_THREADS": t} for t in (8, 16, 32, 64)] if hostcvt else [])
+    for knobs in (SWEEP if sweep else CVT):
+        for k in KNOBS + ("SDPA_HOST_CVT", "SDPA_HOST_CVT_THREADS"):
             os.environ.pop(k, None)
         for k, v in knobs.items():
             os.environ[k] = str(v)
+        if hostcvt:
+            pkg.shutdown()
+            pkg.init(1)
+            if lib.sdpa_prepare(m, n, d, d, flags) != 0:
+                raise SystemExit("sdpa_prepare failed")
         best = None
         for it in range(6):
             t0 = time.perf_counter()
@@ -66,7 +75,7 @@ for name in args or ["headline", "config2", "config1"]:
         row = {"shape": name, "pinned": pinned, "knobs": knobs}
         for k in ("total_us", "head_us", "tail_us", "register_us", "kv_stage_us", "pipeline_us", "kernel_us"):
             row[k.replace("_us", "_ms")] = round(best[k] / 1e3, 3)
-        for k in ("q_batches", "kv_chunks", "fused_launches", "kv_splits"):
+        for k in ("q_batches", "kv_chunks", "fused_launches", "kv_splits", "host_convert_threads"):
             row[k] = best[k]
         row["kernel_tflops"] = round(4.0 * m * n * d / (best["kernel_us"] * 1e-6) / 1e12, 1)
         print(json.dumps(row), flush=True)

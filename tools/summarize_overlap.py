@@ -18,7 +18,9 @@ for name, a, b, st in coll:
     over = [(fa, fb, fs) for _, fa, fb, fs in fused if fa < b and fb > a]
     n_over += 1 if over else 0
     if (name, a, b, st) in tail:
-        short = name.split("(")[0].split("::")[-1]
+        import re
+        mm = re.search(r"(loop_\w+)", name)
+        short = mm.group(1) if mm else name[:28]
         print("%-28s stream %-4s %9.1f .. %9.1f us (%6.1f us)  concurrent fused launches: %s" % (
             short, st, (a - t0) / 1e3, (b - t0) / 1e3, (b - a) / 1e3,
             ", ".join("stream %s %.0f..%.0f us" % (fs, (fa - t0) / 1e3, (fb - t0) / 1e3) for fa, fb, fs in over) or "none"))
