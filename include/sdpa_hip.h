@@ -185,6 +185,15 @@ SDPA_API int sdpa_kv_prefetch(const double *K, const double *V, int m, int n, in
 SDPA_API void *sdpa_host_alloc(size_t bytes);
 SDPA_API void  sdpa_host_free(void *p);
 
+/* The host-side converter: `rows` rows of fp64 -> rows of an operand image, on the calling thread, with
+ * the device converters' roundings bit for bit.  kind 0: float rows of `ld` floats, pad columns zero
+ * (cvt_d2f_avx512, attention-mpi.c:31-64: vcvtpd2ps, 8 doubles at a time, where the CPU has AVX-512);
+ * kind 1: bf16 rows, bf16((float)(x * mult)), both roundings to nearest even.  flags bit 0: the plain C
+ * rows instead of the AVX-512 ones.  This is what $SDPA_HOST_CVT=1 runs on a pool of host threads inside
+ * sdpa_attention_f64 (the reference's own placement of the converts, :224-225, :303); it needs no GPU.  */
+SDPA_API int sdpa_host_cvt_rows(const double *src, void *dst, long rows, int cols, int ld, int kind,
+                                double mult, int flags);
+
 /* K/V row partition, attention-mpi.c:19-27. */
 SDPA_API int sdpa_owner_count(int n, int size, int rank);
 SDPA_API int sdpa_owner_disp(int n, int size, int rank);

@@ -6,6 +6,7 @@
 // sdpa_fwd_bf16.hip and sdpa_aux.hip, for hosts that own device memory and collectives
 // themselves (one process per GPU with RCCL through torch.distributed).
 #include "sdpa_errors.h"
+#include "sdpa_hostcvt.h"
 #include "sdpa_internal.h"
 
 #include <stdint.h>
@@ -116,6 +117,15 @@ int sdpa_dev_shard_partial_f32(const float *Qf, int ldq, const float *Kf, int ld
         sdpa::carve_workspace(a, workspace, sdpa::dense_ld(dv));
     }
     HIP_TRY(sdpa::launch_shard_partial(a, (hipStream_t)stream));
+    return SDPA_OK;
+}
+
+int sdpa_host_cvt_rows(const double *src, void *dst, long rows, int cols, int ld, int kind, double mult, int flags) {
+    if (rows < 0 || cols <= 0 || ld < cols || (kind != 0 && kind != 1)) return SDPA_EINVAL;
+    if (rows == 0) return SDPA_OK;
+    if (!src || !dst) return SDPA_EINVAL;
+    sdpa::host_convert_rows(src, dst, rows, cols, ld, kind == 0 ? sdpa::kCvtF32 : sdpa::kCvtBf16, kind == 0 ? 1.0 : mult,
+                            (flags & 1) != 0);
     return SDPA_OK;
 }
 

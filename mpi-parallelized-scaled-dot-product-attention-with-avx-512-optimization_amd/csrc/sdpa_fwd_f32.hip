@@ -36,14 +36,12 @@
 //                                   accumulator file, asm score chains: 137 TFLOP/s at dk = dv = 256)
 //   fused_partial_kernel<DKP,DVP>   any dk <= 256 (padded to 32/64/128/256), any dv (chunks of <= 128
 //                                   columns): register-staged
-//   fused_dksplit_kernel<DKS,DVS>   256 < dk <= 512, and non-dense 128 < dk <= 256 with dv > 128: the four waves split dk
-//                                   (scores) and dv (accumulate), partial score tiles exchanged through LDS,
-//                                   K/V straight from global memory
-//   fused_dksplit_q_kernel<.,.,1>   512 < dk <= 1024: the same with one query block per workgroup, 192/256-wide dk slices
+//   (fused_dksplit_kernel<DKS,DVS,QB>, 256 < dk <= 1024 and non-dense 128 < dk <= 256 with dv > 128, lives in
+//    sdpa_fwd_f32_dksplit.hip)
 //   generic_partial_kernel          dk > 1024: VALU-only correctness path
 //   split_merge_kernel              merge of the in-GPU K/V splits
 //
-#include "sdpa_internal.h"
+#include "sdpa_f32_device.h"
 
 #include <math.h>
 #include <algorithm>
@@ -62,71 +60,6 @@
 #endif
 
 namespace sdpa {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x1 __attribute__((ext_vector_type(1)));
-
-// key row (within a 32-row tile) held in accumulator register r of half-wave hi
-// for the 32x32 MFMA C/D layout: row = (r&3) + 8*(r>>2) + 4*hi.
-__device__ __forceinline__ constexpr int crow(int r, int hi) {
-    return (r & 3) + 8 * (r >> 2) + 4 * hi;
-}
-
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-
-// exp2 / max as volatile asm: ordered against sched_barrier() and each other, so they stay in
-// the MFMA shadow they were written in (the compiler otherwise gathers pure VALU ops after the
-// MFMA block).  s_nop 0: a TRANS result needs one wait state before a non-TRANS VALU reads it.
-__device__ __forceinline__ float pinned_exp2(float x) {
-    float y;
-    asm volatile("v_exp_f32 %0, %1\n\ts_nop 0" : "=v"(y) : "v"(x));
-    return y;
-}
-__device__ __forceinline__ float pinned_max3(float a, float b, float c) {
-    float y;
-    asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(y) : "v"(a), "v"(b), "v"(c));
-    return y;
-}
-__device__ __forceinline__ float pinned_max(float a, float b) {
-    float y;
-    asm volatile("v_max_f32 %0, %1, %2" : "=v"(y) : "v"(a), "v"(b));
-    return y;
-}
-
-// bijective "contiguous chunk per XCD" remap of a 1-D grid: hardware places
-// block b on XCD b%8; give each XCD a contiguous range of work items so blocks
-// that share a K/V split share an L2.
-__device__ __forceinline__ int xcd_remap(int bid, int total) {
-    const int xcd = bid & 7, slot = bid >> 3;
-    const int q = total >> 3, r = total & 7;
-    const int first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return first + slot;
-}
-
-// NT consecutive floats of one V row (one per 32-column O^T tile) as a native vector.
-template <int NT> struct VFrag;
-template <> struct VFrag<4> {
-    f32x4 v;
-    static __device__ __forceinline__ VFrag load(const float *p) { return {*reinterpret_cast<const f32x4 *>(p)}; }
-};
-template <> struct VFrag<8> {      // two float4, 128 columns apart (tiles 0..3 and 4..7)
-    f32x8 v;
-    static __device__ __forceinline__ VFrag load(const float *p) {
-        const f32x4 lo = *reinterpret_cast<const f32x4 *>(p), up = *reinterpret_cast<const f32x4 *>(p + 128);
-        return {__builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, 6, 7)};
-    }
-};
-template <> struct VFrag<2> {
-    f32x2 v;
-    static __device__ __forceinline__ VFrag load(const float *p) { return {*reinterpret_cast<const f32x2 *>(p)}; }
-};
-template <> struct VFrag<1> {
-    f32x1 v;
-    static __device__ __forceinline__ VFrag load(const float *p) { VFrag f; f.v[0] = *p; return f; }
-};
 
 // dv > 128 is processed in chunks of 128 columns by separate workgroups (n_chunks > 1; the score
 // tile is recomputed per chunk); dk up to 256 keeps the whole Q fragment in registers (128 VGPRs,
@@ -510,6 +443,18 @@ __global__ __launch_bounds__(256, (DK + DV > 256) ? 1 : 2) void fused_pipelined_
         (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)smem);
     auto dma_piece = [&](const char *gbase, unsigned lane_off, unsigned lds_byte) __attribute__((always_inline)) {
         if constexpr (ABL & 1) return;
+#ifdef SDPA_DMA_ASSERT
+        // audit build (tools/build_variant.sh ... -DSDPA_DMA_ASSERT, never shipped): every 16-byte DMA source must lie
+        // inside the K or the V image of this launch, every 1-KiB destination inside the workgroup's LDS tiles
+        {
+            const char *src = gbase + lane_off;
+            const char *k0 = reinterpret_cast<const char *>(a.K), *k1 = k0 + (size_t)a.n_local * DK * 4;
+            const char *v0 = reinterpret_cast<const char *>(a.V), *v1 = v0 + (size_t)a.n_local * DV * 4;
+            const bool in_k = src >= k0 && src + 16 <= k1, in_v = src >= v0 && src + 16 <= v1;
+            const bool lds_ok = lds_byte >= lds_base && lds_byte + 1024u <= lds_base + (unsigned)(2 * (KTILE + VTILE)) * 4u;
+            if (!(in_k || in_v) || !lds_ok || (lane_off & 15u) != 0) __builtin_trap();
+        }
+#endif
         // M0 is written without save/restore: hipcc treats it as reserved and re-initialises it next
         // to each of its own uses (the same choice as in the bf16 wide kernel)
         asm volatile("s_mov_b32 m0, %1\n\t"
@@ -901,502 +846,6 @@ __global__ __launch_bounds__(256, (DK + DV > 256) ? 1 : 2) void fused_pipelined_
 }
 
 // ---------------------------------------------------------------------------
-// 256 < dk <= 512 in fp32 (and 128 < dk <= 256 when dv > 128, where it saves the per-chunk score
-// recompute).  A 32 x 512 fp32 Q fragment alone is 256 registers, so here the four waves of a
-// workgroup SPLIT the contraction dimensions between them instead of the query rows:
-//   * workgroup = 64 query rows (two 32-row MFMA blocks).  Wave w holds Q[:, DKS*w .. DKS*(w+1))
-//     (128 registers at DKS = 128) and the O^T slice of V columns [DVS*w, DVS*(w+1)) of the chunk (<= 128 regs);
-//   * per 32-key tile a wave computes the PARTIAL score tile over its dk slice -- K fragments come
-//     straight from global memory, nobody else needs them -- the four partials go through LDS and
-//     every wave sums them in the same fixed order (bitwise the same S^T in all four, so the
-//     replicated online-softmax state stays in step), then each wave accumulates its dv slice,
-//     V fragments straight from global memory as well;
-//   * no K/V tile in LDS at all; one barrier per tile (the exchange buffer is double-buffered).
-// 256 MFMAs of 64 cycles per wave and tile against 32 KiB of global reads: matrix-pipe bound.
-// Same outputs and the same online-softmax arithmetic as fused_partial_kernel.
-// ---------------------------------------------------------------------------
-template <int DKS, int DVS>
-__global__ __launch_bounds__(256, 1) void fused_dksplit_kernel(
-    PartialArgs a, int kv_per_split, int n_qblocks, int n_chunks, float scale) {
-    // DKS: dk slice of one wave (dk is treated as padded to 4*DKS = 256, 384 or 512)
-    constexpr int NU = DKS / 8;         // 16-byte K reads (4 MFMA k-steps each) per tile per lane
-    constexpr int NT = DVS / 32;        // 32-row O^T blocks per wave; also floats per V read
-    constexpr int XLD = 20;             // floats per lane in the exchange buffer: 16 + pad, b128 conflict-free
-    constexpr int XBUF = 8 * 64 * XLD;  // 4 waves x 2 query blocks x 64 lanes
-    constexpr int PD = 4;               // fragment prefetch depth (16-byte reads in flight)
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][XBUF]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31;
-    const int hi = lane >> 5;
-
-    int work = xcd_remap(blockIdx.x, gridDim.x);
-    const int qblock = work % n_qblocks;
-    work /= n_qblocks;
-    const int chunk = work % n_chunks;
-    const int split = work / n_chunks;
-    const int dk0 = wave * DKS;                          // first dk index of this wave
-    const int dvw0 = chunk * (4 * DVS) + wave * DVS;     // first V / output column of this wave
-
-    const int kv_begin = split * kv_per_split;
-    const int kv_end = min(a.n_local, kv_begin + kv_per_split);
-    const int ntiles = kv_end > kv_begin ? (kv_end - kv_begin + kKvTile - 1) / kKvTile : 0;
-    const float c = scale * 1.44269504088896340736f;
-
-    // Q fragments of both query blocks (k-slot mapping as in fused_partial_kernel: MFMA step
-    // (u,e) of half-wave hi uses dk index dk0 + 8u + 4hi + e); zero past the leading dimension
-    f32x4 qf[2][NU];
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-        const int qrow = qblock * 64 + qb * 32 + li;
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int col = dk0 + 8 * u + 4 * hi;
-            qf[qb][u] = (qrow < a.m && col < a.ldq)
-                            ? *reinterpret_cast<const f32x4 *>(a.Q + (size_t)qrow * a.ldq + col)
-                            : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-
-    // the second query block's fragments live in the accumulator file (an MFMA reads its B operand
-    // from AGPRs as well): 64 registers less on the VGPR side, where the prefetch rings are
-#pragma unroll
-    for (int u = 0; u < NU; ++u) asm volatile("" : "+a"(qf[1][u]));
-
-    f32x16 oacc[NT][2];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[t][qb][r] = 0.f;
-    float m_run[2] = {-INFINITY, -INFINITY};
-    float l_run[2] = {0.f, 0.f};
-    // keep the O accumulators AGPR-class at the tile boundaries: left alone hipcc carries them as
-    // VGPR values (the rescale multiplies them), copies all of them every tile and spills Q
-    // fragments to scratch -- whose reloads put an s_waitcnt vmcnt(0) in front of the K prefetches
-    auto pin_o = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt) {
-            asm volatile("" : "+a"(oacc[tt][0]));
-            asm volatile("" : "+a"(oacc[tt][1]));
-        }
-    };
-    pin_o();
-
-    // (addresses: scalar 64-bit tile base + ONE unsigned 32-bit per-lane byte offset, the saddr form)
-    // K columns past the leading dimension are clamped to the last in-row float4 (Q is zero there);
-    // V columns likewise (never stored); rows past the shard end are clamped to its last row (their
-    // scores are masked to -inf, and 0 * finite = 0 in P.V).
-    const unsigned kcol0 = (unsigned)(dk0 + 4 * hi) * 4u, kcol_last = (unsigned)(a.ldk - 4) * 4u;
-    auto kcolb = [&](int u) __attribute__((always_inline)) -> unsigned { return min(kcol0 + 32u * u, kcol_last); };
-    const unsigned vcolb = (unsigned)min(dvw0 + NT * li, a.ldv - NT) * 4u;
-
-    for (int t = 0; t < ntiles; ++t) {
-        const int base = kv_begin + t * kKvTile;
-        const int last = kv_end - 1 - base;
-        const char *kb = reinterpret_cast<const char *>(a.K + (size_t)base * a.ldk);
-        const char *vb = reinterpret_cast<const char *>(a.V + (size_t)base * a.ldv);
-        const unsigned krow = (unsigned)min(li, last) * (unsigned)a.ldk * 4u;
-
-        // ---- partial S^T over this wave's dk slice, both query blocks
-        pin_o();
-        f32x16 s0, s1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-        f32x4 kq[PD];
-#pragma unroll
-        for (int i = 0; i < PD; ++i) kq[i] = *reinterpret_cast<const f32x4 *>(kb + (krow + kcolb(i)));
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const f32x4 kf = kq[u % PD];
-            if (u + PD < NU) kq[u % PD] = *reinterpret_cast<const f32x4 *>(kb + (krow + kcolb(u + PD)));
-            __builtin_amdgcn_sched_barrier(0);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[0][u].x, s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[1][u].x, s1, 0, 0, 0);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[0][u].y, s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[1][u].y, s1, 0, 0, 0);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[0][u].z, s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[1][u].z, s1, 0, 0, 0);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[0][u].w, s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[1][u].w, s1, 0, 0, 0);
-        }
-
-        pin_o();
-        // first V fragments of this tile go out now, under the exchange
-        VFrag<NT> vq[PD];
-#pragma unroll
-        for (int i = 0; i < PD; ++i)
-            vq[i] = VFrag<NT>::load(reinterpret_cast<const float *>(
-                vb + ((unsigned)min(crow(i, 0) + 4 * hi, last) * (unsigned)a.ldv * 4u + vcolb)));
-
-        // ---- exchange: every wave ends up with the same full S^T (fixed summation order)
-        float *xb = smem + (t & 1) * XBUF;
-        {
-            float *mine = xb + ((wave * 2) * 64 + lane) * XLD;
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                *reinterpret_cast<f32x4 *>(mine + 4 * q4) = f32x4{s0[4 * q4], s0[4 * q4 + 1], s0[4 * q4 + 2], s0[4 * q4 + 3]};
-                *reinterpret_cast<f32x4 *>(mine + 64 * XLD + 4 * q4) =
-                    f32x4{s1[4 * q4], s1[4 * q4 + 1], s1[4 * q4 + 2], s1[4 * q4 + 3]};
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const float *theirs = xb + ((w * 2) * 64 + lane) * XLD;
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const f32x4 p0 = *reinterpret_cast<const f32x4 *>(theirs + 4 * q4);
-                const f32x4 p1 = *reinterpret_cast<const f32x4 *>(theirs + 64 * XLD + 4 * q4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    s0[4 * q4 + e] = (w == 0) ? p0[e] : s0[4 * q4 + e] + p0[e];
-                    s1[4 * q4 + e] = (w == 0) ? p1[e] : s1[4 * q4 + e] + p1[e];
-                }
-            }
-        }
-
-        pin_o();
-        // ragged last tile: key rows past the shard end contribute exp(-inf) = 0
-        const int valid = kv_end - base;
-        if (valid < kKvTile) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (crow(r, hi) >= valid) { s0[r] = -INFINITY; s1[r] = -INFINITY; }
-        }
-
-        // ---- online softmax, replicated in the four waves (identical inputs, identical results)
-        auto softmax = [&](f32x16 &sx, int qb) __attribute__((always_inline)) {
-            float tmax = sx[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sx[r]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-            const float m_new = fmaxf(m_run[qb], tmax);
-            if (__any(m_new > m_run[qb])) {
-                const float alpha = fast_exp2((m_run[qb] - m_new) * c);
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) oacc[tt][qb][r] *= alpha;
-                l_run[qb] *= alpha;
-                m_run[qb] = m_new;
-            }
-            const float mc = m_run[qb] * c;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                sx[r] = fast_exp2(fmaf(sx[r], c, -mc));
-                l_run[qb] += sx[r];
-            }
-        };
-        softmax(s0, 0);
-        softmax(s1, 1);
-        pin_o();
-
-        // ---- O^T slice += V_tile^T . P^T   (k-step r of half-wave hi is key row crow(r, hi))
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const VFrag<NT> vf = vq[r % PD];
-            if (r + PD < 16)
-                vq[r % PD] = VFrag<NT>::load(reinterpret_cast<const float *>(
-                    vb + ((unsigned)min(crow(r + PD, 0) + 4 * hi, last) * (unsigned)a.ldv * 4u + vcolb)));
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt) {
-                oacc[tt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.v[tt], s0[r], oacc[tt][0], 0, 0, 0);
-                oacc[tt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.v[tt], s1[r], oacc[tt][1], 0, 0, 0);
-            }
-        }
-        pin_o();
-    }
-
-    // ---- epilogue
-    float *out = a.contrib;
-    float *omax = a.lmax, *osum = a.lsum;
-    int ldo = a.ldo;
-    if (a.kv_splits > 1) {
-        ldo = a.ws_ld;
-        out = a.ws_contrib + (size_t)split * a.ws_rows * ldo;
-        omax = a.ws_lmax + (size_t)split * a.ws_rows;
-        osum = a.ws_lsum + (size_t)split * a.ws_rows;
-    }
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-        const int qrow = qblock * 64 + qb * 32 + li;
-        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32);
-        if (qrow < a.m) {
-            float *orow = out + (size_t)qrow * ldo + dvw0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int col0 = NT * crow(r, hi);
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt)
-                    if (dvw0 + col0 + tt < a.dv) orow[col0 + tt] = oacc[tt][qb][r];
-            }
-            if (wave == 0 && hi == 0 && chunk == 0) {
-                omax[qrow] = m_run[qb] * scale;
-                osum[qrow] = l_tot;
-            }
-        }
-    }
-}
-
-// The same kernel with the number of 32-row query blocks per workgroup as a parameter; shipped with
-// QB = 1 and 256-wide dk slices for 512 < dk <= 1024, where the Q slice of ONE block already is 128
-// registers.  (Instantiated with QB = 2 it is the kernel above in substance, but hipcc vectorises its
-// exchange sums differently and spills: -5 % at dk = dv = 512, so the two-block form stays as written.)
-template <int DKS, int DVS, int QB>
-__global__ __launch_bounds__(256, 1) void fused_dksplit_q_kernel(
-    PartialArgs a, int kv_per_split, int n_qblocks, int n_chunks, float scale) {
-    // DKS: dk slice of one wave (dk is treated as padded to 4*DKS = 256, 384, 512 or 1024)
-    // QB:  32-row query blocks per workgroup: 2, or 1 where the Q slice of ONE block already is 128
-    //      registers (DKS = 256: 512 < dk <= 1024)
-    static_assert(QB == 1 || QB == 2, "one or two query blocks");
-    constexpr int ROWS = 32 * QB;
-    constexpr int NU = DKS / 8;         // 16-byte K reads (4 MFMA k-steps each) per tile per lane
-    constexpr int NT = DVS / 32;        // 32-row O^T blocks per wave; also floats per V read
-    constexpr int XLD = 20;             // floats per lane in the exchange buffer: 16 + pad, b128 conflict-free
-    constexpr int XBUF = 4 * QB * 64 * XLD;  // 4 waves x QB query blocks x 64 lanes
-    constexpr int PD = 4;               // fragment prefetch depth (16-byte reads in flight)
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][XBUF]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31;
-    const int hi = lane >> 5;
-
-    int work = xcd_remap(blockIdx.x, gridDim.x);
-    const int qblock = work % n_qblocks;
-    work /= n_qblocks;
-    const int chunk = work % n_chunks;
-    const int split = work / n_chunks;
-    const int dk0 = wave * DKS;                          // first dk index of this wave
-    const int dvw0 = chunk * (4 * DVS) + wave * DVS;     // first V / output column of this wave
-
-    const int kv_begin = split * kv_per_split;
-    const int kv_end = min(a.n_local, kv_begin + kv_per_split);
-    const int ntiles = kv_end > kv_begin ? (kv_end - kv_begin + kKvTile - 1) / kKvTile : 0;
-    const float c = scale * 1.44269504088896340736f;
-
-    // Q fragments of both query blocks (k-slot mapping as in fused_partial_kernel: MFMA step
-    // (u,e) of half-wave hi uses dk index dk0 + 8u + 4hi + e); zero past the leading dimension
-    f32x4 qf[QB][NU];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        const int qrow = qblock * ROWS + qb * 32 + li;
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int col = dk0 + 8 * u + 4 * hi;
-            qf[qb][u] = (qrow < a.m && col < a.ldq)
-                            ? *reinterpret_cast<const f32x4 *>(a.Q + (size_t)qrow * a.ldq + col)
-                            : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-
-    // the second query block's fragments live in the accumulator file (an MFMA reads its B operand
-    // from AGPRs as well): 64 registers less on the VGPR side, where the prefetch rings are
-    if constexpr (QB == 2) {
-#pragma unroll
-        for (int u = 0; u < NU; ++u) asm volatile("" : "+a"(qf[QB - 1][u]));
-    }
-
-    f32x16 oacc[NT][QB];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[t][qb][r] = 0.f;
-    float m_run[QB], l_run[QB];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) { m_run[qb] = -INFINITY; l_run[qb] = 0.f; }
-    // keep the O accumulators AGPR-class at the tile boundaries: left alone hipcc carries them as
-    // VGPR values (the rescale multiplies them), copies all of them every tile and spills Q
-    // fragments to scratch -- whose reloads put an s_waitcnt vmcnt(0) in front of the K prefetches
-    auto pin_o = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) asm volatile("" : "+a"(oacc[tt][qb]));
-    };
-    pin_o();
-
-    // (addresses: scalar 64-bit tile base + ONE unsigned 32-bit per-lane byte offset, the saddr form)
-    // K columns past the leading dimension are clamped to the last in-row float4 (Q is zero there);
-    // V columns likewise (never stored); rows past the shard end are clamped to its last row (their
-    // scores are masked to -inf, and 0 * finite = 0 in P.V).
-    const unsigned kcol0 = (unsigned)(dk0 + 4 * hi) * 4u, kcol_last = (unsigned)(a.ldk - 4) * 4u;
-    auto kcolb = [&](int u) __attribute__((always_inline)) -> unsigned { return min(kcol0 + 32u * u, kcol_last); };
-    const unsigned vcolb = (unsigned)min(dvw0 + NT * li, a.ldv - NT) * 4u;
-
-    for (int t = 0; t < ntiles; ++t) {
-        const int base = kv_begin + t * kKvTile;
-        const int last = kv_end - 1 - base;
-        const char *kb = reinterpret_cast<const char *>(a.K + (size_t)base * a.ldk);
-        const char *vb = reinterpret_cast<const char *>(a.V + (size_t)base * a.ldv);
-        const unsigned krow = (unsigned)min(li, last) * (unsigned)a.ldk * 4u;
-
-        // ---- partial S^T over this wave's dk slice, both query blocks
-        pin_o();
-        f32x16 sx[QB];
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sx[qb][r] = 0.f;
-        f32x4 kq[PD];
-#pragma unroll
-        for (int i = 0; i < PD; ++i) kq[i] = *reinterpret_cast<const f32x4 *>(kb + (krow + kcolb(i)));
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const f32x4 kf = kq[u % PD];
-            if (u + PD < NU) kq[u % PD] = *reinterpret_cast<const f32x4 *>(kb + (krow + kcolb(u + PD)));
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (QB == 2) {
-                sx[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[0][u].x, sx[0], 0, 0, 0);
-                sx[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[1][u].x, sx[1], 0, 0, 0);
-                sx[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[0][u].y, sx[0], 0, 0, 0);
-                sx[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[1][u].y, sx[1], 0, 0, 0);
-                sx[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[0][u].z, sx[0], 0, 0, 0);
-                sx[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[1][u].z, sx[1], 0, 0, 0);
-                sx[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[0][u].w, sx[0], 0, 0, 0);
-                sx[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[1][u].w, sx[1], 0, 0, 0);
-            } else {
-                sx[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[0][u].x, sx[0], 0, 0, 0);
-                sx[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[0][u].y, sx[0], 0, 0, 0);
-                sx[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[0][u].z, sx[0], 0, 0, 0);
-                sx[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[0][u].w, sx[0], 0, 0, 0);
-            }
-        }
-
-        pin_o();
-        // first V fragments of this tile go out now, under the exchange
-        VFrag<NT> vq[PD];
-#pragma unroll
-        for (int i = 0; i < PD; ++i)
-            vq[i] = VFrag<NT>::load(reinterpret_cast<const float *>(
-                vb + ((unsigned)min(crow(i, 0) + 4 * hi, last) * (unsigned)a.ldv * 4u + vcolb)));
-
-        // ---- exchange: every wave ends up with the same full S^T (fixed summation order)
-        float *xb = smem + (t & 1) * XBUF;
-        {
-            float *mine = xb + ((wave * QB) * 64 + lane) * XLD;
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4)
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb)
-                    *reinterpret_cast<f32x4 *>(mine + qb * 64 * XLD + 4 * q4) =
-                        f32x4{sx[qb][4 * q4], sx[qb][4 * q4 + 1], sx[qb][4 * q4 + 2], sx[qb][4 * q4 + 3]};
-        }
-        __syncthreads();
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const float *theirs = xb + ((w * QB) * 64 + lane) * XLD;
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                f32x4 pp[QB];
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb) pp[qb] = *reinterpret_cast<const f32x4 *>(theirs + qb * 64 * XLD + 4 * q4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int qb = 0; qb < QB; ++qb)
-                        sx[qb][4 * q4 + e] = (w == 0) ? pp[qb][e] : sx[qb][4 * q4 + e] + pp[qb][e];
-            }
-        }
-
-        pin_o();
-        // ragged last tile: key rows past the shard end contribute exp(-inf) = 0
-        const int valid = kv_end - base;
-        if (valid < kKvTile) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (crow(r, hi) >= valid) {
-#pragma unroll
-                    for (int qb = 0; qb < QB; ++qb) sx[qb][r] = -INFINITY;
-                }
-        }
-
-        // ---- online softmax, replicated in the four waves (identical inputs, identical results)
-        auto softmax = [&](f32x16 &sv, int qb) __attribute__((always_inline)) {
-            float tmax = sv[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sv[r]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-            const float m_new = fmaxf(m_run[qb], tmax);
-            if (__any(m_new > m_run[qb])) {
-                const float alpha = fast_exp2((m_run[qb] - m_new) * c);
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) oacc[tt][qb][r] *= alpha;
-                l_run[qb] *= alpha;
-                m_run[qb] = m_new;
-            }
-            const float mc = m_run[qb] * c;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                sv[r] = fast_exp2(fmaf(sv[r], c, -mc));
-                l_run[qb] += sv[r];
-            }
-        };
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) softmax(sx[qb], qb);
-        pin_o();
-
-        // ---- O^T slice += V_tile^T . P^T   (k-step r of half-wave hi is key row crow(r, hi))
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const VFrag<NT> vf = vq[r % PD];
-            if (r + PD < 16)
-                vq[r % PD] = VFrag<NT>::load(reinterpret_cast<const float *>(
-                    vb + ((unsigned)min(crow(r + PD, 0) + 4 * hi, last) * (unsigned)a.ldv * 4u + vcolb)));
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb)
-                    oacc[tt][qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.v[tt], sx[qb][r], oacc[tt][qb], 0, 0, 0);
-        }
-        pin_o();
-    }
-
-    // ---- epilogue
-    float *out = a.contrib;
-    float *omax = a.lmax, *osum = a.lsum;
-    int ldo = a.ldo;
-    if (a.kv_splits > 1) {
-        ldo = a.ws_ld;
-        out = a.ws_contrib + (size_t)split * a.ws_rows * ldo;
-        omax = a.ws_lmax + (size_t)split * a.ws_rows;
-        osum = a.ws_lsum + (size_t)split * a.ws_rows;
-    }
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        const int qrow = qblock * ROWS + qb * 32 + li;
-        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32);
-        if (qrow < a.m) {
-            float *orow = out + (size_t)qrow * ldo + dvw0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int col0 = NT * crow(r, hi);
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt)
-                    if (dvw0 + col0 + tt < a.dv) orow[col0 + tt] = oacc[tt][qb][r];
-            }
-            if (wave == 0 && hi == 0 && chunk == 0) {
-                omax[qrow] = m_run[qb] * scale;
-                osum[qrow] = l_tot;
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
 // In-GPU split merge: the reference's shard merge (attention-mpi.c:340-362 minus
 // the final 1/gsum, which stays with the caller) applied to the kv_splits partial
 // triples of one GPU.  One thread per (row, 4 columns).
@@ -1508,9 +957,6 @@ static inline int pad_dim(int d) { return d <= 32 ? 32 : (d <= 64 ? 64 : (d <= 1
 static inline int dv_chunk(int dv) { return dv <= 32 ? 32 : (dv <= 64 ? 64 : 128); }
 static inline int dv_chunks(int dv) { return (dv + dv_chunk(dv) - 1) / dv_chunk(dv); }
 
-// 256 < dk <= 512: per-wave dv slice of the dk-split kernel (chunk = 4 slices)
-static inline int dksplit_slice(int dv) { return dv <= 128 ? 32 : (dv <= 256 ? 64 : 128); }
-static inline int dksplit_chunks(int dv) { return (dv + 4 * dksplit_slice(dv) - 1) / (4 * dksplit_slice(dv)); }
 
 // the dk-split kernel takes 256 < dk <= 512, and 128 < dk <= 256 when dv needs more than one
 // 128-column chunk of fused_partial_kernel (measured: 102 vs 86 TFLOP/s at dk = dv = 256, but
@@ -1606,58 +1052,6 @@ static hipError_t launch_fast(const PartialArgs &a, hipStream_t s) {
     return e;
 }
 
-template <int DKS, int DVS>
-static hipError_t launch_dksplit(const PartialArgs &a, hipStream_t s) {
-    const int nqb = (a.m + 63) / 64;
-    const int ntiles = (a.n_local + kKvTile - 1) / kKvTile;
-    const int tiles_per_split = (ntiles + a.kv_splits - 1) / a.kv_splits;
-    const int kv_per_split = tiles_per_split > 0 ? tiles_per_split * kKvTile : kKvTile;
-    const int chunks = dksplit_chunks(a.dv);
-    const size_t lds = (size_t)2 * 8 * 64 * 20 * sizeof(float);
-    static bool attr_done[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_dksplit_kernel<DKS, DVS>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done[dev] = true;
-    }
-    const float scale = 1.0f / sqrtf((float)a.dk);   // attention-mpi.c:208
-    hipLaunchKernelGGL((fused_dksplit_kernel<DKS, DVS>), dim3(nqb * chunks * a.kv_splits), dim3(256), lds, s,
-                       a, kv_per_split, nqb, chunks, scale);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    if (a.kv_splits > 1 && !a.defer_merge) e = launch_split_merge(a, s);
-    return e;
-}
-
-template <int DKS, int DVS, int QB>
-static hipError_t launch_dksplit_q(const PartialArgs &a, hipStream_t s) {
-    const int nqb = (a.m + 32 * QB - 1) / (32 * QB);
-    const int ntiles = (a.n_local + kKvTile - 1) / kKvTile;
-    const int tiles_per_split = (ntiles + a.kv_splits - 1) / a.kv_splits;
-    const int kv_per_split = tiles_per_split > 0 ? tiles_per_split * kKvTile : kKvTile;
-    const int chunks = dksplit_chunks(a.dv);
-    const size_t lds = (size_t)2 * 4 * QB * 64 * 20 * sizeof(float);
-    static bool attr_done[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_dksplit_q_kernel<DKS, DVS, QB>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done[dev] = true;
-    }
-    const float scale = 1.0f / sqrtf((float)a.dk);   // attention-mpi.c:208
-    hipLaunchKernelGGL((fused_dksplit_q_kernel<DKS, DVS, QB>), dim3(nqb * chunks * a.kv_splits), dim3(256), lds, s,
-                       a, kv_per_split, nqb, chunks, scale);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    if (a.kv_splits > 1 && !a.defer_merge) e = launch_split_merge(a, s);
-    return e;
-}
-
 template <int DK, int DV, int ABL = 0>
 static hipError_t launch_pipelined(const PartialArgs &a, hipStream_t s) {
     const int nqb = (a.m + kQRowsPerBlock - 1) / kQRowsPerBlock;
@@ -1719,40 +1113,8 @@ hipError_t launch_shard_partial(const PartialArgs &a_in, hipStream_t s) {
         if (kp == 256 && vp == 128) return launch_pipelined<256, 128>(a, s);
         if (kp == 128 && vp == 256) return launch_pipelined<128, 256>(a, s);
     }
-    if (uses_dksplit(a.dk, a.dv) && !(a.tune & 8)) {   // $SDPA_TUNE&8: the kernels it replaced
-        if (a.dk > 512 && a.dk <= 768) {     // 192-wide dk slices, ONE query block per workgroup
-            switch (dksplit_slice(a.dv)) {
-                case 32: return launch_dksplit_q<192, 32, 1>(a, s);
-                case 64: return launch_dksplit_q<192, 64, 1>(a, s);
-                default: return launch_dksplit_q<192, 128, 1>(a, s);
-            }
-        }
-        if (a.dk > 768) {              // 768 < dk <= 1024: 256-wide dk slices, ONE query block per workgroup
-            switch (dksplit_slice(a.dv)) {
-                case 32: return launch_dksplit_q<256, 32, 1>(a, s);
-                case 64: return launch_dksplit_q<256, 64, 1>(a, s);
-                default: return launch_dksplit_q<256, 128, 1>(a, s);
-            }
-        }
-        if (a.dk > 384) {
-            switch (dksplit_slice(a.dv)) {
-                case 32: return launch_dksplit<128, 32>(a, s);
-                case 64: return launch_dksplit<128, 64>(a, s);
-                default: return launch_dksplit<128, 128>(a, s);
-            }
-        }
-        if (a.dk > kMaxMfmaDk) {       // 256 < dk <= 384: 96-wide dk slices, no score MFMAs on padding
-            switch (dksplit_slice(a.dv)) {
-                case 32: return launch_dksplit<96, 32>(a, s);
-                case 64: return launch_dksplit<96, 64>(a, s);
-                default: return launch_dksplit<96, 128>(a, s);
-            }
-        }
-        switch (dksplit_slice(a.dv)) {
-            case 64: return launch_dksplit<64, 64>(a, s);
-            default: return launch_dksplit<64, 128>(a, s);
-        }
-    }
+    if (uses_dksplit(a.dk, a.dv) && !(a.tune & 8))     // $SDPA_TUNE&8: the kernels it replaced
+        return launch_dksplit(a, s);                    // sdpa_fwd_f32_dksplit.hip
     if (a.dk > kMaxMfmaDk) {
         const size_t lds = (size_t)4 * a.ldq * sizeof(float);
         if (lds > 64 * 1024) return hipErrorInvalidValue;          // dk <= 4096

@@ -857,6 +857,8 @@ int rank_batch(Call &c, int g, int b) {
     if (b >= 2) {
         HIP_TRY(hipStreamWaitEvent(rk.s_cp, rk.ev_q[s], 0));
         HIP_TRY(hipStreamWaitEvent(rk.s_in, rk.ev_run[s], 0));
+        // host converts: the copy itself writes the operand image qf[s], which batch b-2's kernels read
+        if (HI.cv) HIP_TRY(hipStreamWaitEvent(rk.s_cp, rk.ev_run[s], 0));
     }
     if (head_pieces) {
         for (int j = 0; j < pieces; ++j)

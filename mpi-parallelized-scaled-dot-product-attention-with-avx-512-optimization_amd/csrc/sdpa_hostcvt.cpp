@@ -1,7 +1,8 @@
-// sdpa_hostcvt.hip -- see sdpa_hostcvt.h.  Host code only (no kernel in this translation unit).
+// sdpa_hostcvt.cpp -- see sdpa_hostcvt.h.  Host code only: compiled by g++ (x86-64), no device pass.
 #include "sdpa_hostcvt.h"
 
-#include <hip/hip_runtime.h>
+#include <hip/hip_runtime_api.h>
+#include <immintrin.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -24,7 +25,7 @@ inline void relax() {
 
 // (float)double under the default rounding mode is round-to-nearest-even: what __double2float_rn and
 // _mm512_cvtpd_ps (attention-mpi.c:31-64) do.
-inline void rows_to_f32(const double *src, float *dst, long rows, int cols, int ld) {
+void rows_to_f32_scalar(const double *src, float *dst, long rows, int cols, int ld) {
     for (long r = 0; r < rows; ++r) {
         const double *s = src + r * cols;
         float *d = dst + r * ld;
@@ -42,16 +43,67 @@ inline unsigned short to_bf16(double x) {
     return (unsigned short)(u >> 16);
 }
 
-inline void rows_to_bf16(const double *src, unsigned short *dst, long rows, int cols, int ld, double mult) {
+void rows_to_bf16_scalar(const double *src, unsigned short *dst, long rows, int cols, int ld, double mult) {
     for (long r = 0; r < rows; ++r) {
         const double *s = src + r * cols;
         unsigned short *d = dst + r * ld;
-        if (mult == 1.0)
-            for (int c = 0; c < cols; ++c) d[c] = to_bf16(s[c]);
-        else
-            for (int c = 0; c < cols; ++c) d[c] = to_bf16(s[c] * mult);
+        for (int c = 0; c < cols; ++c) d[c] = to_bf16(s[c] * mult);       // (x * 1.0 is x)
         for (int c = cols; c < ld; ++c) d[c] = 0;
     }
+}
+
+// AVX-512 rows: 8 doubles per vcvtpd2ps, as the reference's cvt_d2f_avx512 (attention-mpi.c:31-64); the
+// bf16 form does the device kernel's integer rounding on 8 lanes at a time.  Masked tail, no alignment
+// assumed.  Same results as the scalar rows bit for bit (tests/test_hostcvt.py).
+__attribute__((target("avx512f,avx512bw,avx512vl")))
+void rows_to_f32_avx512(const double *src, float *dst, long rows, int cols, int ld) {
+    for (long r = 0; r < rows; ++r) {
+        const double *s = src + r * cols;
+        float *d = dst + r * ld;
+        int c = 0;
+        for (; c + 8 <= cols; c += 8) _mm256_storeu_ps(d + c, _mm512_cvtpd_ps(_mm512_loadu_pd(s + c)));
+        if (c < cols) {
+            const __mmask8 k = (__mmask8)((1u << (cols - c)) - 1u);
+            _mm256_mask_storeu_ps(d + c, k, _mm512_cvtpd_ps(_mm512_maskz_loadu_pd(k, s + c)));
+        }
+        for (c = cols; c < ld; ++c) d[c] = 0.f;
+    }
+}
+
+__attribute__((target("avx512f,avx512bw,avx512vl")))
+void rows_to_bf16_avx512(const double *src, unsigned short *dst, long rows, int cols, int ld, double mult) {
+    const __m512d vm = _mm512_set1_pd(mult);
+    const __m256i one = _mm256_set1_epi32(1), bias = _mm256_set1_epi32(0x7fff);
+    for (long r = 0; r < rows; ++r) {
+        const double *s = src + r * cols;
+        unsigned short *d = dst + r * ld;
+        int c = 0;
+        for (; c < cols; c += 8) {
+            const int left = cols - c;
+            const __mmask8 k = left >= 8 ? (__mmask8)0xff : (__mmask8)((1u << left) - 1u);
+            const __m512d x = _mm512_mul_pd(_mm512_maskz_loadu_pd(k, s + c), vm);
+            __m256i u = _mm256_castps_si256(_mm512_cvtpd_ps(x));
+            u = _mm256_add_epi32(u, _mm256_add_epi32(bias, _mm256_and_si256(_mm256_srli_epi32(u, 16), one)));
+            _mm_mask_storeu_epi16(d + c, k, _mm256_cvtepi32_epi16(_mm256_srli_epi32(u, 16)));
+        }
+        for (c = cols; c < ld; ++c) d[c] = 0;
+    }
+}
+
+bool have_avx512() {
+    static const bool yes = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") &&
+                            __builtin_cpu_supports("avx512vl");
+    return yes;
+}
+
+inline void rows_to_f32(const double *src, float *dst, long rows, int cols, int ld) {
+    if (have_avx512()) rows_to_f32_avx512(src, dst, rows, cols, ld);
+    else rows_to_f32_scalar(src, dst, rows, cols, ld);
+}
+
+inline void rows_to_bf16(const double *src, unsigned short *dst, long rows, int cols, int ld, double mult) {
+    if (have_avx512()) rows_to_bf16_avx512(src, dst, rows, cols, ld, mult);
+    else rows_to_bf16_scalar(src, dst, rows, cols, ld, mult);
 }
 
 struct Task {
@@ -197,6 +249,18 @@ private:
 };
 
 }  // namespace
+
+// one thread, `rows` rows: the conversion the pool's threads run (also the C ABI's sdpa_host_cvt_rows)
+void host_convert_rows(const double *src, void *dst, long rows, int cols, int ld, CvtKind kind, double mult,
+                       bool force_scalar) {
+    if (kind == kCvtF32) {
+        if (force_scalar) rows_to_f32_scalar(src, (float *)dst, rows, cols, ld);
+        else rows_to_f32(src, (float *)dst, rows, cols, ld);
+    } else {
+        if (force_scalar) rows_to_bf16_scalar(src, (unsigned short *)dst, rows, cols, ld, mult);
+        else rows_to_bf16(src, (unsigned short *)dst, rows, cols, ld, mult);
+    }
+}
 
 HostConverter *HostConverter::create(int threads) {
     if (threads < 1) threads = 1;

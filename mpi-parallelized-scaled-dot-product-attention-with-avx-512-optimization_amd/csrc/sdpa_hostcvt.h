@@ -17,6 +17,10 @@ enum CvtKind {
     kCvtBf16 = 1,     // bf16 image, rows padded to ld, values bf16((float)(x * mult)) (cvt_d2bf_kernel)
 };
 
+// `rows` rows on the calling thread (AVX-512 where the CPU has it; force_scalar: the plain-C rows)
+void host_convert_rows(const double *src, void *dst, long rows, int cols, int ld, CvtKind kind, double mult,
+                       bool force_scalar);
+
 class HostConverter {
 public:
     static HostConverter *create(int threads);      // nullptr on failure

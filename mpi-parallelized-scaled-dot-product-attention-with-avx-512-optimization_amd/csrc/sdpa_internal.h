@@ -106,6 +106,11 @@ size_t workspace_bytes(int m, int n_local, int dk, int dv);
 // a.m rows x ws_ld floats, the two statistics arrays, the arrival words.  Needs a.m, a.kv_splits.
 void carve_workspace(PartialArgs &a, void *ws, int ws_ld);
 
+// the dk-split kernels (sdpa_fwd_f32_dksplit.hip): launcher and the grid arithmetic pick_kv_splits needs
+hipError_t launch_dksplit(const PartialArgs &a, hipStream_t s);
+int dksplit_chunks(int dv);
+int dksplit_rows(int dk);
+
 // Enqueue the fused kernel (+ the split merge when kv_splits > 1).
 hipError_t launch_shard_partial(const PartialArgs &a, hipStream_t s);
 

@@ -1,0 +1,73 @@
+"""CPU: the host-side converter of $SDPA_HOST_CVT=1 (csrc/sdpa_hostcvt.cpp, C ABI sdpa_host_cvt_rows) --
+the reference's own placement of the fp64 -> fp32 converts (cvt_d2f_avx512, attention-mpi.c:31-64,
+called at :224-225 and :303), here writing the operand images the GPU kernels read.  Its rows must be
+the device converters' rows bit for bit: fp32 = round-to-nearest-even of the double (numpy's astype),
+bf16 = that float rounded to nearest even on its bit pattern; AVX-512 rows == plain-C rows."""
+import ctypes
+
+import numpy as np
+import pytest
+
+
+def cvt(pkg, src, ld, kind, mult=1.0, scalar=False):
+    rows, cols = src.shape
+    dst = np.full((rows, ld), 0x7f, dtype=np.float32 if kind == 0 else np.uint16)
+    src = np.ascontiguousarray(src, dtype=np.float64)
+    rc = pkg.load().sdpa_host_cvt_rows(src.ctypes.data, dst.ctypes.data, rows, cols, ld, kind, mult, 1 if scalar else 0)
+    assert rc == 0
+    return dst
+
+
+def bf16_bits(x64, mult):
+    with np.errstate(over="ignore"):
+        f = (x64 * mult).astype(np.float32)
+    u = f.view(np.uint32).astype(np.uint64)
+    u = (u + 0x7fff + ((u >> 16) & 1)) & 0xffffffff
+    return (u >> 16).astype(np.uint16)
+
+
+def samples(rows, cols, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((rows, cols)) * np.exp(rng.uniform(-30, 30, (rows, cols)))
+    flat = x.reshape(-1)
+    # exact ties of the fp64 -> fp32 rounding (23-bit mantissa + half an ulp), both parities
+    base = np.float32(1.0) + np.arange(8, dtype=np.float32) * np.float32(2.0 ** -23)
+    ties = base.astype(np.float64) + 2.0 ** -24
+    # ties of the fp32 -> bf16 rounding: 1 + (2k+1) * 2^-8
+    ties16 = 1.0 + (2 * np.arange(8) + 1) * 2.0 ** -8
+    special = np.concatenate([ties, -ties, ties16, -ties16, [0.0, -0.0, 1e-320, -1e-45, 3.4028235677973366e38, 1e39, -1e39,
+                                                              65504.0, 2.0 ** -126, 2.0 ** -149, 1.0 + 2.0 ** -52]])
+    flat[:min(len(special), flat.size)] = special[:flat.size]
+    return x
+
+
+@pytest.mark.parametrize("cols,ld", [(1, 4), (7, 8), (8, 8), (9, 12), (64, 64), (72, 128), (100, 128), (128, 128), (300, 300), (513, 516)])
+def test_fp32_rows_are_numpy_astype_rows(cols, ld, pkg):
+    x = samples(37, cols, cols)
+    with np.errstate(over="ignore"):
+        want = x.astype(np.float32)
+    for scalar in (False, True):
+        got = cvt(pkg, x, ld, 0, scalar=scalar)
+        assert np.array_equal(got[:, :cols].view(np.uint32), want.view(np.uint32)), "scalar=%s" % scalar
+        assert not got[:, cols:].any(), "pad columns must be zero"
+
+
+@pytest.mark.parametrize("cols,ld", [(1, 64), (7, 64), (8, 8), (64, 64), (100, 128), (250, 256), (512, 512), (13, 13)])
+@pytest.mark.parametrize("mult", [1.0, float(np.float32(1.44269504088896340736) * (np.float32(1.0) / np.sqrt(np.float32(128.0))))])
+def test_bf16_rows_are_the_device_converters_two_roundings(cols, ld, mult, pkg):
+    x = samples(29, cols, 1000 + cols)
+    want = bf16_bits(x, mult)
+    for scalar in (False, True):
+        got = cvt(pkg, x, ld, 1, mult, scalar=scalar)
+        assert np.array_equal(got[:, :cols], want), "scalar=%s" % scalar
+        assert not got[:, cols:].any()
+
+
+def test_argument_checks(pkg):
+    lib = pkg.load()
+    buf = (ctypes.c_double * 16)()
+    p = ctypes.addressof(buf)
+    assert lib.sdpa_host_cvt_rows(p, p, 1, 8, 4, 0, 1.0, 0) == pkg._lib.SDPA_EINVAL      # ld < cols
+    assert lib.sdpa_host_cvt_rows(p, p, 1, 4, 4, 2, 1.0, 0) == pkg._lib.SDPA_EINVAL      # unknown kind
+    assert lib.sdpa_host_cvt_rows(None, p, 1, 4, 4, 0, 1.0, 0) == pkg._lib.SDPA_EINVAL
+    assert lib.sdpa_host_cvt_rows(None, None, 0, 4, 4, 0, 1.0, 0) == 0

@@ -123,3 +123,30 @@ def test_f32_pipelined_kernel_one_wave_per_simd_keeps_o_in_the_accumulator_file(
     assert c["v_accvgpr_read_b32"] == dv and c["v_accvgpr_write_b32"] == dv, c  # 2 steps x (dv/32 tiles x 16) / ... cold branch only
     assert c["v_exp_f32"] <= 34 and c["global_load_lds_dwordx4"] == 2 * (dk // 16 + dv // 16), c
 
+
+
+@pytest.fixture(scope="module")
+def dksplit_asm(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc here")
+    return device_asm(tmp_path_factory, "sdpa_fwd_f32_dksplit.hip")
+
+
+@pytest.mark.parametrize("dks,dvs,qb", [(128, 128, 2), (96, 128, 2), (64, 64, 2), (256, 128, 1), (192, 64, 1)])
+def test_f32_dksplit_kernel_is_one_template_with_both_block_counts(dks, dvs, qb, dksplit_asm):
+    """round 3: fused_dksplit_kernel<DKS,DVS,QB> replaces the two copies (two query blocks per workgroup for
+    dk <= 512, one beyond).  Per 32-key tile and wave: DKS/2 x QB score MFMAs + 16 x DVS/32 x QB P.V MFMAs,
+    K and V fragments straight from global memory (no LDS tile), the exchange of the partial score tiles
+    as b128 LDS accesses, and no scratch traffic beyond the one reload the two-block 128/128 form always had."""
+    c = main_loop_mix(kernel_lines(dksplit_asm, "fused_dksplit_kernelILi%dELi%dELi%dE" % (dks, dvs, qb)))
+    assert c["v_mfma_f32_32x32x2_f32"] == qb * (dks // 2 + 16 * dvs // 32), c
+    assert sum(v for k, v in c.items() if k.startswith("scratch_")) <= 1, c
+    assert c["ds_write_b128"] == 4 * qb and c["ds_read_b128"] == 16 * qb, c
+    assert c["global_load_lds_dwordx4"] == 0, c
+
+
+@pytest.mark.parametrize("dk,dv", [(64, 64), (128, 64), (64, 128)])
+def test_f32_pipelined_kernel_small_dims_first_pass_is_spill_free(dk, dv, f32_asm):
+    c = main_loop_mix(kernel_lines(f32_asm, "fused_pipelined_kernelILi%dELi%dELi0E" % (dk, dv)))
+    assert c["v_mfma_f32_32x32x2_f32"] == 2 * (dk // 2 + 16 * dv // 32), c
+    assert sum(v for k, v in c.items() if k.startswith("scratch_")) == 0, c
