@@ -441,18 +441,22 @@ __global__ __launch_bounds__(256, (DK + DV > 256) ? 1 : 2) void fused_pipelined_
     // s_waitcnt vmcnt(0) in front of the end-of-step barrier (stage_fence).
     const unsigned lds_base = __builtin_amdgcn_readfirstlane(
         (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)smem);
+#ifdef SDPA_DMA_ASSERT
+    int audit_bad = 0;
+#endif
     auto dma_piece = [&](const char *gbase, unsigned lane_off, unsigned lds_byte) __attribute__((always_inline)) {
         if constexpr (ABL & 1) return;
 #ifdef SDPA_DMA_ASSERT
         // audit build (tools/build_variant.sh ... -DSDPA_DMA_ASSERT, never shipped): every 16-byte DMA source must lie
-        // inside the K or the V image of this launch, every 1-KiB destination inside the workgroup's LDS tiles
+        // inside the K or the V image of this launch, every 1-KiB destination inside the workgroup's LDS tiles.
+        // A violation poisons the row sum (NaN), which every parity test sees -- no branch near the asm.
         {
             const char *src = gbase + lane_off;
             const char *k0 = reinterpret_cast<const char *>(a.K), *k1 = k0 + (size_t)a.n_local * DK * 4;
             const char *v0 = reinterpret_cast<const char *>(a.V), *v1 = v0 + (size_t)a.n_local * DV * 4;
             const bool in_k = src >= k0 && src + 16 <= k1, in_v = src >= v0 && src + 16 <= v1;
             const bool lds_ok = lds_byte >= lds_base && lds_byte + 1024u <= lds_base + (unsigned)(2 * (KTILE + VTILE)) * 4u;
-            if (!(in_k || in_v) || !lds_ok || (lane_off & 15u) != 0) __builtin_trap();
+            audit_bad |= (!(in_k || in_v) || !lds_ok || (lane_off & 15u) != 0) ? 1 : 0;
         }
 #endif
         // M0 is written without save/restore: hipcc treats it as reserved and re-initialises it next
@@ -717,6 +721,9 @@ __global__ __launch_bounds__(256, (DK + DV > 256) ? 1 : 2) void fused_pipelined_
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[tt][r] *= fold;
     l_tot = (l_run + __shfl_xor(l_run, 32)) * fold;
+#ifdef SDPA_DMA_ASSERT
+    if (__any(audit_bad)) l_tot = __builtin_nanf("");
+#endif
     };  // run_pass
 
     auto store_rows = [&](float *out, int ldo, float *omax, float *osum, const f32x16 (&o)[NT], float vmax,

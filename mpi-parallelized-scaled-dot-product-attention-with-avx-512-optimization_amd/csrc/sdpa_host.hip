@@ -1070,6 +1070,40 @@ int rank_thread(void *arg, int g) {
     return SDPA_OK;
 }
 
+// ---- where the fp64 -> operand converts run ($SDPA_HOST_CVT) ----------------------------------------
+// 0 = always on the device; 1 = always on host threads; unset / "auto" = per problem: on the host when the
+// call would otherwise wait for PCIe -- the fp64 inputs take clearly longer over the link than the
+// kernels take (BASELINE config 5 in bf16: 671 MB in for 3.6 ms of kernel, boundary 15.2 -> 9.1 ms;
+// config 2: 1.15 -> 0.92 ms) -- and on the device when the kernels cover the transfer anyway (the
+// metric shape: 9.6 vs 10.0-10.9 ms) or several ranks share the host's convert threads
+// (profiles/r03/host_convert_ab.log).
+int host_cvt_mode() {
+    const char *v = getenv("SDPA_HOST_CVT");
+    if (!v || !*v || strcmp(v, "auto") == 0) return 2;
+    return atoi(v) > 0 ? 1 : 0;
+}
+
+bool want_host_cvt(const Plan &pl) {
+    const int mode = host_cvt_mode();
+    if (mode != 2) return mode == 1;
+    if (pl.P != 1) return false;
+    const double elems = (double)pl.m * pl.dk + (double)pl.n * pl.dk + (double)pl.n * pl.dv;
+    if (elems < 1e6) return false;                                   // latency bound either way
+    const double t_link = elems * 8.0 / 55e9;                        // fp64 over PCIe Gen5 x16, as measured
+    const double rate = pl.bf16 ? 1.0e15 : (pl.dk <= 256 ? 1.3e14 : 1.0e14);
+    const double t_kernel = 2.0 * pl.m * (double)pl.n * (pl.dk + pl.dv) / rate;
+    return t_link > 1.4 * t_kernel;
+}
+
+// the converter pool is created on first use (32 threads, $SDPA_HOST_CVT_THREADS)
+int ensure_host_converter() {
+    if (E.hc) return SDPA_OK;
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int dflt = std::max(1, std::min(32, hw > 4 ? hw - 2 : 1));
+    E.hc = sdpa::HostConverter::create(env_int("SDPA_HOST_CVT_THREADS", dflt));
+    return E.hc ? SDPA_OK : SDPA_ENOMEM;
+}
+
 int lazy_init() {
     if (E.up) return SDPA_OK;
     int want = 1;                       // several GPUs from one process is opt-in
@@ -1184,8 +1218,7 @@ int init_impl(int n_gpus) {
         return SDPA_ENODEV;
     }
     if (want > sdpa::kMaxRanks) return SDPA_EINVAL;
-    if (E.up && E.n == want && E.virtual_ranks == (virt > 0) && (E.hc != nullptr) == (env_int("SDPA_HOST_CVT", 0) > 0))
-        return SDPA_OK;
+    if (E.up && E.n == want && E.virtual_ranks == (virt > 0)) return SDPA_OK;
     if (E.up) sdpa_shutdown();
 
     E.r.assign(want, Rank());
@@ -1212,12 +1245,6 @@ int init_impl(int n_gpus) {
             E.coll = sdpa::make_rccl_collectives(want, devs.data());
         }
         if (!E.coll) return SDPA_ERCCL;
-    }
-    if (env_int("SDPA_HOST_CVT", 0) > 0) {
-        const int hw = (int)std::thread::hardware_concurrency();
-        const int dflt = std::max(1, std::min(32, hw > 4 ? hw - 2 : 1));
-        E.hc = sdpa::HostConverter::create(env_int("SDPA_HOST_CVT_THREADS", dflt));
-        if (!E.hc) return SDPA_ENOMEM;
     }
     if (want > 1 && !(getenv("SDPA_ENQUEUE_THREADS") && atoi(getenv("SDPA_ENQUEUE_THREADS")) == 0)) {
         std::vector<int> devs(want);
@@ -1335,7 +1362,7 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
         }
     } end_hostcvt;
     HI = HostImages();
-    if (E.hc && !PF.active) {
+    if (!PF.active && want_host_cvt(pl) && ensure_host_converter() == SDPA_OK) {
         const size_t kel = pl.kv_elem, qel = pl.q_elem;
         const int ldv_h = pl.bf16 ? dv : pl.ldv;
         const size_t vel = pl.bf16 ? sizeof(unsigned short) : sizeof(float);
@@ -1491,10 +1518,11 @@ int sdpa_kv_prefetch(const double *K, const double *V, int m, int n, int dk, int
     if (k_rows_final < 0 || v_rows_final < 0 || k_rows_final > n || v_rows_final > n) return SDPA_EINVAL;
     DeviceRestore restore;
     SDPA_TRY(lazy_init());
-    if (E.hc) return SDPA_OK;           // host converts read the caller's arrays inside the compute call: nothing to stage ahead
     Plan pl;
     make_plan(pl, m, n, dk, dv, flags);
     SDPA_TRY(check_plan(pl));
+    if (host_cvt_mode() == 1) return SDPA_OK;   // host converts read the caller's arrays inside the compute call: nothing to stage ahead
+    // (auto mode: a prefetched problem keeps its device converts -- the compute call finds PF.active)
     // the chunk layout is a function of environment knobs as well: a prefetch planned differently
     // from this call (other SDPA_KV_CHUNK_*, SDPA_QBATCH, rank count) starts over instead of
     // indexing its per-chunk state with the new plan's chunk numbers
@@ -1592,7 +1620,8 @@ int sdpa_prepare(int m, int n, int dk, int dv, int flags) {
     make_plan(pl, m, n, dk, dv, flags);
     SDPA_TRY(check_plan(pl));
     SDPA_TRY(ensure_buffers(pl));
-    if (E.hc) {      // and the page-locked staging of the host converts (hundreds of MB: not inside a timed call)
+    if (want_host_cvt(pl)) {      // and the page-locked staging of the host converts (hundreds of MB: not inside a timed call)
+        SDPA_TRY(ensure_host_converter());
         const size_t vrow = pl.bf16 ? (size_t)dv * sizeof(unsigned short) : (size_t)pl.ldv * sizeof(float);
         if (!E.hc->staging(0, (size_t)n * pl.ldk * pl.kv_elem) || !E.hc->staging(1, (size_t)n * vrow) ||
             !E.hc->staging(2, (size_t)m * pl.ldq * pl.q_elem))

@@ -339,7 +339,7 @@ def test_host_side_convert_gives_the_device_converts_result_bit_for_bit(m, n, dk
     result bit for bit; checked against the fp64 oracle as well."""
     Q, K, V = O.make_inputs(m, n, dk, dv, "D2", seed=m + dk)
     common = dict(SDPA_KV_CHUNK_MIN=1024, SDPA_KV_CHUNK_MAX=2048, SDPA_PIECE_MIN_ROWS=128, **env)
-    pkg = engine(**common)
+    pkg = engine(SDPA_HOST_CVT=0, **common)
     want = pkg.attention(Q, K, V, precision=prec)
     assert pkg.last_timing()["host_convert_threads"] == 0
     tol = 1e-2 * max(1.0, float(np.abs(V).max())) if prec == "bf16" else None
@@ -351,3 +351,24 @@ def test_host_side_convert_gives_the_device_converts_result_bit_for_bit(m, n, dk
             assert np.array_equal(got, want), "host converts (%d threads, call %d) differ from the device converts" % (threads, rep)
         t = pkg.last_timing()
         assert t["host_convert_threads"] == threads and t["register_us"] >= 0, t
+
+
+def test_convert_placement_is_chosen_per_problem(engine, orc, O):
+    """$SDPA_HOST_CVT unset: per problem.  Host threads convert when the fp64 inputs would take clearly
+    longer over PCIe than the kernels take (one rank only); the device converts when the kernels cover
+    the transfer anyway, and always with several ranks (they would share the host's convert threads)."""
+    pkg = engine()
+    Q, K, V = O.make_inputs(260, 5000, 512, 512, "D1", seed=3)            # config 5's dims: copy bound
+    got = pkg.attention(Q, K, V, precision="bf16")
+    assert pkg.last_timing()["host_convert_threads"] > 0
+    check(got, orc.attention_f64(Q, K, V), V, "auto -> host converts", 1e-2 * max(1.0, float(np.abs(V).max())))
+    rng = np.random.default_rng(1)
+    Q, K, V = (rng.uniform(-1, 1, s) for s in ((16384, 128), (16384, 128), (16384, 128)))   # kernel bound
+    pkg.attention(Q, K, V)
+    assert pkg.last_timing()["host_convert_threads"] == 0
+    assert pkg.attention(Q[:64], K[:512], V[:512]).shape == (64, 128)     # tiny: latency bound either way
+    assert pkg.last_timing()["host_convert_threads"] == 0
+    pkg = engine(SDPA_VIRTUAL_GPUS=2)
+    Q, K, V = O.make_inputs(260, 5000, 512, 512, "D1", seed=3)
+    pkg.attention(Q, K, V, precision="bf16")
+    assert pkg.last_timing()["host_convert_threads"] == 0 and pkg.last_timing()["n_gpus"] == 2

@@ -14,8 +14,9 @@ sweep = "--sweep" in sys.argv
 pinned = "--pinned" in sys.argv
 lib = pkg.load()
 pkg.init(1)
-# --hostcvt: A/B of the convert placement -- each shape first with the device converts, then with
-# $SDPA_HOST_CVT=1 at several thread counts (the engine is re-created for each)
+# --hostcvt: A/B of the convert placement -- each shape first with the device converts ($SDPA_HOST_CVT=0),
+# then with host converts (=1) at several thread counts, then the default (auto: chosen per problem); the
+# engine is re-created for each
 hostcvt = "--hostcvt" in sys.argv
 KNOBS = ("SDPA_QBATCH", "SDPA_KV_CHUNK_MIN", "SDPA_KV_CHUNK_MAX", "SDPA_ROW_PIECES", "SDPA_PIECE_MIN_ROWS", "SDPA_HOST_REGISTER",
          "SDPA_PROGRESSIVE_PIN")
@@ -53,7 +54,7 @@ for name in args or ["headline", "config2", "config1"]:
     (Q, pq), (K, pk), (V, pv) = hostbuf(Q), hostbuf(K), hostbuf(V)
     R, pr = hostbuf(np.zeros((m, d)))
     flags = 2 if prec else 0
-    CVT = [{}] + ([{"SDPA_HOST_CVT": 1, "SDPA_HOST_CVT_THREADS": t} for t in (8, 16, 32, 64)] if hostcvt else [])
+    CVT = ([{"SDPA_HOST_CVT": 0}] + [{"SDPA_HOST_CVT": 1, "SDPA_HOST_CVT_THREADS": t} for t in (8, 16, 32, 64)] + [{}]) if hostcvt else [{}]
     for knobs in (SWEEP if sweep else CVT):
         for k in KNOBS + ("SDPA_HOST_CVT", "SDPA_HOST_CVT_THREADS"):
             os.environ.pop(k, None)
