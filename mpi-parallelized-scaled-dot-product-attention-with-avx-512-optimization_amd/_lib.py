@@ -110,6 +110,8 @@ def load():
         pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in _PROTOS.items():
+        if os.environ.get("SDPA_HIP_LIB") and not hasattr(lib, name):
+            continue          # an older build loaded for an A/B (tools/): it simply lacks the newer entry points
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args

@@ -44,6 +44,16 @@ def run(src, dst_ptr, kind, threads, cpus):
     return rows * cols * 8 / best / 1e9
 
 
+libc = ctypes.CDLL(None, use_errno=True)
+
+
+def page_node(addr):
+    """NUMA node of the page at addr: get_mempolicy(MPOL_F_NODE | MPOL_F_ADDR); None when the call is not allowed"""
+    node = ctypes.c_int(-1)
+    rc = libc.syscall(239, ctypes.byref(node), None, 0, ctypes.c_void_p(addr), 1 | 2)
+    return node.value if rc == 0 else None
+
+
 for src_node in nodes[:2]:
     os.sched_setaffinity(0, node_cpus(src_node))           # first touch on this node
     src = np.random.default_rng(0).uniform(-1, 1, (rows, cols))
@@ -51,6 +61,8 @@ for src_node in nodes[:2]:
     pin = lib.sdpa_host_alloc(rows * cols * 4)
     ctypes.memset(pin, 0, rows * cols * 4)
     os.sched_setaffinity(0, allcpus)
+    print(json.dumps({"first_touch_node": src_node, "get_mempolicy_says": {"src": page_node(src.ctypes.data), "numpy_dst": page_node(dst_np.ctypes.data),
+                      "pinned_dst": page_node(pin)}}))
     other = [n for n in nodes if n != src_node][:1]
     for kind in (0, 1):
         for threads in (8, 32, 64):

@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 3, call g: same-box A/B of the shipped library against the ROUND-2 library (commit 10ba295, built into
-# lib/variants/libsdpa_hip_r02.so): did the round's kernel changes move the headline kernel, or is it the box?
+# round 3, call h: (1) same-box A/B of the shipped library against the ROUND-2 library (commit 10ba295 built into
+# lib/variants/libsdpa_hip_r02.so); (2) where the host converts' ~100 GB/s come from (NUMA probe, no GPU work).
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r03g
+O=$R/gpurun_out/r03h
 PKG=mpi-parallelized-scaled-dot-product-attention-with-avx-512-optimization_amd
 mkdir -p $O
 cd $R
@@ -16,5 +16,5 @@ for it in 1 2 3; do
   done
 done
 unset SDPA_HIP_LIB
-timeout 900 python -m pytest tests/test_gpu_host_pipeline.py -m gpu -x -q -k "convert" 2>&1 | tail -4 > $O/pytest_convert.log
-cat $O/shipped_vs_round2_library_ab.log; cat $O/pytest_convert.log; tail -3 $O/bench.err
+timeout 600 python tools/gpu_hostcvt_probe.py > $O/hostcvt_numa_probe.log 2>$O/probe.err
+cat $O/shipped_vs_round2_library_ab.log; cut -c1-420 $O/hostcvt_numa_probe.log; tail -3 $O/probe.err $O/bench.err
