@@ -331,7 +331,9 @@ __global__ __launch_bounds__(256, (DKP > 128) ? 1 : 2) void fused_partial_kernel
 // ---------------------------------------------------------------------------
 // ABL: timing-only ablation switches (results are wrong when non-zero; $SDPA_TUNE selects them):
 //   1 = no DMA / no barrier in the steady state, 2 = no LDS fragment reads, 4 = no softmax VALU
-template <int DK, int DV, int ABL = 0>
+// MERGE: 1 = the launch merges its K/V splits itself (arrival words, $SDPA_SPLIT_MERGE=kernel); the shipped
+// default instantiation carries none of that code
+template <int DK, int DV, int ABL = 0, int MERGE = 0>
 __global__ __launch_bounds__(256, (DK + DV > 256) ? 1 : 2) void fused_pipelined_kernel(PartialArgs a, int kv_per_split,
                                                                                        int n_qblocks, float scale) {
     constexpr int NU = DK / 8;                // 16-byte K reads per tile per lane
@@ -784,7 +786,9 @@ __global__ __launch_bounds__(256, (DK + DV > 256) ? 1 : 2) void fused_pipelined_
 #endif
     store_mine();
     if (a.kv_splits <= 1) return;
-    if (a.tickets == nullptr) return;         // the slots are merged by a later pass (split_merge_kernel)
+    if constexpr (!MERGE) {
+        return;                               // the slots are merged by a later pass (split_merge_kernel)
+    } else {
 
     // ---- in-kernel split merge: the LAST workgroup of this query block to arrive merges the block's
     // kv_splits partial triples (attention-mpi.c:340-351 applied inside one GPU).  Placement-independent
@@ -849,6 +853,7 @@ __global__ __launch_bounds__(256, (DK + DV > 256) ? 1 : 2) void fused_pipelined_
         }
     }
     store_rows(a.contrib, a.ldo, a.lmax, a.lsum, macc, gm, tot);
+    }   // MERGE
 }
 
 // ---------------------------------------------------------------------------
@@ -1087,9 +1092,21 @@ static hipError_t launch_pipelined(const PartialArgs &a, hipStream_t s) {
     if (k.kv_splits <= 1 || k.defer_merge || (reinterpret_cast<uintptr_t>(k.tickets) & 7) != 0 ||
         !(form && strcmp(form, "kernel") == 0))
         k.tickets = nullptr;
-    if (k.tickets) k.ticket_tag = next_ticket_tag();
-    hipLaunchKernelGGL((fused_pipelined_kernel<DK, DV, ABL>), dim3(nqb * k.kv_splits), dim3(256), lds, s,
-                       k, kv_per_split, nqb, scale);
+    if (k.tickets) {
+        k.ticket_tag = next_ticket_tag();
+        static bool attr_merge[64] = {};
+        if (!attr_merge[dev]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_pipelined_kernel<DK, DV, ABL, 1>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr_merge[dev] = true;
+        }
+        hipLaunchKernelGGL((fused_pipelined_kernel<DK, DV, ABL, 1>), dim3(nqb * k.kv_splits), dim3(256), lds, s,
+                           k, kv_per_split, nqb, scale);
+    } else {
+        hipLaunchKernelGGL((fused_pipelined_kernel<DK, DV, ABL, 0>), dim3(nqb * k.kv_splits), dim3(256), lds, s,
+                           k, kv_per_split, nqb, scale);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (k.kv_splits > 1 && !k.defer_merge && !k.tickets) e = launch_split_merge(k, s);
