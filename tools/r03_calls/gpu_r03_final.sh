@@ -1,0 +1,30 @@
+#!/bin/bash
+# round 3, final evidence on one box: full -m gpu suite + smoke(), rocprofv3 profiles of the fp32 workloads
+# (headline, d = 256, config 2; the bf16 config-5 profile of call f still carries the current source stamp),
+# bench lines, boundary timings.  Outputs land in gpurun_out/r03final/ and are copied to profiles/r03/.
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r03final
+mkdir -p $O
+cd $R
+export TMPDIR=/tmp
+timeout 2400 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|FAILED|^E " | cut -c1-200 > $O/pytest_gpu_final.log
+python -c "import __graft_entry__ as g; g.smoke()" >> $O/pytest_gpu_final.log 2>&1
+timeout 900 bash tools/gpu_profile.sh r03 > $O/profile_headline.log 2>&1
+BENCH_ARGS="--workload d256" timeout 900 bash tools/gpu_profile.sh r03_f32_d256 > $O/profile_f32_d256.log 2>&1
+BENCH_ARGS="--workload config2" PROF_STEPS=40 timeout 900 bash tools/gpu_profile.sh r03_config2 > $O/profile_config2.log 2>&1
+python tools/merge_traffic.py gpurun_out/prof_r03/traffic.json gpurun_out/prof_r03_f32_d256/traffic.json gpurun_out/prof_r03_config2/traffic.json > $O/merge_traffic.log 2>&1
+cp profiles/traffic_latest.json $O/traffic_latest.json
+for t in r03 r03_f32_d256 r03_config2; do
+  mkdir -p $O/prof/$t
+  cp $R/gpurun_out/prof_$t/summary.txt $R/gpurun_out/prof_$t/traffic.json $O/prof/$t/ 2>/dev/null
+  find $R/gpurun_out/prof_$t/trace -name "*kernel_stats.csv" -exec cp {} $O/prof/$t/kernel_stats.csv \; 2>/dev/null
+  rm -rf $R/gpurun_out/prof_$t
+done
+timeout 600 python bench.py > $O/bench_n1.json 2> $O/bench.err
+timeout 300 python bench.py --workload config2 --no-cpu-baseline > $O/bench_config2.json 2>> $O/bench.err
+timeout 300 python bench.py --workload d256 --no-cpu-baseline > $O/bench_d256_f32.json 2>> $O/bench.err
+timeout 300 python bench.py --workload config5 --precision bf16 --no-cpu-baseline > $O/bench_config5_bf16.json 2>> $O/bench.err
+timeout 300 python bench.py --workload config3 --no-cpu-baseline --no-boundary --steps 5 > $O/bench_config3_one_gpu.json 2>> $O/bench.err
+timeout 300 python bench.py --emulate-ranks 8 --no-cpu-baseline > $O/bench_one_rank_share_of_8.json 2>> $O/bench.err
+timeout 600 python tools/gpu_hostlevel.py headline config2 config1 config4 config3 config5:bf16 > $O/hostlevel_all_configs.log 2>> $O/bench.err
+cat $O/pytest_gpu_final.log; for t in r03 r03_f32_d256 r03_config2; do grep -A4 "== dominant kernel" $O/prof/$t/summary.txt | cut -c1-200; done; cat $O/merge_traffic.log; for f in n1 config2 d256_f32 config5_bf16 config3_one_gpu one_rank_share_of_8; do python -c "import json,sys; j=json.load(open('$O/bench_$f.json')); r=j['roofline']; print('$f', round(j['ms_per_step'],4), round(r['kernel_ms_avg'],4), round(r['frac'],4), r['traffic'], r['hbm_gbps'], r['mfma_util'], j.get('parity_max_err'))" 2>&1 | cut -c1-300; done; cut -c1-260 $O/hostlevel_all_configs.log; tail -3 $O/bench.err
