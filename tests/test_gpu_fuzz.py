@@ -93,7 +93,10 @@ def test_fuzz_host_boundary(prec, pkg, orc, O, monkeypatch):
                  "SDPA_QBATCH": int(rng.choice([64, 256, 32768])),
                  "SDPA_ROW_PIECES": int(rng.choice([1, 2, 4])),
                  "SDPA_PIECE_MIN_ROWS": int(rng.choice([128, 4096])),
-                 "SDPA_PROGRESSIVE_PIN": int(rng.integers(0, 2))}
+                 "SDPA_PROGRESSIVE_PIN": int(rng.integers(0, 2)),
+                 # convert placement (round 3): device, host threads, or chosen per problem
+                 "SDPA_HOST_CVT": str(rng.choice(["0", "1", "auto"])),
+                 "SDPA_HOST_CVT_THREADS": int(rng.choice([1, 5, 32]))}
         for k, v in knobs.items():
             monkeypatch.setenv(k, str(v))
         Q, K, V = O.make_inputs(m, n, dk, dv, dist, seed=9000 + it)
@@ -111,7 +114,7 @@ def test_fuzz_loopback_ranks(pkg, orc, O, monkeypatch):
     assert torch.cuda.is_available()
     rng = np.random.default_rng(31337)
     knob_names = ("SDPA_VIRTUAL_GPUS", "SDPA_QBATCH", "SDPA_KV_CHUNK_MIN", "SDPA_KV_CHUNK_MAX", "SDPA_ROW_PIECES",
-                  "SDPA_PIECE_MIN_ROWS")
+                  "SDPA_PIECE_MIN_ROWS", "SDPA_EGRESS", "SDPA_ENQUEUE_THREADS", "SDPA_HOST_CVT", "SDPA_PROGRESSIVE_PIN")
     try:
         for it in range(max(8, CASES // 4)):
             P = int(rng.choice([2, 3, 4, 5, 8, 16]))
@@ -124,7 +127,10 @@ def test_fuzz_loopback_ranks(pkg, orc, O, monkeypatch):
             merge = "allreduce" if it % 2 else None
             knobs = {"SDPA_VIRTUAL_GPUS": P, "SDPA_QBATCH": int(rng.choice([64, 192, 32768])),
                      "SDPA_KV_CHUNK_MIN": 1024, "SDPA_KV_CHUNK_MAX": int(rng.choice([1024, 4096])),
-                     "SDPA_ROW_PIECES": int(rng.choice([1, 4])), "SDPA_PIECE_MIN_ROWS": 128}
+                     "SDPA_ROW_PIECES": int(rng.choice([1, 4])), "SDPA_PIECE_MIN_ROWS": 128,
+                     # the round-3 schedule switches: every combination is an exact schedule
+                     "SDPA_EGRESS": str(rng.choice(["root", "scatter"])), "SDPA_ENQUEUE_THREADS": int(rng.integers(0, 2)),
+                     "SDPA_HOST_CVT": str(rng.choice(["0", "1"])), "SDPA_PROGRESSIVE_PIN": int(rng.integers(0, 2))}
             pkg.shutdown()
             for k, v in knobs.items():
                 monkeypatch.setenv(k, str(v))
