@@ -1330,9 +1330,16 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
     }
     struct ClearPrefetch { ~ClearPrefetch() { PF.reset(); } } clear_prefetch;   // one-shot, also on errors
 
-    // Destruction order on every exit: first the ranks' enqueue threads are waited for (they use `c`),
-    // then every device is drained (no queued copy may still reference the caller's arrays), then
-    // c.pins unregisters them.
+    // Destruction order on every exit: first the ranks' enqueue threads are waited for (they use `c` and
+    // the host images), then every device is drained (no queued copy may still reference the caller's
+    // arrays or the converters' staging), then the host converters are waited for and forgotten, then
+    // c.pins unregisters the caller's arrays.
+    struct EndHostCvt {
+        ~EndHostCvt() {
+            if (HI.cv) HI.cv->finish();          // no thread reads the caller's arrays once we return
+            HI = HostImages();
+        }
+    } end_hostcvt;
     DrainOnExit drain;
     struct JoinThreads {
         Call &c;
@@ -1355,12 +1362,6 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
     // $SDPA_HOST_CVT=1: host threads write the operand images; submit every conversion now, in the order
     // the copies will ask for them (every rank's chunk 0, the first Q batch, the other chunks, the other
     // batches), and let the enqueue code wait for each piece right before it copies it
-    struct EndHostCvt {
-        ~EndHostCvt() {
-            if (HI.cv) HI.cv->finish();          // no thread reads the caller's arrays once we return
-            HI = HostImages();
-        }
-    } end_hostcvt;
     HI = HostImages();
     if (!PF.active && want_host_cvt(pl) && ensure_host_converter() == SDPA_OK) {
         const size_t kel = pl.kv_elem, qel = pl.q_elem;
