@@ -604,7 +604,9 @@ def main():
         peak = BF16_MFMA_PEAK_TFLOPS if args.precision == "bf16" else F32_MFMA_PEAK_TFLOPS
         if args.precision == "bf16":
             pad = 512 if d > 256 else 256 if d > 128 else 128 if d > 64 else 64
-            kernel_name = ("sdpa::fused_bf16_wide_kernel<%d,0> (+ its redo pass)" % pad if d > 256
+            tandem = os.environ.get("SDPA_BF16_TANDEM", "1") != "0"
+            kernel_name = (("sdpa::fused_bf16_tandem_kernel<%d>" if tandem else "sdpa::fused_bf16_wide_kernel<%d,0>") % pad +
+                           " (+ its redo pass)" if d > 256
                            else "sdpa::fused_bf16_duo_kernel<%d,%d> (+ its redo pass)" % (pad, pad))
         elif d in (64, 128, 256):
             kernel_name = "sdpa::fused_pipelined_kernel<%d,%d,0>" % (d, d)

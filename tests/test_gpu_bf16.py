@@ -3,6 +3,8 @@
 Tolerance: max|got - fp64 oracle| <= 1e-2 * max(1, max|V|).  A tighter
 check isolates the kernel from the input rounding: against the fp64 oracle evaluated on the
 SAME bf16-rounded Q, K, V the budget is 4e-3 * max(1, max|V|) (P is rounded to bf16 once)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -312,3 +314,58 @@ def test_bf16_race_screen_repeatability(pkg, be, O):
                 first = cur
             else:
                 assert all(torch.equal(a_, b_) for a_, b_ in zip(cur, first)), "launch %d differs" % it
+
+
+# ---------------------------------------------------------------- tandem kernel (dv > 256, round 3) --------
+@pytest.mark.parametrize("m,n,dk,dv,dist", [
+    (260, 5000, 512, 512, "D2"),       # BASELINE config 5's dims: ragged rows, in-GPU splits
+    (128, 32, 512, 512, "D1"),         # one tile
+    (129, 33, 512, 512, "D2"),         # two tiles, the second ragged; a ragged query block
+    (200, 64, 256, 384, "D2"),         # two full tiles, dv padded to 512
+    (300, 96, 128, 300, "D4"),         # three tiles
+    (70, 700, 64, 260, "D2"),          # narrowest K rows (one DMA piece per wave)
+    (140, 3000, 512, 700, "D2"),       # dv > 512: two chunks of 512 columns
+    (513, 2048, 384, 512, "D3"),       # dk padded to 512, peaky scores
+    (32, 4100, 512, 1024, "D1"),       # fewer rows than a pair holds
+])
+def test_bf16_tandem_kernel_equals_the_wide_kernel_bit_for_bit(m, n, dk, dv, dist, pkg, be, orc, O):
+    """dv > 256 has two kernels: `wide` (every wave owns 32 rows x 512 columns) and `tandem` (two waves share 64
+    rows and split the columns, P handed over through LDS: 50 instead of 64 LDS fragment reads per 64 MFMAs).
+    Same MFMA order per accumulator and the same softmax arithmetic: the triples must be IDENTICAL, 5 launches;
+    and within the bf16 tolerance of the fp64 oracle."""
+    Q, K, V = O.make_inputs(m, n, dk, dv, dist, seed=m + n + dk)
+    sa = pkg.ShardedAttention(be, precision="bf16")
+    sa.load_kv_from_root(K, V, n, dk, dv)
+    qb = sa.convert_q(torch.from_numpy(np.ascontiguousarray(Q)).cuda())
+    try:
+        os.environ["SDPA_BF16_TANDEM"] = "0"
+        want = tuple(t.clone() for t in sa.batch_partial(qb))
+        os.environ["SDPA_BF16_TANDEM"] = "1"
+        for it in range(5):
+            got = sa.batch_partial(qb)
+            for name, g, w in zip(("contrib", "lmax", "lsum"), got, want):
+                g, w = (g[:, :dv], w[:, :dv]) if g.dim() == 2 else (g, w)
+                assert torch.equal(g, w), "launch %d: %s of the tandem kernel differs from the wide kernel" % (it, name)
+        res = be.finish_f64(got[0], got[2], dv).cpu().numpy()
+    finally:
+        os.environ.pop("SDPA_BF16_TANDEM", None)
+    assert np.isfinite(res).all()
+    assert np.abs(res - orc.attention_f64(Q, K, V)).max() <= bf16_tol(V)
+
+
+def test_bf16_tandem_steep_scores_take_the_redo_pass(pkg, be, O):
+    """rows whose scores leave the fixed reference range are flagged by the wave that SCORES them and redone by
+    the general kernel -- also when the other half of their columns sits in the partner wave"""
+    m, n, d = 256, 2048, 512
+    rng = np.random.default_rng(7)
+    Q, K, V = (rng.standard_normal(s) for s in ((m, d), (n, d), (n, d)))
+    Q[5] *= 40.0                       # one row of wave 0 ...
+    Q[100] *= 40.0                     # ... and one of wave 3's: both pairs redo
+    want = O.numpy_attention_f64(Q, K, V)
+    try:
+        os.environ["SDPA_BF16_TANDEM"] = "1"
+        got = dev_attention_bf16(pkg, be, Q, K, V)
+    finally:
+        os.environ.pop("SDPA_BF16_TANDEM", None)
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= bf16_tol(V)

@@ -98,6 +98,17 @@ def test_wide_kernel_loop_is_spill_free(bf16_asm):
     assert c["v_accvgpr_read_b32"] <= 16 and c["v_accvgpr_write_b32"] <= 16, c
 
 
+def test_tandem_kernel_loop_is_spill_free_and_reads_50_fragments_per_64_mfmas(bf16_asm):
+    """dv > 256 default since round 3: two waves share 64 rows and split the value columns.  Per step and wave:
+    32 + 32 MFMAs, 32 K + 16 Vt + 2 P fragment reads (the wide kernel: 64), 2 P stores, 16 DMA pieces,
+    two barriers; O stays in the accumulator file."""
+    c = main_loop_mix(kernel_lines(bf16_asm, "fused_bf16_tandem_kernelILi512E"))
+    assert c["v_mfma_f32_32x32x16_bf16"] == 128 and c["ds_read_b128"] == 100 and c["ds_write_b128"] == 4, c
+    assert sum(v for k, v in c.items() if k.startswith("scratch_")) == 0, c
+    assert c["v_accvgpr_read_b32"] <= 16 and c["v_accvgpr_write_b32"] <= 16, c
+    assert c["global_load_lds_dwordx4"] == 32 and c["s_barrier"] == 4 and c["v_exp_f32"] == 32, c
+
+
 @pytest.fixture(scope="module")
 def f32_asm(tmp_path_factory):
     if not os.path.exists(HIPCC):
