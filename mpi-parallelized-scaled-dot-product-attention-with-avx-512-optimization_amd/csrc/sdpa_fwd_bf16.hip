@@ -1821,7 +1821,10 @@ int pick_kv_splits_bf16(int m, int n_local, int dk, int dv) {
         if (cap < 1) cap = 1;
         if (want > cap) want = cap;
         if (want > 64) want = 64;
-        return want < 1 ? 1 : want;
+        if (want < 1) want = 1;
+        const double kernel_s = 2.0 * m * (double)n_local * (dk + dv) / 1.2e15;
+        const double slab_s = 2.0 * m * (double)((dv + 3) / 4 * 4) * sizeof(float) / 3.0e12;
+        return splits_for_full_rounds(nqb, 256, want, cap, kernel_s, slab_s);      // a fuller last round (sdpa_internal.h)
     }
     const int nqb = (m + kQRowsPerBlock - 1) / kQRowsPerBlock;
     const int chunks = bf16_pad_dv(dv) / bf16_chunk_dv(dv);
@@ -1832,7 +1835,10 @@ int pick_kv_splits_bf16(int m, int n_local, int dk, int dv) {
     if (cap < 1) cap = 1;
     if (want > cap) want = cap;
     if (want > 64) want = 64;
-    return want < 1 ? 1 : want;
+    if (want < 1) want = 1;
+    const double kernel_s = 2.0 * m * (double)n_local * (dk + dv) / 1.1e15;
+    const double slab_s = 2.0 * m * (double)((dv + 3) / 4 * 4) * sizeof(float) / 3.0e12;
+    return splits_for_full_rounds((long)nqb * chunks, 256 * per_cu, want, cap, kernel_s, slab_s);
 }
 
 template <int DK, int DVC, int ABL = 0>

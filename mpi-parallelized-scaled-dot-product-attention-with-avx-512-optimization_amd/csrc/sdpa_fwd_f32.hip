@@ -979,25 +979,32 @@ static inline bool uses_dksplit(int dk, int dv) {
 int pick_kv_splits(int m, int n_local, int dk, int dv) {
     if (dk > kMaxDkSplit) return 1;              // VALU-only fallback kernel: no splits
     if (m <= 0 || n_local <= 0) return 1;
-    if (uses_dksplit(dk, dv)) {                  // 64-row workgroups (32 at dk > 512), one per CU
-        const int rows = dk > 512 ? 32 : 64;
-        const int nb = ((m + rows - 1) / rows) * dksplit_chunks(dv);
-        const int ntiles = (n_local + kKvTile - 1) / kKvTile;
-        int want = (256 + nb - 1) / nb, cap = ntiles / 4;
-        if (cap < 1) cap = 1;
-        if (want > cap) want = cap;
-        if (want > 64) want = 64;
-        return want < 1 ? 1 : want;
-    }
-    const int nqb = ((m + kQRowsPerBlock - 1) / kQRowsPerBlock) * dv_chunks(dv);
     const int ntiles = (n_local + kKvTile - 1) / kKvTile;
-    // aim for 2 resident workgroups on each of the 256 CUs (1 when dk > 128), >= 4 tiles a split
-    int want = ((dk > 128 ? 256 : 512) + nqb - 1) / nqb;
-    int cap = ntiles / 4;
+    int cap = ntiles / 4;                        // >= 4 tiles a split
     if (cap < 1) cap = 1;
+    // head dims in (128, 256] x (.., 256]: the dense images (what the hosts always build) take the pipelined
+    // kernels at one 128-row workgroup per CU, whatever uses_dksplit() says about other leading dimensions
+    const bool wide256 = dk <= kMaxMfmaDk && dv <= 256 && (dk > kMaxFastDim || dv > kMaxFastDim);
+    long blocks;
+    int slots;
+    double rate;
+    if (uses_dksplit(dk, dv) && !wide256) {      // 64-row workgroups (32 at dk > 512), one per CU
+        blocks = (long)((m + dksplit_rows(dk) - 1) / dksplit_rows(dk)) * dksplit_chunks(dv);
+        slots = 256;
+        rate = 1.0e14;
+    } else {
+        blocks = (long)((m + kQRowsPerBlock - 1) / kQRowsPerBlock) * (wide256 ? 1 : dv_chunks(dv));
+        slots = (dk > kMaxFastDim || wide256) ? 256 : 512;   // 2 resident workgroups per CU, 1 beyond 128-wide operands
+        rate = slots == 512 ? 1.4e14 : 1.3e14;
+    }
+    int want = (int)((slots + blocks - 1) / blocks);
     if (want > cap) want = cap;
     if (want > 64) want = 64;
-    return want < 1 ? 1 : want;
+    if (want < 1) want = 1;
+    // more than one round of workgroups: a fuller last round (sdpa_internal.h)
+    const double kernel_s = 2.0 * m * (double)n_local * (dk + dv) / rate;
+    const double slab_s = 2.0 * m * (double)dense_ld(dv) * sizeof(float) / 3.0e12;
+    return splits_for_full_rounds(blocks, slots, want, cap, kernel_s, slab_s);
 }
 
 size_t workspace_bytes(int m, int n_local, int dk, int dv) {

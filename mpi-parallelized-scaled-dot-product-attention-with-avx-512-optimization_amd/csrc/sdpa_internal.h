@@ -100,6 +100,31 @@ hipError_t launch_cvt_bf_t_part(const unsigned short *src, unsigned short *dst, 
                                 int cols_pad, long ldt, hipStream_t s);
 hipError_t launch_split_merge(const PartialArgs &a, hipStream_t s);
 
+// In-GPU K/V splits against TAIL QUANTISATION.  `blocks * s` workgroups run in ceil(blocks * s / slots) rounds of
+// `slots` resident workgroups; once there is more than one round, a thinly filled last round idles most of the
+// chip (m = 40000 at d = 128: 313 query blocks x 2 splits = 626 workgroups = 1.22 rounds: 61 %).  From the count
+// `s0` that fills the chip once, look further for a fuller last round; every extra split costs one more slab
+// written and read by the merge, so the choice minimises  kernel time / efficiency(s) + s x slab time.
+// Shapes whose workgroups fit one round keep s0 (all BASELINE shapes do: 64, 256, 1024 query blocks).
+inline int splits_for_full_rounds(long blocks, int slots, int s0, int cap, double kernel_s, double slab_s) {
+    if (blocks * s0 <= slots || kernel_s <= 0.0) return s0;
+    auto cost = [&](int sp) {
+        const long w = blocks * sp, rounds = (w + slots - 1) / slots;
+        return kernel_s * (double)(rounds * slots) / (double)w + sp * slab_s;
+    };
+    int best = s0;
+    double bc = cost(s0);
+    const int hi = cap < 64 ? cap : 64;
+    for (int sp = s0 + 1; sp <= hi && sp <= s0 + 14; ++sp) {
+        const double cst = cost(sp);
+        if (cst < bc * 0.98) {           // a clear win only: near-ties keep the smaller count
+            best = sp;
+            bc = cst;
+        }
+    }
+    return best;
+}
+
 int  pick_kv_splits(int m, int n_local, int dk, int dv);
 size_t workspace_bytes(int m, int n_local, int dk, int dv);
 // Point a.ws_* (and a.tickets) into a scratch area of workspace_bytes(a.m, ...) bytes: kv_splits slabs of

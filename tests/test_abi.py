@@ -75,7 +75,13 @@ def test_bf16_image_geometry_helpers(pkg):
     assert lib.sdpa_dev_workspace_bytes_bf16(32768, 65536, 128, 128) == (s1 * 32768 * (128 + 2) * 4 if s1 > 1 else 0) + 256 * s1 * 4
     s0 = lib.sdpa_dev_kv_splits_bf16(32768, 65536, 512, 256)      # general kernel: no flags
     assert lib.sdpa_dev_workspace_bytes_bf16(32768, 65536, 512, 256) == (s0 * 32768 * (256 + 2) * 4 if s0 > 1 else 0)
-    assert lib.sdpa_dev_kv_splits_bf16(70000, 4096, 64, 64) == 1 and lib.sdpa_dev_workspace_bytes_bf16(70000, 4096, 64, 64) == 547 * 4
+    # 274 workgroups of 256 rows on 256 CUs would run 1.07 rounds: two splits fill the last round better
+    s2 = lib.sdpa_dev_kv_splits_bf16(70000, 4096, 64, 64)
+    assert s2 == 2 and lib.sdpa_dev_workspace_bytes_bf16(70000, 4096, 64, 64) == s2 * 70000 * (64 + 2) * 4 + 547 * s2 * 4
+    assert lib.sdpa_dev_kv_splits_bf16(65536, 4096, 64, 64) == 1 and lib.sdpa_dev_workspace_bytes_bf16(65536, 4096, 64, 64) == 512 * 4
+    # fp32: one round of workgroups keeps the count that fills the chip once; beyond one round the last round is filled
+    assert lib.sdpa_dev_kv_splits(40000, 65536, 128, 128) == 8       # 313 query blocks: 2 splits = 1.22 rounds (61 %), 8 = 4.9 (98 %)
+    assert lib.sdpa_dev_kv_splits(32768, 65536, 256, 256) == 1 and lib.sdpa_dev_kv_splits(40000, 65536, 256, 256) == 4
     splits = lib.sdpa_dev_kv_splits_bf16(32768, 65536, 512, 512)
     assert splits == 1 and lib.sdpa_dev_workspace_bytes_bf16(32768, 65536, 512, 512) == 256 * 4
     s2 = lib.sdpa_dev_kv_splits_bf16(256, 8192, 512, 512)
