@@ -88,6 +88,72 @@ public:
     const char *name() const override { return "rccl"; }
     const char *last_error() const override { return err_; }
 
+    // Every collective the pipeline uses, once, on known data, before the first real batch: RCCL with more
+    // than one rank has never run under this engine on hardware (one-GPU development boxes), so the first
+    // multi-GPU call checks its transport and fails loudly at engine creation instead of computing on it.
+    // Rank r contributes r + 1 in every element.
+    bool selftest(const int *devs) {
+        const size_t n = 1024;                      // elements per rank
+        std::vector<float *> a(P_, nullptr), b(P_, nullptr);
+        std::vector<hipStream_t> st(P_, nullptr);
+        std::vector<float> host(n * (size_t)P_);
+        bool ok = true;
+        auto fail = [&](const char *what) {
+            snprintf(err_, sizeof err_, "RCCL self-test: %s", what);
+            fprintf(stderr, "sdpa: %s\n", err_);
+            ok = false;
+        };
+        for (int r = 0; r < P_ && ok; ++r) {
+            if (hipSetDevice(devs[r]) != hipSuccess || hipMalloc((void **)&a[r], n * P_ * sizeof(float)) != hipSuccess ||
+                hipMalloc((void **)&b[r], n * P_ * sizeof(float)) != hipSuccess ||
+                hipStreamCreateWithFlags(&st[r], hipStreamNonBlocking) != hipSuccess) {
+                fail("device buffers");
+                break;
+            }
+            for (size_t i = 0; i < n * P_; ++i) host[i] = (float)(r + 1);
+            if (hipMemcpy(a[r], host.data(), n * P_ * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) fail("upload");
+        }
+        auto sync_all = [&]() {
+            for (int r = 0; r < P_; ++r)
+                if (hipSetDevice(devs[r]) != hipSuccess || hipStreamSynchronize(st[r]) != hipSuccess) return false;
+            return true;
+        };
+        auto expect = [&](int r, float *dev, size_t count, auto want, const char *what) {
+            if (!ok) return;
+            if (hipSetDevice(devs[r]) != hipSuccess ||
+                hipMemcpy(host.data(), dev, count * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+                fail(what);
+                return;
+            }
+            for (size_t i = 0; i < count; ++i)
+                if (host[i] != want(i)) {
+                    char msg[120];
+                    snprintf(msg, sizeof msg, "%s: rank %d element %zu is %g, expected %g", what, r, i, (double)host[i],
+                             (double)want(i));
+                    fail(msg);
+                    return;
+                }
+        };
+        const float sum = (float)(P_ * (P_ + 1) / 2);
+        if (ok && (all_reduce(a.data(), b.data(), n, RedOp::Sum, st.data()) || !sync_all())) fail("all_reduce(SUM)");
+        for (int r = 0; r < P_; ++r) expect(r, b[r], n, [&](size_t) { return sum; }, "all_reduce(SUM)");
+        if (ok && (all_reduce(a.data(), b.data(), n, RedOp::Max, st.data()) || !sync_all())) fail("all_reduce(MAX)");
+        for (int r = 0; r < P_; ++r) expect(r, b[r], n, [&](size_t) { return (float)P_; }, "all_reduce(MAX)");
+        if (ok && (all_gather(a.data(), b.data(), n, st.data()) || !sync_all())) fail("all_gather");
+        for (int r = 0; r < P_; ++r) expect(r, b[r], n * P_, [&](size_t i) { return (float)(i / n + 1); }, "all_gather");
+        if (ok && (reduce_scatter_sum(a.data(), b.data(), n, st.data()) || !sync_all())) fail("reduce_scatter");
+        for (int r = 0; r < P_; ++r) expect(r, b[r], n, [&](size_t) { return sum; }, "reduce_scatter");
+        if (ok && (reduce_sum_to_root(a.data(), b[0], n, st.data()) || !sync_all())) fail("reduce to root");
+        expect(0, b[0], n, [&](size_t) { return sum; }, "reduce to root");
+        for (int r = 0; r < P_; ++r) {
+            if (hipSetDevice(devs[r]) != hipSuccess) continue;
+            if (a[r]) (void)hipFree(a[r]);
+            if (b[r]) (void)hipFree(b[r]);
+            if (st[r]) (void)hipStreamDestroy(st[r]);
+        }
+        return ok;
+    }
+
     int all_reduce(float *const *send, float *const *recv, size_t count, RedOp op,
                    hipStream_t const *streams) override {
         const int nop = op == RedOp::Max ? kNcclMax : kNcclSum;
@@ -267,7 +333,7 @@ private:
 Collectives *make_rccl_collectives(int P, const int *devs) {
     if (P < 1 || P > kMaxRanks) return nullptr;
     RcclCollectives *c = new RcclCollectives;
-    if (!c->init(P, devs)) {
+    if (!c->init(P, devs) || !c->selftest(devs)) {
         delete c;
         return nullptr;
     }
