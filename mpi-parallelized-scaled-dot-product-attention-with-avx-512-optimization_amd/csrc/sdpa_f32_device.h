@@ -40,6 +40,12 @@ __device__ __forceinline__ float pinned_max(float a, float b) {
     return y;
 }
 
+__device__ __forceinline__ float pinned_add(float a, float b) {
+    float y;
+    asm volatile("v_add_f32 %0, %1, %2" : "=v"(y) : "v"(a), "v"(b));
+    return y;
+}
+
 // bijective "contiguous chunk per XCD" remap of a 1-D grid: hardware places
 // block b on XCD b%8; give each XCD a contiguous range of work items so blocks
 // that share a K/V split share an L2.

@@ -472,6 +472,40 @@ def test_in_kernel_split_merge_equals_the_separate_pass_bitwise(m, n, dk, dv, pk
     assert np.isfinite(be.finish_f64(got[0], got[2], dv).cpu().numpy()).all()
 
 
+@pytest.mark.parametrize("m,n,dk,dv,dist", [
+    (260, 5000, 512, 512, "D2"),       # BASELINE config 5's dims: ragged rows, in-GPU splits, ragged last tile
+    (64, 32, 512, 512, "D1"),          # one tile
+    (65, 33, 512, 512, "D2"),          # two tiles, the second one key long
+    (130, 64, 384, 384, "D3"),         # two full tiles; 96-wide dk slices
+    (100, 95, 320, 264, "D4"),         # three tiles, the last ragged
+    (257, 1000, 768, 768, "D2"),       # one query block per workgroup, two dv chunks
+    (96, 777, 1024, 32, "D2"),         # 256-wide slices, ONE P.V MFMA per k-step: four units per gap
+    (1024, 2049, 512, 200, "D3"),      # 64-wide dv slices (two units per gap), dv not a multiple of the chunk
+    (96, 777, 700, 130, "D2"),
+    (200, 3000, 200, 256, "D2"),       # the non-dense 128 < dk <= 256 use of the kernel
+    (33, 1, 640, 640, "D1"),           # a single key
+])
+def test_f32_dksplit_pipelined_kernel_equals_the_serial_one_bit_for_bit(m, n, dk, dv, dist, pkg, be, orc, O, monkeypatch):
+    """dk > 256 in fp32: fused_dksplit_pipe_kernel (the default) places the exchange sums and the softmax of
+    tile t+1 between the P.V MFMAs of tile t; fused_dksplit_kernel ($SDPA_DKSPLIT_PIPE=0) runs the phases one
+    after the other.  Same operations in the same order on every value: the triples must be IDENTICAL
+    (5 launches), and within the fp32 tolerance of the fp64 oracle."""
+    Q, K, V = O.make_inputs(m, n, dk, dv, dist, seed=m + n + dk)
+    sa = pkg.ShardedAttention(be)
+    sa.load_kv_from_root(K, V, n, dk, dv)
+    qf = sa.convert_q(torch.from_numpy(np.ascontiguousarray(Q)).cuda())
+    monkeypatch.setenv("SDPA_DKSPLIT_PIPE", "0")
+    want = tuple(t.clone() for t in sa.batch_partial(qf))
+    monkeypatch.setenv("SDPA_DKSPLIT_PIPE", "1")
+    for it in range(5):
+        got = sa.batch_partial(qf)
+        for name, g, w in zip(("contrib", "lmax", "lsum"), got, want):
+            g, w = (g[:, :dv], w[:, :dv]) if g.dim() == 2 else (g, w)
+            assert torch.equal(g, w), "launch %d: %s of the pipelined kernel differs from the serial one" % (it, name)
+    res = be.finish_f64(got[0], got[2], dv).cpu().numpy()
+    check(res, orc.attention_f64(Q, K, V), V, "dk-split pipelined")
+
+
 def steep_late_rise_inputs(m, n, d, vscale, seed=3, first=32, rise_nats=15.0):
     """Keys [0, first) score `rise_nats` BELOW all the others for every query, and every V entry is
     ~ +vscale: a kernel that defers its accumulator rescale (rise < 2^24) carries weights of e^15

@@ -33,7 +33,11 @@ def kernel_lines(lines, name_re):
 
 
 def main_loop_mix(k):
-    """instruction histogram of the INNERMOST backward-branch loop of a kernel that holds the most MFMAs
+    return main_loop_span(k)[2]
+
+
+def main_loop_span(k):
+    """(first line, last line, instruction histogram) of the INNERMOST backward-branch loop of a kernel that holds the most MFMAs
     (a loop that contains another backward branch is an outer loop: the fp32 kernels' second pass
     around the whole K/V walk, for instance)"""
     labels = {m.group(1): i for i, l in enumerate(k) if (m := re.match(r"^(\.LBB\d+_\d+):", l))}
@@ -61,9 +65,9 @@ def main_loop_mix(k):
         # twice (straight-line), and the second copy is the rare eager-rescale pass behind a failed
         # range check -- it may spill, the first one may not
         if best is None or n > best[0]:
-            best = (n, hi - lo, c)
+            best = (n, (lo, hi), c)
     assert best is not None, "no loop found"
-    return best[2]
+    return best[1][0], best[1][1], best[2]
 
 
 @pytest.fixture(scope="module")
@@ -154,6 +158,28 @@ def test_f32_dksplit_kernel_is_one_template_with_both_block_counts(dks, dvs, qb,
     assert sum(v for k, v in c.items() if k.startswith("scratch_")) <= 1, c
     assert c["ds_write_b128"] == 4 * qb and c["ds_read_b128"] == 16 * qb, c
     assert c["global_load_lds_dwordx4"] == 0, c
+
+
+@pytest.mark.parametrize("dks,dvs,qb", [(128, 128, 2), (96, 128, 2), (64, 64, 2), (256, 128, 1), (192, 64, 1), (128, 32, 2)])
+def test_f32_dksplit_pipelined_kernel_keeps_the_softmax_between_the_pv_mfmas(dks, dvs, qb, dksplit_asm):
+    """fused_dksplit_pipe_kernel: the same MFMAs per tile as the serial-phase kernel, nothing spilled, one
+    barrier -- and the exchange reads, the row max and the exponentials of the NEXT tile sit between the P.V
+    MFMAs of this one (one wave per SIMD: only instructions written between two MFMAs run in an MFMA's
+    shadow).  Left to itself LLVM sinks that pure VALU work to the loop end, next to its first use."""
+    k = kernel_lines(dksplit_asm, "fused_dksplit_pipe_kernelILi%dELi%dELi%dE" % (dks, dvs, qb))
+    lo, hi, c = main_loop_span(k)
+    assert c["v_mfma_f32_32x32x2_f32"] == qb * (dks // 2 + 16 * dvs // 32), c
+    assert sum(v for name, v in c.items() if name.startswith("scratch_")) == 0, c
+    assert c["s_barrier"] == 1 and c["ds_write_b128"] == 4 * qb and c["ds_read_b128"] == 16 * qb, c
+    ops = [m.group(1) for l in k[lo:hi + 1] if (m := re.match(r"^\t([a-z_0-9]+)", l))]
+    mfma_at = [i for i, o in enumerate(ops) if o.startswith("v_mfma")]
+    inside = lambda name: sum(1 for i, o in enumerate(ops) if o == name and mfma_at[0] < i < mfma_at[-1])
+    assert inside("v_exp_f32") >= 17 * qb, c           # 16 exponentials + alpha per block, all before the last MFMA
+    assert inside("ds_read_b128") == 16 * qb, c
+    # and never more than a few of them in one gap between two MFMAs
+    gaps = [sum(1 for o in ops[a + 1:b] if o == "v_exp_f32") for a, b in zip(mfma_at, mfma_at[1:])]
+    slots = 16 * qb * dvs // 32                         # P.V MFMAs per tile; 50 units per query block to place
+    assert max(gaps) <= -(-50 * qb // slots), gaps
 
 
 @pytest.mark.parametrize("dk,dv", [(64, 64), (128, 64), (64, 128)])
