@@ -153,11 +153,16 @@ def cpu_baseline(m, n, d, budget_rows=8192):
                 tflops=flop / dt / 1e12, cpu=model, build="oracle/sdpa_oracle.c, gcc -O2 -fopenmp")
 
 
+# the translation units (and their shared headers) that define the fused kernels of one precision
+KERNEL_SOURCES = {"f32": ("sdpa_fwd_f32.hip", "sdpa_fwd_f32_dksplit.hip", "sdpa_f32_device.h", "sdpa_internal.h"),
+                  "bf16": ("sdpa_fwd_bf16.hip", "sdpa_internal.h")}
+
+
 def kernel_source_stamp(precision="f32"):
     """identifies the build a profile of the fused kernel was taken from: sha256 over the
     sources that define it (git is not available on the GPU box)"""
     h = hashlib.sha256()
-    for f in ("sdpa_fwd_bf16.hip" if precision == "bf16" else "sdpa_fwd_f32.hip", "sdpa_internal.h"):
+    for f in KERNEL_SOURCES[precision]:
         h.update(open(os.path.join(ROOT, PKG, "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -612,7 +617,9 @@ def main():
             kernel_name = "sdpa::fused_pipelined_kernel<%d,%d,0>" % (d, d)
         elif 128 < d <= 512:
             dks = 128 if d > 384 else 96 if d > 256 else 64
-            kernel_name = "sdpa::fused_dksplit_kernel<%d,%d>" % (dks, 128 if d > 256 else 64)
+            piped = os.environ.get("SDPA_DKSPLIT_PIPE", "1") != "0"
+            kernel_name = ("sdpa::fused_dksplit_pipe_kernel<%d,%d,2>" if piped else "sdpa::fused_dksplit_kernel<%d,%d,2>") % (
+                dks, 128 if d > 256 else 64)
         else:
             kernel_name = "sdpa::fused_partial_kernel / generic_partial_kernel"
         total_flop = 4.0 * m * n * d

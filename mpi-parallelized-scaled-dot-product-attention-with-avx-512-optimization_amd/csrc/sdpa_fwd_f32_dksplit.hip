@@ -313,7 +313,9 @@ __global__ __launch_bounds__(256, 1) void fused_dksplit_pipe_kernel(
     constexpr int U_M = 6 * QB;                // row max (5 units of 3 max) + running-max update, per block
     constexpr int U_E = 16 * QB;               // one exponential each
     constexpr int UNITS = U_X + U_M + U_E;
-    constexpr int UPS = (UNITS + SLOTS - 1) / SLOTS;
+    constexpr int USLOTS = 14 * MPS;           // step 0 carries the exchange stores, the barrier sits behind step 1
+    constexpr int UPS = (UNITS + USLOTS - 1) / USLOTS;
+    constexpr int WPS = (4 * QB + MPS - 1) / MPS;      // exchange stores per MFMA of step 0
 
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][XBUF]
 
@@ -395,21 +397,19 @@ __global__ __launch_bounds__(256, 1) void fused_dksplit_pipe_kernel(
 #pragma unroll
         for (int i = 0; i < PD; ++i) kq[i] = *reinterpret_cast<const f32x4 *>(kb + (krow + kcolb(i)));
     };
-    // ---- A: partial S^T of tile `tile` over this wave's dk slice -> n0 / n1 -> own slot of the exchange buffer
+    // ---- A: partial S^T of tile `tile` over this wave's dk slice -> n0 / n1 (first_k(tile) went out a phase ago)
     auto partial_scores = [&](int tile) __attribute__((always_inline)) {
         const int base = kv_begin + tile * kKvTile;
-        const int last = kv_end - 1 - base;
         const char *kb = reinterpret_cast<const char *>(a.K + (size_t)base * a.ldk);
-        const unsigned krow = (unsigned)min(li, last) * (unsigned)a.ldk * 4u;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { n0[r] = 0.f; n1[r] = 0.f; }
+        const unsigned krow = (unsigned)min(li, kv_end - 1 - base) * (unsigned)a.ldk * 4u;
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const f32x4 kf = kq[u % PD];
             if (u + PD < NU) kq[u % PD] = *reinterpret_cast<const f32x4 *>(kb + (krow + kcolb(u + PD)));
             __builtin_amdgcn_sched_barrier(0);
-            n0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[0][u].x, n0, 0, 0, 0);
-            if constexpr (QB == 2) n1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[QB - 1][u].x, n1, 0, 0, 0);
+            n0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[0][u].x, u == 0 ? zero : n0, 0, 0, 0);
+            if constexpr (QB == 2) n1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[QB - 1][u].x, u == 0 ? zero : n1, 0, 0, 0);
             n0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[0][u].y, n0, 0, 0, 0);
             if constexpr (QB == 2) n1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[QB - 1][u].y, n1, 0, 0, 0);
             n0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[0][u].z, n0, 0, 0, 0);
@@ -417,14 +417,18 @@ __global__ __launch_bounds__(256, 1) void fused_dksplit_pipe_kernel(
             n0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[0][u].w, n0, 0, 0, 0);
             if constexpr (QB == 2) n1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[QB - 1][u].w, n1, 0, 0, 0);
         }
-        float *mine = smem + (tile & 1) * XBUF + ((wave * QB) * 64 + lane) * XLD;
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
+    };
+    // piece i (of 4 * QB) of this wave's partial -> its slot of tile's exchange buffer (block 0's four first)
+    auto store_partial = [&](auto I, int tile) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value, qb = i / 4, q4 = i % 4;
+        float *mine = smem + (tile & 1) * XBUF + ((wave * QB + qb) * 64 + lane) * XLD;
+        if constexpr (qb == 0)
             *reinterpret_cast<f32x4 *>(mine + 4 * q4) = f32x4{n0[4 * q4], n0[4 * q4 + 1], n0[4 * q4 + 2], n0[4 * q4 + 3]};
-            if constexpr (QB == 2)
-                *reinterpret_cast<f32x4 *>(mine + 64 * XLD + 4 * q4) =
-                    f32x4{n1[4 * q4], n1[4 * q4 + 1], n1[4 * q4 + 2], n1[4 * q4 + 3]};
-        }
+        else
+            *reinterpret_cast<f32x4 *>(mine + 4 * q4) = f32x4{n1[4 * q4], n1[4 * q4 + 1], n1[4 * q4 + 2], n1[4 * q4 + 3]};
+    };
+    auto store_partials = [&](int tile) __attribute__((always_inline)) {
+        static_for<0, 4 * QB>([&](auto I) __attribute__((always_inline)) { store_partial(I, tile); });
     };
 
     // first V fragments of a tile (the ring the P.V loop continues)
@@ -504,7 +508,9 @@ __global__ __launch_bounds__(256, 1) void fused_dksplit_pipe_kernel(
         static_for<U_X, UNITS>([&](auto K) __attribute__((always_inline)) { unit(K, xb); });
     };
 
-    // ---- B: O^T slice += V(tile)^T . P(tile)^T; with NEXT, the units of tile + 1 between the MFMAs
+    // ---- B: O^T slice += V(tile)^T . P(tile)^T.  With NEXT (a full tile + 1 follows, its partial scores in n0 / n1):
+    // step 0 carries the exchange stores of tile + 1, the barrier sits behind step 1, the units of tile + 1 follow
+    // between the MFMAs of steps 2..15.
     auto pv = [&](auto next, int tile) __attribute__((always_inline)) {
         constexpr bool NEXT = decltype(next)::value;
         const int base = kv_begin + tile * kKvTile;
@@ -525,9 +531,16 @@ __global__ __launch_bounds__(256, 1) void fused_dksplit_pipe_kernel(
                 else
                     oacc[tt][QB - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.v[tt], s1[r], oacc[tt][QB - 1], 0, 0, 0);
                 if constexpr (NEXT) {
-                    constexpr int slot = r * MPS + i;
-                    static_for<slot * UPS, (slot + 1) * UPS < UNITS ? (slot + 1) * UPS : UNITS>(
-                        [&](auto K) __attribute__((always_inline)) { unit(K, xb); });
+                    if constexpr (r == 0) {
+                        static_for<i * WPS, (i + 1) * WPS < 4 * QB ? (i + 1) * WPS : 4 * QB>(
+                            [&](auto W) __attribute__((always_inline)) { store_partial(W, tile + 1); });
+                    } else if constexpr (r == 1) {
+                        if constexpr (i == MPS - 1) __syncthreads();
+                    } else {
+                        constexpr int slot = (r - 2) * MPS + i;
+                        static_for<slot * UPS, (slot + 1) * UPS < UNITS ? (slot + 1) * UPS : UNITS>(
+                            [&](auto K) __attribute__((always_inline)) { unit(K, xb); });
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
@@ -550,10 +563,12 @@ __global__ __launch_bounds__(256, 1) void fused_dksplit_pipe_kernel(
         if constexpr (QB == 2) s1 = n1;
     };
 
+
     if (ntiles > 0) {
         // tile 0: nothing to overlap with yet (O is zero: no rescale)
         first_k(0);
         partial_scores(0);
+        store_partials(0);
         __syncthreads();
         if (ntiles > 1) first_k(1);
         units_serial(0, kv_end - kv_begin);
@@ -565,7 +580,6 @@ __global__ __launch_bounds__(256, 1) void fused_dksplit_pipe_kernel(
             first_v(cur);                      // in flight under the score MFMAs
             partial_scores(cur + 1);
             pin_o();
-            __syncthreads();
             first_k(min(cur + 2, ntiles - 1)); // in flight under the P.V MFMAs (the last one is a harmless re-read)
             pv(std::true_type{}, cur);
             pin_o();
@@ -577,6 +591,7 @@ __global__ __launch_bounds__(256, 1) void fused_dksplit_pipe_kernel(
             pin_o();
             first_v(cur);
             partial_scores(cur + 1);
+            store_partials(cur + 1);
             pin_o();
             __syncthreads();
             pv(std::false_type{}, cur);

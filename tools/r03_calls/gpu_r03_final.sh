@@ -51,3 +51,37 @@ if [ "$1" = "bf16" ]; then
   SDPA_FUZZ_CASES=150 timeout 900 python -m pytest tests/test_gpu_fuzz.py -q -s -k "bf16 or loopback" 2>&1 | grep -E "worst|passed|failed|FAILED|^E " | cut -c1-300 > $O/fuzz_bf16.log
   cat $O/pytest_gpu_final.log; grep -A12 "== dominant kernel" $O/prof/r03_config5_bf16/summary.txt | cut -c1-220; python -c "import json; j=json.load(open('$O/bench_config5_bf16.json')); print(round(j['ms_per_step'],4), j['roofline'], j['parity_max_err'])" | cut -c1-500; cut -c1-300 $O/hostlevel_config5_bf16.log; cat $O/bf16_head_dims.log $O/fuzz_bf16.log; tail -2 $O/bench.err
 fi
+
+# ---- addendum 2 (after the fp32 dk-split kernel became software-pipelined; the fp32 source stamp now covers
+# sdpa_fwd_f32_dksplit.hip and sdpa_f32_device.h too): full suite, every fp32 profile again, bench lines
+if [ "$1" = "f32b" ]; then
+  O=$R/gpurun_out/r03final_f32b
+  mkdir -p $O
+  timeout 2400 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|FAILED|^E " | cut -c1-200 > $O/pytest_gpu_final.log
+  python -c "import __graft_entry__ as g; g.smoke()" >> $O/pytest_gpu_final.log 2>&1
+  timeout 600 bash tools/gpu_profile.sh r03 > $O/profile_headline.log 2>&1
+  BENCH_ARGS="--workload d256" timeout 600 bash tools/gpu_profile.sh r03_f32_d256 > $O/profile_f32_d256.log 2>&1
+  BENCH_ARGS="--workload config2" PROF_STEPS=40 timeout 600 bash tools/gpu_profile.sh r03_config2 > $O/profile_config2.log 2>&1
+  BENCH_ARGS="--workload config3" PROF_STEPS=5 timeout 600 bash tools/gpu_profile.sh r03_config3 > $O/profile_config3.log 2>&1
+  BENCH_ARGS="--workload config4" PROF_STEPS=5 timeout 600 bash tools/gpu_profile.sh r03_config4 > $O/profile_config4.log 2>&1
+  BENCH_ARGS="--workload config5" PROF_STEPS=5 timeout 600 bash tools/gpu_profile.sh r03_config5_f32 > $O/profile_config5_f32.log 2>&1
+  TAGS="r03 r03_f32_d256 r03_config2 r03_config3 r03_config4 r03_config5_f32"
+  python tools/merge_traffic.py $(for t in $TAGS; do echo gpurun_out/prof_$t/traffic.json; done) > $O/merge_traffic.log 2>&1
+  cp profiles/traffic_latest.json $O/traffic_latest.json
+  for t in $TAGS; do
+    mkdir -p $O/prof/$t
+    cp $R/gpurun_out/prof_$t/summary.txt $R/gpurun_out/prof_$t/traffic.json $O/prof/$t/ 2>/dev/null
+    find $R/gpurun_out/prof_$t/trace -name "*kernel_stats.csv" -exec cp {} $O/prof/$t/kernel_stats.csv \; 2>/dev/null
+    rm -rf $R/gpurun_out/prof_$t
+  done
+  timeout 600 python bench.py > $O/bench_n1.json 2> $O/bench.err
+  timeout 300 python bench.py --workload config2 --no-cpu-baseline > $O/bench_config2.json 2>> $O/bench.err
+  timeout 300 python bench.py --workload d256 --no-cpu-baseline > $O/bench_d256_f32.json 2>> $O/bench.err
+  timeout 300 python bench.py --workload config5 --no-cpu-baseline > $O/bench_config5_f32.json 2>> $O/bench.err
+  timeout 300 python bench.py --workload config3 --no-cpu-baseline --no-boundary --steps 5 > $O/bench_config3_one_gpu.json 2>> $O/bench.err
+  timeout 300 python tools/gpu_hostlevel.py config5 > $O/hostlevel_config5_f32.log 2>> $O/bench.err
+  timeout 300 python tools/gpu_f32_dims.py 128 256 384 512 2>&1 | grep tflops > $O/f32_head_dims.log
+  cat $O/pytest_gpu_final.log; for t in $TAGS; do grep -A4 "== dominant kernel" $O/prof/$t/summary.txt | cut -c1-200; done; cat $O/merge_traffic.log
+  for f in n1 config2 d256_f32 config5_f32 config3_one_gpu; do python -c "import json,sys; j=json.load(open('$O/bench_$f.json')); r=j['roofline']; print('$f', round(j['ms_per_step'],4), round(r['kernel_ms_avg'],4), round(r['frac'],4), r['traffic'], r['hbm_gbps'], r['mfma_util'], j.get('parity_max_err'))" 2>&1 | cut -c1-300; done
+  cut -c1-300 $O/hostlevel_config5_f32.log; cat $O/f32_head_dims.log; tail -3 $O/bench.err
+fi

@@ -119,8 +119,9 @@ if disp:
         print("HBM-side rate              %.1f GB/s = %.2f %% of the 8 TB/s peak" % (gbps, gbps / 80.0))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    src = "sdpa_fwd_bf16.hip" if precision == "bf16" else "sdpa_fwd_f32.hip"
-    for fn in (src, "sdpa_internal.h"):       # the fused kernel's sources (bench.py quotes the figures only for this build)
+    srcs = (("sdpa_fwd_bf16.hip", "sdpa_internal.h") if precision == "bf16" else       # = bench.KERNEL_SOURCES
+            ("sdpa_fwd_f32.hip", "sdpa_fwd_f32_dksplit.hip", "sdpa_f32_device.h", "sdpa_internal.h"))
+    for fn in srcs:                           # the fused kernels' sources (bench.py quotes the figures only for this build)
         h.update(open(os.path.join(root, "mpi-parallelized-scaled-dot-product-attention-with-avx-512-optimization_amd", "csrc", fn), "rb").read())
     entry["kernel_src_sha16"] = h.hexdigest()[:16]
     entry["correction"] = "FETCH_SIZE KiB x1024 x2 (gfx950 wide-read under-count) + WRITE_SIZE KiB x1024"
