@@ -7,7 +7,7 @@ O=$R/gpurun_out/r03final
 mkdir -p $O
 cd $R
 export TMPDIR=/tmp
-if [ "$1" != "bf16" ]; then
+if [ -z "$1" ]; then
 timeout 2400 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|FAILED|^E " | cut -c1-200 > $O/pytest_gpu_final.log
 python -c "import __graft_entry__ as g; g.smoke()" >> $O/pytest_gpu_final.log 2>&1
 timeout 900 bash tools/gpu_profile.sh r03 > $O/profile_headline.log 2>&1
