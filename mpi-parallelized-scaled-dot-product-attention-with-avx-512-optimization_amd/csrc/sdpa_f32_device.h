@@ -78,4 +78,25 @@ template <> struct VFrag<1> {
     static __device__ __forceinline__ VFrag load(const float *p) { VFrag f; f.v[0] = *p; return f; }
 };
 
+// NT CONSECUTIVE floats of one V row (the dk-split kernels: O^T tile tt of a wave's slice holds column
+// NT * li + tt), 4-byte aligned; 3 / 6 / 8 floats come as dwordx3 / dwordx4 + dwordx2 / 2 x dwordx4.
+template <int NT> struct VRun {
+    typedef float vec_t __attribute__((ext_vector_type(NT)));
+    vec_t v;
+    static __device__ __forceinline__ VRun load(const float *p) {
+        VRun f;
+        if constexpr (NT == 1) {
+            f.v[0] = *p;
+        } else if constexpr (NT == 2 || NT == 4) {
+            f.v = *reinterpret_cast<const vec_t *>(p);       // 8- / 16-byte aligned by construction (NT * li floats into an aligned row)
+        } else {
+            float t[NT];
+            __builtin_memcpy(t, p, NT * sizeof(float));
+#pragma unroll
+            for (int i = 0; i < NT; ++i) f.v[i] = t[i];
+        }
+        return f;
+    }
+};
+
 }  // namespace sdpa

@@ -989,7 +989,7 @@ int pick_kv_splits(int m, int n_local, int dk, int dv) {
     int slots;
     double rate;
     if (uses_dksplit(dk, dv) && !wide256) {      // 64-row workgroups (32 at dk > 512), one per CU
-        blocks = (long)((m + dksplit_rows(dk) - 1) / dksplit_rows(dk)) * dksplit_chunks(dv);
+        blocks = (long)((m + dksplit_rows(dk) - 1) / dksplit_rows(dk)) * dksplit_chunks(dk, dv);
         slots = 256;
         rate = 1.0e14;
     } else {

@@ -148,10 +148,10 @@ __global__ __launch_bounds__(256, 1) void fused_dksplit_kernel(
 
         pin_o();
         // first V fragments of this tile go out now, under the exchange
-        VFrag<NT> vq[PD];
+        VRun<NT> vq[PD];
 #pragma unroll
         for (int i = 0; i < PD; ++i)
-            vq[i] = VFrag<NT>::load(reinterpret_cast<const float *>(
+            vq[i] = VRun<NT>::load(reinterpret_cast<const float *>(
                 vb + ((unsigned)min(crow(i, 0) + 4 * hi, last) * (unsigned)a.ldv * 4u + vcolb)));
 
         // ---- exchange: every wave ends up with the same full S^T (fixed summation order)
@@ -225,9 +225,9 @@ __global__ __launch_bounds__(256, 1) void fused_dksplit_kernel(
         // ---- O^T slice += V_tile^T . P^T   (k-step r of half-wave hi is key row crow(r, hi))
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const VFrag<NT> vf = vq[r % PD];
+            const VRun<NT> vf = vq[r % PD];
             if (r + PD < 16)
-                vq[r % PD] = VFrag<NT>::load(reinterpret_cast<const float *>(
+                vq[r % PD] = VRun<NT>::load(reinterpret_cast<const float *>(
                     vb + ((unsigned)min(crow(r + PD, 0) + 4 * hi, last) * (unsigned)a.ldv * 4u + vcolb)));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256, 1) void fused_dksplit_pipe_kernel(
     float tmax0 = 0.f, tmax1 = 0.f, alpha0 = 1.f, alpha1 = 1.f, mc0 = 0.f, mc1 = 0.f;
     bool rise = false;
     f32x4 rd[4];
-    VFrag<NT> vq[PD];
+    VRun<NT> vq[PD];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; n0[r] = 0.f; n1[r] = 0.f; }
 
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256, 1) void fused_dksplit_pipe_kernel(
         const char *vb = reinterpret_cast<const char *>(a.V + (size_t)base * a.ldv);
 #pragma unroll
         for (int i = 0; i < PD; ++i)
-            vq[i] = VFrag<NT>::load(reinterpret_cast<const float *>(
+            vq[i] = VRun<NT>::load(reinterpret_cast<const float *>(
                 vb + ((unsigned)min(crow(i, 0) + 4 * hi, last) * (unsigned)a.ldv * 4u + vcolb)));
     };
 
@@ -519,9 +519,9 @@ __global__ __launch_bounds__(256, 1) void fused_dksplit_pipe_kernel(
         const float *xb = smem + ((tile + 1) & 1) * XBUF;
         static_for<0, 16>([&](auto R) __attribute__((always_inline)) {
             constexpr int r = decltype(R)::value;
-            const VFrag<NT> vf = vq[r % PD];
+            const VRun<NT> vf = vq[r % PD];
             if constexpr (r + PD < 16)
-                vq[r % PD] = VFrag<NT>::load(reinterpret_cast<const float *>(
+                vq[r % PD] = VRun<NT>::load(reinterpret_cast<const float *>(
                     vb + ((unsigned)min(crow(r + PD, 0) + 4 * hi, last) * (unsigned)a.ldv * 4u + vcolb)));
             __builtin_amdgcn_sched_barrier(0);
             static_for<0, MPS>([&](auto I) __attribute__((always_inline)) {
@@ -644,8 +644,17 @@ __global__ __launch_bounds__(256, 1) void fused_dksplit_pipe_kernel(
 // host-side launch logic
 // ---------------------------------------------------------------------------
 // per-wave dv slice (a dv chunk = 4 slices)
-static inline int dksplit_slice(int dv) { return dv <= 128 ? 32 : (dv <= 256 ? 64 : 128); }
-int dksplit_chunks(int dv) { return (dv + 4 * dksplit_slice(dv) - 1) / (4 * dksplit_slice(dv)); }
+// per-wave dv slice (a dv chunk = 4 slices), matched to dv so that no P.V MFMA runs on padding columns and a
+// second chunk -- which recomputes the scores -- only starts where one workgroup's accumulators end: two query
+// blocks (dk <= 512) hold 128 columns per wave, one block (dk > 512) 256
+static inline int dksplit_slice(int dk, int dv) {
+    if (dv <= 128) return 32;
+    if (dv <= 256) return 64;
+    if (dv <= 384) return 96;
+    if (dv <= 512 || dk <= 512) return 128;
+    return dv <= 768 ? 192 : 256;
+}
+int dksplit_chunks(int dk, int dv) { return (dv + 4 * dksplit_slice(dk, dv) - 1) / (4 * dksplit_slice(dk, dv)); }
 int dksplit_rows(int dk) { return dk > 512 ? 32 : 64; }      // query rows per workgroup: one block beyond dk = 512
 
 // $SDPA_DKSPLIT_PIPE=0: the serial-phase kernel (kept for A/B and as the bitwise reference of the pipelined one)
@@ -663,7 +672,7 @@ static hipError_t launch_one(const PartialArgs &a, hipStream_t s) {
     const int ntiles = (a.n_local + kKvTile - 1) / kKvTile;
     const int tiles_per_split = (ntiles + a.kv_splits - 1) / a.kv_splits;
     const int kv_per_split = tiles_per_split > 0 ? tiles_per_split * kKvTile : kKvTile;
-    const int chunks = dksplit_chunks(a.dv);
+    const int chunks = (a.dv + 4 * DVS - 1) / (4 * DVS);
     const size_t lds = (size_t)2 * 4 * QB * 64 * 20 * sizeof(float);
     static bool attr_done[64] = {};
     int dev = 0;
@@ -690,12 +699,27 @@ static hipError_t launch_one(const PartialArgs &a, hipStream_t s) {
     return e;
 }
 
+// the slice a launch uses: the matched one when the V image's rows are a whole number of lane runs (dense_ld()
+// images always are), else the 128-wide one, whose runs of 4 fit every leading dimension the API accepts
+static inline int launch_slice_width(const PartialArgs &a) {
+    const int w = dksplit_slice(a.dk, a.dv);
+    return (a.ldv % (w / 32) == 0) ? w : 128;
+}
+
 template <int DKS, int QB>
 static hipError_t launch_slice(const PartialArgs &a, hipStream_t s) {
-    switch (dksplit_slice(a.dv)) {
+    switch (launch_slice_width(a)) {
         case 32: return launch_one<DKS, 32, QB>(a, s);
         case 64: return launch_one<DKS, 64, QB>(a, s);
-        default: return launch_one<DKS, 128, QB>(a, s);
+        case 96: return launch_one<DKS, 96, QB>(a, s);
+        case 128: return launch_one<DKS, 128, QB>(a, s);
+        default:
+            if constexpr (QB == 1) {
+                if (launch_slice_width(a) == 192) return launch_one<DKS, 192, 1>(a, s);
+                return launch_one<DKS, 256, 1>(a, s);
+            } else {
+                return hipErrorInvalidValue;      // two query blocks never get more than 128 columns per wave
+            }
     }
 }
 
@@ -705,7 +729,11 @@ hipError_t launch_dksplit(const PartialArgs &a, hipStream_t s) {
     if (a.dk > 384) return launch_slice<128, 2>(a, s);
     if (a.dk > kMaxMfmaDk) return launch_slice<96, 2>(a, s); // 256 < dk <= 384: 96-wide slices, no score MFMAs on padding
     // non-dense 128 < dk <= 256 with dv > 128
-    return dksplit_slice(a.dv) == 64 ? launch_one<64, 64, 2>(a, s) : launch_one<64, 128, 2>(a, s);
+    switch (launch_slice_width(a)) {
+        case 64: return launch_one<64, 64, 2>(a, s);
+        case 96: return launch_one<64, 96, 2>(a, s);
+        default: return launch_one<64, 128, 2>(a, s);
+    }
 }
 
 }  // namespace sdpa

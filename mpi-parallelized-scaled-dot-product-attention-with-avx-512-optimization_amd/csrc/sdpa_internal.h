@@ -21,7 +21,14 @@ constexpr int kMaxMfmaDk     = 256;   // dk <= 256 takes an MFMA kernel (any dv,
 // Leading dimension the fp32 operand images and the contrib rows are best given: head dims in (32, 256]
 // padded (with zero columns) to 64 / 128 / 256, so that they take the LDS-DMA pipelined kernel whatever
 // the dims are -- it does the padded MFMA work the any-shape kernels do as well, at its own rate.
-inline int dense_ld(int d) { return d <= 32 ? (d + 3) / 4 * 4 : d <= 64 ? 64 : d <= 128 ? 128 : d <= 256 ? 256 : (d + 3) / 4 * 4; }
+// Beyond 256 (the dk-split kernels): a whole number of the lane runs its dv slice reads -- 3 / 4 / 6 / 8
+// consecutive V columns for the 96 / 128 / 192 / 256-wide slices of dv <= 384 / 512 / 768 / 1024+ -- and of 4,
+// so that no run straddles the row end: multiples of 12 / 4 / 12 / 8 (384, 512, 768, 1024 stay as they are).
+inline int dense_ld(int d) {
+    if (d <= 256) return d <= 32 ? (d + 3) / 4 * 4 : d <= 64 ? 64 : d <= 128 ? 128 : 256;
+    const int q = d <= 384 ? 12 : d <= 512 ? 4 : d <= 768 ? 12 : 8;
+    return (d + q - 1) / q * q;
+}
 constexpr int kMaxDkSplit    = 1024;  // 256 < dk <= 1024: the dk-split MFMA kernel (waves split dk and dv)
 
 struct PartialArgs {
@@ -133,7 +140,7 @@ void carve_workspace(PartialArgs &a, void *ws, int ws_ld);
 
 // the dk-split kernels (sdpa_fwd_f32_dksplit.hip): launcher and the grid arithmetic pick_kv_splits needs
 hipError_t launch_dksplit(const PartialArgs &a, hipStream_t s);
-int dksplit_chunks(int dv);
+int dksplit_chunks(int dk, int dv);
 int dksplit_rows(int dk);
 
 // Enqueue the fused kernel (+ the split merge when kv_splits > 1).

@@ -40,8 +40,12 @@ def round4(x):
 
 def dense_ld(d):
     """leading dimension of an fp32 operand image: head dims in (32, 256] padded (zero columns) to
-    64 / 128 / 256, the widths of the pipelined LDS-DMA kernel (csrc/sdpa_internal.h: dense_ld)"""
-    return round4(d) if d <= 32 or d > 256 else 64 if d <= 64 else 128 if d <= 128 else 256
+    64 / 128 / 256, the widths of the pipelined LDS-DMA kernel; beyond 256 a whole number of the dk-split kernels' lane runs
+    (csrc/sdpa_internal.h: dense_ld)"""
+    if d > 256:       # the dk-split kernels read 3 / 4 / 6 / 8 consecutive V columns per lane (dv <= 384 / 512 / 768 / beyond)
+        q = 12 if d <= 384 else 4 if d <= 512 else 12 if d <= 768 else 8
+        return (d + q - 1) // q * q
+    return round4(d) if d <= 32 else 64 if d <= 64 else 128 if d <= 128 else 256
 
 
 def _ld(be, d):

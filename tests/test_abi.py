@@ -38,14 +38,18 @@ def test_owner_partition_matches_oracle(n, size, pkg, orc):
 
 
 def test_dense_ld_python_and_c_agree(pkg):
-    """leading dimension of the fp32 operand images: (32, 256] padded to 64 / 128 / 256, else rounded to 4"""
+    """leading dimension of the fp32 operand images: (32, 256] padded to 64 / 128 / 256, up to 32 rounded to 4,
+    beyond 256 to 12 / 4 / 12 / 8 (dv <= 384 / 512 / 768 / more: a lane of the dk-split kernels reads 3 / 4 / 6 / 8
+    consecutive V columns, and no run may straddle the row end)"""
     lib = pkg.load()
     from importlib import import_module
     eng = import_module(pkg.__name__ + ".engine")
     for d in range(1, 700):
         assert lib.sdpa_dev_dense_ld(d) == eng.dense_ld(d) >= d and eng.dense_ld(d) % 4 == 0
     assert [lib.sdpa_dev_dense_ld(d) for d in (1, 32, 33, 64, 65, 100, 128, 129, 256, 257)] == \
-        [4, 32, 64, 64, 128, 128, 128, 256, 256, 260]
+        [4, 32, 64, 64, 128, 128, 128, 256, 256, 264]
+    assert [lib.sdpa_dev_dense_ld(d) for d in (320, 384, 385, 512, 513, 640, 768, 769, 1024, 2100)] == \
+        [324, 384, 388, 512, 516, 648, 768, 776, 1024, 2104]
     assert lib.sdpa_dev_dense_ld(0) == 0
 
 

@@ -506,6 +506,29 @@ def test_f32_dksplit_pipelined_kernel_equals_the_serial_one_bit_for_bit(m, n, dk
     check(res, orc.attention_f64(Q, K, V), V, "dk-split pipelined")
 
 
+@pytest.mark.parametrize("m,n,dk,dv", [(70, 200, 600, 2100),      # 256-wide dv slices want rows of 8 k floats: 2100 is not
+                                        (90, 500, 320, 320),       # 96-wide slices want rows of 12 k: 320 is not
+                                        (64, 300, 700, 700)])      # 192-wide slices want rows of 12 k: 700 is not
+def test_f32_dksplit_kernels_take_any_leading_dimension_the_api_accepts(m, n, dk, dv, pkg, be, orc, O):
+    """the device-level entry point accepts any image leading dimension that is a multiple of 4.  The dk-split
+    kernels' matched dv slices read runs of 3 / 6 / 8 consecutive V columns per lane, which must not straddle a
+    row end: dense_ld() images never do, for any other leading dimension the launch takes the 128-wide slices
+    (runs of 4).  Images built by hand at round4(d) against the images cvt_d2f builds, and the fp64 oracle."""
+    Q, K, V = O.make_inputs(m, n, dk, dv, "D2", seed=dk + dv)
+    want = orc.attention_f64(Q, K, V)
+
+    def image(x, ld):
+        t = torch.zeros((x.shape[0], ld), dtype=torch.float32, device="cuda")
+        t[:, :x.shape[1]] = torch.from_numpy(x).cuda().to(torch.float32)
+        return t
+    r4 = lambda d: (d + 3) // 4 * 4
+    assert r4(dv) != pkg.load().sdpa_dev_dense_ld(dv)
+    for ldq, ldk, ldv in ((r4(dk), r4(dk), r4(dv)), (r4(dk) + 4, r4(dk) + 8, r4(dv) + 4)):
+        contrib, lmax, lsum = be.shard_partial(image(Q, ldq), image(K, ldk), image(V, ldv), dk, dv)
+        check(be.finish_f64(contrib, lsum, dv).cpu().numpy(), want, V, "hand-built images, ld %d / %d / %d" % (ldq, ldk, ldv))
+    check(dev_attention(pkg, be, Q, K, V), want, V, "dense_ld images")
+
+
 def steep_late_rise_inputs(m, n, d, vscale, seed=3, first=32, rise_nats=15.0):
     """Keys [0, first) score `rise_nats` BELOW all the others for every query, and every V entry is
     ~ +vscale: a kernel that defers its accumulator rescale (rise < 2^24) carries weights of e^15

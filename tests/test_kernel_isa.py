@@ -160,7 +160,8 @@ def test_f32_dksplit_kernel_is_one_template_with_both_block_counts(dks, dvs, qb,
     assert c["global_load_lds_dwordx4"] == 0, c
 
 
-@pytest.mark.parametrize("dks,dvs,qb", [(128, 128, 2), (96, 128, 2), (64, 64, 2), (256, 128, 1), (192, 64, 1), (128, 32, 2)])
+@pytest.mark.parametrize("dks,dvs,qb", [(128, 128, 2), (96, 128, 2), (64, 64, 2), (256, 128, 1), (192, 64, 1), (128, 32, 2),
+                                        (96, 96, 2), (192, 192, 1), (256, 256, 1)])      # the dv slices matched to dv = 384 / 768 / 1024
 def test_f32_dksplit_pipelined_kernel_keeps_the_softmax_between_the_pv_mfmas(dks, dvs, qb, dksplit_asm):
     """fused_dksplit_pipe_kernel: the same MFMAs per tile as the serial-phase kernel, nothing spilled, one
     barrier -- and the exchange reads, the row max and the exponentials of the NEXT tile sit between the P.V
@@ -182,7 +183,9 @@ def test_f32_dksplit_pipelined_kernel_keeps_the_softmax_between_the_pv_mfmas(dks
     assert max(gaps) <= -(-50 * qb // slots), gaps       # 50 units per query block to place
     # the partial scores go to the exchange buffer between the first P.V MFMAs, not in front of them
     writes = [i for i, o in enumerate(ops) if o == "ds_write_b128"]
-    assert sum(1 for a, b in zip(mfma_at, mfma_at[1:]) if any(a < w < b for w in writes)) >= min(4 * qb, qb * dvs // 32), writes
+    mps = qb * dvs // 32                                # MFMAs of P.V step 0; ceil(4 qb / mps) stores behind each
+    per_gap = -(-4 * qb // mps)
+    assert sum(1 for a, b in zip(mfma_at, mfma_at[1:]) if any(a < w < b for w in writes)) >= -(-4 * qb // per_gap), writes
 
 
 @pytest.mark.parametrize("dk,dv", [(64, 64), (128, 64), (64, 128)])
