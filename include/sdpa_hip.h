@@ -217,9 +217,11 @@ SDPA_API int sdpa_dev_stream_create(int reserve_cus, void **stream);
 SDPA_API int sdpa_dev_stream_destroy(void *stream);
 
 /* The leading dimension to give the fp32 images of a matrix with d columns (and the contrib rows
- * of a dv-column result): d in (32, 256] padded to 64 / 128 / 256, otherwise d rounded up to 4.
- * Images of those widths run the LDS-DMA pipelined kernels whatever the head dims are; any other
- * ld >= d (multiple of 4, pad columns zero) is accepted and takes the any-shape kernels.        */
+ * of a dv-column result): d in (32, 256] padded to 64 / 128 / 256, d <= 32 rounded up to 4, beyond
+ * 256 to 12 / 4 / 12 / 8 for d <= 384 / 512 / 768 / more (whole lane runs of the dk-split kernels'
+ * matched dv slices; 384, 512, 768, 1024 stay as they are).  Images of those widths run the fastest
+ * kernel for the head dims; any other ld >= d (multiple of 4, pad columns zero) is accepted and
+ * takes the any-shape kernels / the 128-wide dv slices.                                          */
 SDPA_API int sdpa_dev_dense_ld(int d);
 
 /* fp64 -> fp32, round-to-nearest-even; dst[r*ld + c], pad columns zeroed.

@@ -80,7 +80,7 @@ if [ "$1" = "f32b" ]; then
   timeout 300 python bench.py --workload config5 --no-cpu-baseline > $O/bench_config5_f32.json 2>> $O/bench.err
   timeout 300 python bench.py --workload config3 --no-cpu-baseline --no-boundary --steps 5 > $O/bench_config3_one_gpu.json 2>> $O/bench.err
   timeout 300 python tools/gpu_hostlevel.py config5 > $O/hostlevel_config5_f32.log 2>> $O/bench.err
-  timeout 300 python tools/gpu_f32_dims.py 128 256 384 512 2>&1 | grep tflops > $O/f32_head_dims.log
+  timeout 300 python tools/gpu_f32_dims.py 128 256 320 384 512 640 768 1024 2>&1 | grep tflops > $O/f32_head_dims.log
   cat $O/pytest_gpu_final.log; for t in $TAGS; do grep -A4 "== dominant kernel" $O/prof/$t/summary.txt | cut -c1-200; done; cat $O/merge_traffic.log
   for f in n1 config2 d256_f32 config5_f32 config3_one_gpu; do python -c "import json,sys; j=json.load(open('$O/bench_$f.json')); r=j['roofline']; print('$f', round(j['ms_per_step'],4), round(r['kernel_ms_avg'],4), round(r['frac'],4), r['traffic'], r['hbm_gbps'], r['mfma_util'], j.get('parity_max_err'))" 2>&1 | cut -c1-300; done
   cut -c1-300 $O/hostlevel_config5_f32.log; cat $O/f32_head_dims.log; tail -3 $O/bench.err
