@@ -18,8 +18,25 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.dirname(os.path.abspath(__
 os.environ.setdefault("AMD_LOG_LEVEL", "1")
 
 
+def _install_abort_trace():
+    """$SDPA_ABORT_TRACE: compile tests/abort_trace.c and install its SIGABRT handler, which names the native
+    thread that called abort() and prints its backtrace before Python's faulthandler takes over"""
+    import ctypes
+    import subprocess
+    import tempfile
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "abort_trace.c")
+    so = os.path.join(tempfile.mkdtemp(prefix="abort_trace_"), "abort_trace.so")
+    subprocess.check_call(["gcc", "-O1", "-g", "-shared", "-fPIC", "-o", so, src])
+    lib = ctypes.CDLL(so)
+    if lib.abort_trace_install(os.dup(sys.__stderr__.fileno())) != 0:      # the real stderr: fd 2 is captured while a test runs
+        raise RuntimeError("abort_trace_install failed")
+    return lib
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if os.environ.get("SDPA_ABORT_TRACE"):
+        config._sdpa_abort_trace = _install_abort_trace()      # keep the library loaded for the session
 
 
 @pytest.fixture(scope="session")

@@ -119,3 +119,22 @@ def test_clock_prewarm_count_is_a_function_of_the_shape_only():
     assert f(512, 512, 64, "f32", 60.0) == 400             # capped
     assert f(32768, 65536, 512, "bf16", 60.0) == 14
     assert f(32768, 65536, 128, "f32", 0.0) == 0           # --prewarm-ms 0: off
+
+
+def test_abort_trace_names_the_native_thread_that_aborts(tmp_path):
+    """tests/abort_trace.c (loaded by conftest.py under $SDPA_ABORT_TRACE, set by tools/gpu_flaky_hunt.sh): when
+    some native thread of a -m gpu run calls abort(), the log must say WHICH thread and from which module --
+    faulthandler alone shows the Python main thread, wherever it happened to be."""
+    import shutil
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc here")
+    so = str(tmp_path / "abort_trace.so")
+    subprocess.check_call(["gcc", "-O1", "-g", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tests", "abort_trace.c")])
+    code = ("import ctypes, threading\n"
+            "lib = ctypes.CDLL(%r); assert lib.abort_trace_install(2) == 0\n"
+            "libc = ctypes.CDLL(None)\n"
+            "t = threading.Thread(target=lambda: libc.abort(), name='doomed'); t.start(); t.join()\n" % so)
+    r = subprocess.run([sys.executable, "-X", "faulthandler", "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == -6, r
+    assert "SIGABRT raised on thread" in r.stderr and "abort+0x" in r.stderr and "end of native backtrace" in r.stderr, r.stderr
+    assert r.stderr.index("SIGABRT raised") < r.stderr.index("Fatal Python error"), r.stderr      # then faulthandler's dump
