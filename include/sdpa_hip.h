@@ -97,6 +97,16 @@ struct sdpa_timing {
     int    enqueue_threads; /* host threads that enqueued (1 = the calling thread only)          */
     int    host_convert_threads; /* $SDPA_HOST_CVT=1: host threads that converted fp64 -> operand  */
                           /* images (attention-mpi.c:224-225's placement); 0 = the device converts */
+    /* -- fields added in ABI 4 (appended) ---------------------------------------------------- */
+    int    compute_cus;   /* compute units the fused kernels' stream may use (256 - $SDPA_COMM_CUS)  */
+    int    stream_k;      /* 1 = the last fused launch used the stream-K work distribution           */
+    int    host_widen;    /* 1 = fp32 rows came home and host threads widened them to fp64           */
+                          /* (cvt_f2d_avx512's placement, attention-mpi.c:373,:396)                  */
+    int    rccl_selftest; /* 1 = the engine's RCCL collectives passed their known-answer self-test   */
+                          /* on this many ranks at creation (0 = loopback ranks / one rank)          */
+    double merge_us;      /* rank 0, last batch: all-gather/all-reduce + merge kernel (comm stream)  */
+    double reduce_us;     /* rank 0, last batch: reduce / reduce-scatter of the contributions        */
+    double egress_us;     /* rank 0, last batch: widen + D2H of its rows                             */
 };
 
 /* ---- lifecycle ---------------------------------------------------------- */
@@ -121,7 +131,21 @@ SDPA_API int sdpa_init(int n_gpus);
 SDPA_API void sdpa_shutdown(void);
 SDPA_API int sdpa_device_count(void);          /* visible HIP devices, <0 on error */
 SDPA_API const char *sdpa_strerror(int code);
+/* "sdpa-hip <abi> (gfx950, ...; hipcc <version>; src <sha256/16 of the kernel sources>)": the compiler the
+ * hand-scheduled kernels were built with and the sources they were built from travel with the library (the
+ * GPU boxes run a prebuilt .so; tests/test_kernel_isa.py's guarantees hold for that compiler only).        */
 SDPA_API const char *sdpa_version(void);
+/* Bumped whenever a struct of this header changes size or a documented behaviour changes; hosts compare it
+ * with the SDPA_ABI_VERSION they were compiled against (the package's ctypes loader and both C hosts do). */
+#define SDPA_ABI_VERSION 4
+SDPA_API int sdpa_abi_version(void);
+
+/* The launch paths read their environment knobs ($SDPA_STREAMK, $SDPA_SPLIT_MERGE, $SDPA_DKSPLIT_PIPE,
+ * $SDPA_BF16_TANDEM) from ONE snapshot, taken at first use and by every host-level entry point on the
+ * calling thread: the launchers run on the engine's enqueue threads, and the C environment must not be
+ * read there while the application may setenv().  A device-level host that changes one of these knobs
+ * between launches calls this (from the thread that changed it, with no launch in flight elsewhere).      */
+SDPA_API void sdpa_reload_env(void);
 
 /* ---- host level: replaces the body of attention() ------------------------ */
 
@@ -146,6 +170,10 @@ SDPA_API const char *sdpa_version(void);
 SDPA_API int sdpa_attention_f64(const double *Q, const double *K, const double *V,
                                 double *result, int m, int n, int dk, int dv,
                                 int flags);
+/* Copies min(size, sizeof(struct sdpa_timing)) bytes: a caller compiled against an older, shorter struct
+ * passes ITS sizeof and is never written past it (fields are only ever appended).  sdpa_last_timing(out)
+ * is sdpa_last_timing_sized(out, sizeof of THIS header's struct) and is kept for round-2/3 binaries only. */
+SDPA_API int sdpa_last_timing_sized(struct sdpa_timing *out, size_t size);
 SDPA_API int sdpa_last_timing(struct sdpa_timing *out);
 
 /* Optional: size the engine for one problem before the timed call -- allocates every device
@@ -211,8 +239,11 @@ SDPA_API int sdpa_owner_disp(int n, int size, int rank);
  * stream.  Why: a fused launch holds every wave slot of every CU until its last workgroup ends, so a
  * collective (RCCL) or merge kernel that becomes ready while it runs cannot start -- whatever its
  * stream or priority.  A host that wants batch b's reduce to run UNDER batch b+1's fused kernel
- * (attention-mpi.c:364-380) launches the fused kernels on such a stream (the C host: $SDPA_COMM_CUS;
- * bench.py: --reserve-cus).  Opt-in: it costs the fused kernel reserve_cus/256 of the chip.          */
+ * (attention-mpi.c:364-380) launches the fused kernels on such a stream (the C host: $SDPA_COMM_CUS,
+ * default 8 when it drives several ranks; bench.py: --reserve-cus).  It costs the fused kernel
+ * reserve_cus/256 of the chip and no more: sdpa_dev_shard_partial_f32 sizes its stream-K grid by the
+ * compute units of the stream it is given.  The stream is a BLOCKING stream (the mask API has no flags):
+ * it synchronises with the legacy NULL stream, so keep the NULL stream idle beside it.              */
 SDPA_API int sdpa_dev_stream_create(int reserve_cus, void **stream);
 SDPA_API int sdpa_dev_stream_destroy(void *stream);
 
@@ -232,8 +263,10 @@ SDPA_API int sdpa_dev_cvt_d2f(const double *src, float *dst, long rows, int cols
 SDPA_API int sdpa_dev_cvt_f2d(const float *src, int ld, double *dst, long rows,
                               int cols, void *stream);
 
-/* Number of in-GPU K/V splits the fused kernel will use for this shape, and the
- * scratch it needs (0 bytes when the answer is 1 split).                      */
+/* Number of in-GPU K/V splits (slabs of partial triples) the fused kernel uses for this shape on a
+ * stream that owns the whole chip, and the scratch a launch needs on ANY stream -- a CU-masked stream
+ * cuts the work differently (stream-K over its resident workgroup slots) and may use a slab more;
+ * the byte count covers both (0 bytes when the answer is 1 split everywhere).     */
 SDPA_API int    sdpa_dev_kv_splits(int m, int n_local, int dk, int dv);
 SDPA_API size_t sdpa_dev_workspace_bytes(int m, int n_local, int dk, int dv);
 

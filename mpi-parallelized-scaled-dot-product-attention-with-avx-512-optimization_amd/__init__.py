@@ -10,10 +10,10 @@ The directory name contains hyphens (it is the name the task prescribes), so imp
     importlib.import_module("mpi-parallelized-scaled-dot-product-attention-with-avx-512-optimization_amd")
 """
 from . import _lib
-from ._lib import SdpaError, header_symbols, load
+from ._lib import SdpaError, header_symbols, load, reload_env
 from .engine import (DEFAULT_Q_BATCH, HipBackend, ShardedAttention, attention, attention_mpi, attention_qrows, init,
                      last_timing, owner_count, owner_disp, plan, round4, shutdown)
 
-__all__ = ["SdpaError", "header_symbols", "load", "HipBackend", "ShardedAttention", "attention",
+__all__ = ["SdpaError", "header_symbols", "load", "reload_env", "HipBackend", "ShardedAttention", "attention",
            "attention_mpi", "attention_qrows", "init", "last_timing", "owner_count", "owner_disp", "plan", "round4", "shutdown",
            "DEFAULT_Q_BATCH", "_lib"]

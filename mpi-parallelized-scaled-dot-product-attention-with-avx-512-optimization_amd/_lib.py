@@ -30,7 +30,13 @@ class SdpaTiming(ctypes.Structure):
                 ("kv_chunks", _c_int), ("fused_launches", _c_int), ("plan", _c_int), ("merge", _c_int),
                 ("virtual_ranks", _c_int),
                 ("enqueue_total_us", ctypes.c_double), ("enqueue_first_kernel_us", ctypes.c_double * 16),
-                ("egress", _c_int), ("enqueue_threads", _c_int), ("host_convert_threads", _c_int)]
+                ("egress", _c_int), ("enqueue_threads", _c_int), ("host_convert_threads", _c_int),
+                # ABI 4
+                ("compute_cus", _c_int), ("stream_k", _c_int), ("host_widen", _c_int), ("rccl_selftest", _c_int),
+                ("merge_us", ctypes.c_double), ("reduce_us", ctypes.c_double), ("egress_us", ctypes.c_double)]
+
+
+SDPA_ABI_VERSION = 4          # the SDPA_ABI_VERSION of include/sdpa_hip.h this binding was written against
 
 
 class SdpaError(RuntimeError):
@@ -47,6 +53,9 @@ _PROTOS = {
     "sdpa_version": (ctypes.c_char_p, []),
     "sdpa_attention_f64": (_c_int, [_c_void_p] * 4 + [_c_int] * 5),
     "sdpa_last_timing": (_c_int, [ctypes.POINTER(SdpaTiming)]),
+    "sdpa_last_timing_sized": (_c_int, [ctypes.POINTER(SdpaTiming), ctypes.c_size_t]),
+    "sdpa_abi_version": (_c_int, []),
+    "sdpa_reload_env": (None, []),
     "sdpa_prepare": (_c_int, [_c_int] * 5),
     "sdpa_plan_describe": (_c_int, [_c_int] * 6 + [ctypes.c_char_p, ctypes.c_size_t]),
     "sdpa_kv_prefetch": (_c_int, [_c_void_p, _c_void_p] + [_c_int] * 7),
@@ -115,8 +124,19 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    if not os.environ.get("SDPA_HIP_LIB"):
+        got = lib.sdpa_abi_version()
+        if got != SDPA_ABI_VERSION:      # a stale build: caller-allocated structs would not match
+            raise ImportError("%s reports ABI %d, this binding needs %d: rebuild it (make -C %s)"
+                              % (LIB_PATH, got, SDPA_ABI_VERSION, os.path.join(PKG_DIR, "csrc")))
     _lib = lib
     return lib
+
+
+def reload_env():
+    """sdpa_reload_env(): the launch paths read their $SDPA_* knobs from one snapshot; a device-level
+    host that changes one between launches re-takes it (include/sdpa_hip.h)."""
+    load().sdpa_reload_env()
 
 
 def strerror(code):

@@ -10,6 +10,90 @@
 #include "sdpa_internal.h"
 
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+#include <mutex>
+#include <utility>
+#include <vector>
+
+namespace sdpa {
+
+// ---- CU budget of the streams this library created with a CU mask ---------------------------------------------
+namespace {
+std::mutex &cus_mu() { static std::mutex *m = new std::mutex; return *m; }
+std::vector<std::pair<hipStream_t, int>> &cus_tab() { static auto *t = new std::vector<std::pair<hipStream_t, int>>; return *t; }
+std::atomic<int> dev_cus[64];
+}  // namespace
+
+void register_stream_cus(hipStream_t s, int cus) {
+    std::lock_guard<std::mutex> lk(cus_mu());
+    for (auto &e : cus_tab())
+        if (e.first == s) { e.second = cus; return; }
+    cus_tab().push_back({s, cus});
+}
+
+void forget_stream_cus(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(cus_mu());
+    auto &t = cus_tab();
+    for (size_t i = 0; i < t.size(); ++i)
+        if (t[i].first == s) { t[i] = t.back(); t.pop_back(); return; }
+}
+
+int stream_cus(hipStream_t s) {
+    {
+        std::lock_guard<std::mutex> lk(cus_mu());
+        for (auto &e : cus_tab())
+            if (e.first == s) return e.second;
+    }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return kChipCus; }
+    int c = dev_cus[dev].load(std::memory_order_relaxed);
+    if (c <= 0) {
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) {
+            (void)hipGetLastError();
+            c = kChipCus;
+        }
+        dev_cus[dev].store(c, std::memory_order_relaxed);
+    }
+    return c;
+}
+
+// ---- launch-path knobs: one immutable snapshot of the environment -------------------------------------------
+namespace {
+std::atomic<const LaunchKnobs *> knobs_now{nullptr};
+const LaunchKnobs *read_knobs() {
+    LaunchKnobs *k = new LaunchKnobs;      // (snapshots are never freed: a launcher on another thread may still hold one)
+    const char *v = getenv("SDPA_SPLIT_MERGE");
+    k->split_merge_kernel = (v && strcmp(v, "kernel") == 0) ? 1 : 0;
+    v = getenv("SDPA_DKSPLIT_PIPE");
+    k->dksplit_pipe = !(v && *v) || atoi(v) != 0;
+    v = getenv("SDPA_BF16_TANDEM");
+    k->bf16_tandem = !(v && *v) || atoi(v) != 0;
+    v = getenv("SDPA_STREAMK");
+    k->streamk = (!(v && *v) || strcmp(v, "auto") == 0) ? -1 : (atoi(v) != 0 ? 1 : 0);
+    return k;
+}
+}  // namespace
+
+const LaunchKnobs &launch_knobs() {
+    const LaunchKnobs *k = knobs_now.load(std::memory_order_acquire);
+    if (!k) {
+        static std::mutex *mu = new std::mutex;
+        std::lock_guard<std::mutex> lk(*mu);
+        k = knobs_now.load(std::memory_order_acquire);
+        if (!k) {
+            k = read_knobs();
+            knobs_now.store(k, std::memory_order_release);
+        }
+    }
+    return *k;
+}
+
+void reload_launch_knobs() { knobs_now.store(read_knobs(), std::memory_order_release); }
+
+}  // namespace sdpa
 
 namespace {
 
@@ -25,7 +109,13 @@ bool misaligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) 
 
 extern "C" {
 
-const char *sdpa_version(void) { return "sdpa-hip 0.2 (gfx950, f32 + bf16 MFMA)"; }
+#ifndef SDPA_BUILD_STAMP
+#define SDPA_BUILD_STAMP "hipcc unknown; src unknown"
+#endif
+const char *sdpa_version(void) { return "sdpa-hip 0.4 abi 4 (gfx950, f32 + bf16 MFMA; " SDPA_BUILD_STAMP ")"; }
+int sdpa_abi_version(void) { return SDPA_ABI_VERSION; }
+
+void sdpa_reload_env(void) { sdpa::reload_launch_knobs(); }
 
 const char *sdpa_strerror(int code) {
     switch (code) {
@@ -110,9 +200,17 @@ int sdpa_dev_shard_partial_f32(const float *Qf, int ldq, const float *Kf, int ld
     a.Q = Qf; a.ldq = ldq; a.K = Kf; a.ldk = ldk; a.V = Vf; a.ldv = ldv;
     a.contrib = contrib; a.ldo = ldo; a.lmax = lmax; a.lsum = lsum;
     a.m = m; a.n_local = n_local; a.dk = dk; a.dv = dv;
-    a.kv_splits = sdpa::pick_kv_splits(m, n_local, dk, dv);
+    // the split count belongs to the STREAM: a CU-masked one has fewer resident workgroup slots, and the
+    // stream-K cuts (sdpa_internal.h) follow them.  sdpa_dev_workspace_bytes() covers either.
+    a.kv_splits = sdpa::pick_kv_splits(m, n_local, dk, dv, sdpa::stream_cus((hipStream_t)stream));
+    if (a.kv_splits > 1 && workspace && workspace_bytes < sdpa::workspace_bytes_for(m, dv, a.kv_splits) &&
+        workspace_bytes >= sdpa::workspace_bytes(m, n_local, dk, dv)) {
+        // a masked stream with stream-K switched off wants more equal splits than the documented scratch
+        // holds: any smaller count is as correct (only less evenly spread), so take what fits
+        while (a.kv_splits > 1 && workspace_bytes < sdpa::workspace_bytes_for(m, dv, a.kv_splits)) --a.kv_splits;
+    }
     if (a.kv_splits > 1) {
-        if (!workspace || workspace_bytes < sdpa::workspace_bytes(m, n_local, dk, dv)) return SDPA_EINVAL;
+        if (!workspace || workspace_bytes < sdpa::workspace_bytes_for(m, dv, a.kv_splits)) return SDPA_EINVAL;
         if (misaligned16(workspace)) return SDPA_EINVAL;
         sdpa::carve_workspace(a, workspace, sdpa::dense_ld(dv));
     }
@@ -140,6 +238,7 @@ int sdpa_dev_stream_create(int reserve_cus, void **stream) {
 
 int sdpa_dev_stream_destroy(void *stream) {
     if (!stream) return SDPA_EINVAL;
+    sdpa::forget_stream_cus((hipStream_t)stream);
     HIP_TRY(hipStreamDestroy((hipStream_t)stream));
     return SDPA_OK;
 }

@@ -1849,7 +1849,7 @@ static hipError_t launch_bf16_pipe(const Bf16Args &a, hipStream_t s) {
     const int tiles_per_split = (ntiles + a.kv_splits - 1) / a.kv_splits;
     const int kv_per_split = tiles_per_split > 0 ? tiles_per_split * kKvTile : kKvTile;
     const size_t lds = (size_t)2 * (kKvTile * DK + DVC * 36) * sizeof(unsigned short);
-    static bool attr_done[64] = {};
+    static std::atomic<bool> attr_done[64];   // (zero-initialised; set from any enqueue thread)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!attr_done[dev]) {
@@ -1872,7 +1872,7 @@ static hipError_t launch_bf16_wide(const Bf16Args &a, hipStream_t s) {
     const int tiles_per_split = (ntiles + a.kv_splits - 1) / a.kv_splits;
     const int kv_per_split = tiles_per_split > 0 ? tiles_per_split * kKvTile : kKvTile;
     const size_t lds = ((size_t)3 * kKvTile * DK + (size_t)2 * 512 * kKvTile) * sizeof(unsigned short);
-    static bool attr_done[64] = {};
+    static std::atomic<bool> attr_done[64];   // (zero-initialised; set from any enqueue thread)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!attr_done[dev]) {
@@ -1895,7 +1895,7 @@ static hipError_t launch_bf16_tandem(const Bf16Args &a, hipStream_t s) {
     const int tiles_per_split = (ntiles + a.kv_splits - 1) / a.kv_splits;
     const int kv_per_split = tiles_per_split > 0 ? tiles_per_split * kKvTile : kKvTile;
     const size_t lds = ((size_t)2 * kKvTile * DK + (size_t)2 * 512 * kKvTile) * sizeof(unsigned short) + 16384;
-    static bool attr_done[64] = {};
+    static std::atomic<bool> attr_done[64];   // (zero-initialised; set from any enqueue thread)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!attr_done[dev]) {
@@ -1910,11 +1910,9 @@ static hipError_t launch_bf16_tandem(const Bf16Args &a, hipStream_t s) {
 }
 
 // dv > 256: the tandem kernel (two waves share 64 rows and split the columns; the default since round 3), or
-// the wide kernel it was derived from -- both exact, bit-identical to each other ($SDPA_BF16_TANDEM=0/1, read
-// per launch: A/B timing)
-static bool bf16_uses_tandem() {
-    const char *v = getenv("SDPA_BF16_TANDEM");
-    return v ? atoi(v) != 0 : SDPA_BF16_TANDEM_DEFAULT != 0;
+// the wide kernel it was derived from -- both exact, bit-identical to each other ($SDPA_BF16_TANDEM=0/1, A/B timing)
+static bool bf16_uses_tandem() {       // (from the launch-knob snapshot: no getenv on an enqueue thread)
+    return SDPA_BF16_TANDEM_DEFAULT != 0 ? launch_knobs().bf16_tandem != 0 : false;
 }
 
 template <int DK, int DV>
@@ -1925,7 +1923,7 @@ static hipError_t launch_bf16_duo(const Bf16Args &a, hipStream_t s) {
     const int tiles_per_split = (ntiles + a.kv_splits - 1) / a.kv_splits;
     const int kv_per_split = tiles_per_split > 0 ? tiles_per_split * kKvTile : kKvTile;
     const size_t lds = DuoCfg<DK, DV>::lds_bytes;
-    static bool attr_done[64] = {};
+    static std::atomic<bool> attr_done[64];   // (zero-initialised; set from any enqueue thread)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!attr_done[dev]) {

@@ -333,9 +333,21 @@ __global__ __launch_bounds__(256, (DKP > 128) ? 1 : 2) void fused_partial_kernel
 //   1 = no DMA / no barrier in the steady state, 2 = no LDS fragment reads, 4 = no softmax VALU
 // MERGE: 1 = the launch merges its K/V splits itself (arrival words, $SDPA_SPLIT_MERGE=kernel); the shipped
 // default instantiation carries none of that code
-template <int DK, int DV, int ABL = 0, int MERGE = 0>
+// SK: 1 = stream-K work distribution (round 4).  The launch's n_qblocks x ntiles tile steps (query block
+// major) are cut into gridDim.x equal runs of `kv_per_split` steps, one per workgroup = one per RESIDENT
+// workgroup slot of the stream's compute units; a workgroup walks its run piece by piece (a piece = the part
+// of one query block's K/V range inside the run) and writes each piece's partial triple into slab
+// (workgroup - first workgroup of that query block) of the split scratch.  Every workgroup then does the
+// same number of tile steps whatever m, n and the number of compute units are -- a CU mask that leaves
+// room for RCCL's kernels, an odd m or a short shard no longer break "the grid is exactly one round".
+// Slabs a query block does not use are filled with the empty triple (0, -inf, 0) by its last piece, so
+// that the merge passes (split_merge_kernel, the hosts' slot merge) stay what they are.  When the cuts
+// coincide with the classic equal splits the pieces, their slabs and therefore the results are the same
+// bit for bit.
+template <int DK, int DV, int ABL = 0, int MERGE = 0, int SK = 0>
 __global__ __launch_bounds__(256, (DK + DV > 256) ? 1 : 2) void fused_pipelined_kernel(PartialArgs a, int kv_per_split,
                                                                                        int n_qblocks, float scale) {
+    static_assert(!(SK && MERGE), "the in-kernel split merge counts equal splits");
     constexpr int NU = DK / 8;                // 16-byte K reads per tile per lane
     constexpr int PPU = NU <= 16 ? 16 / NU : 1;   // P values finished per 4-MFMA QK^T step ...
     constexpr int PEV = NU <= 16 ? 1 : NU / 16;   // ... of every PEV-th step (dk = 256: every other one)
@@ -368,13 +380,25 @@ __global__ __launch_bounds__(256, (DK + DV > 256) ? 1 : 2) void fused_pipelined_
     const int hi = lane >> 5;
 
     const int work = xcd_remap(blockIdx.x, gridDim.x);
-    const int split = work / n_qblocks;
-    const int qblock = work - split * n_qblocks;
-    const int qrow = qblock * kQRowsPerBlock + wave * 32 + li;
-
-    const int kv_begin = split * kv_per_split;
-    const int kv_end = min(a.n_local, kv_begin + kv_per_split);
-    const int T = kv_end > kv_begin ? (kv_end - kv_begin + kKvTile - 1) / kKvTile : 0;
+    // the piece of work in hand: query block, K/V range, slab.  Classic: fixed for the launch.  SK: one per
+    // trip of the piece loop below (sk_pos .. sk_end = this workgroup's run of tile steps)
+    int split, qblock, qrow, kv_begin, kv_end, T;
+    int sk_pos = 0, sk_end = 0, sk_ntiles = 1;
+    if constexpr (SK) {
+        sk_ntiles = (a.n_local + kKvTile - 1) / kKvTile;
+        const int total = n_qblocks * sk_ntiles;              // < 2^31: the launcher checks
+        sk_pos = min(total, work * kv_per_split);             // kv_per_split = tile steps per workgroup here
+        sk_end = min(total, sk_pos + kv_per_split);
+        if (sk_pos >= sk_end) return;
+        split = 0; qblock = 0; qrow = 0; kv_begin = 0; kv_end = 0; T = 0;
+    } else {
+        split = work / n_qblocks;
+        qblock = work - split * n_qblocks;
+        qrow = qblock * kQRowsPerBlock + wave * 32 + li;
+        kv_begin = split * kv_per_split;
+        kv_end = min(a.n_local, kv_begin + kv_per_split);
+        T = kv_end > kv_begin ? (kv_end - kv_begin + kKvTile - 1) / kKvTile : 0;
+    }
     const float c = scale * 1.44269504088896340736f;
 
     // Q is pre-multiplied by scale*log2(e): the MFMA chain then yields scores directly in the
@@ -382,12 +406,15 @@ __global__ __launch_bounds__(256, (DK + DV > 256) ? 1 : 2) void fused_pipelined_
     // P value costs ONE VALU instruction (v_exp_f32).  VALU cycles are MFMA cycles lost here: the
     // f32-input MFMA runs at the f32 vector rate and does not overlap VALU issue.
     float4 qf[NU];
+    auto load_q = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        qf[u] = qrow < a.m ? *reinterpret_cast<const float4 *>(a.Q + (size_t)qrow * DK + 8 * u + 4 * hi)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
-        qf[u].x *= c; qf[u].y *= c; qf[u].z *= c; qf[u].w *= c;
-    }
+        for (int u = 0; u < NU; ++u) {
+            qf[u] = qrow < a.m ? *reinterpret_cast<const float4 *>(a.Q + (size_t)qrow * DK + 8 * u + 4 * hi)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+            qf[u].x *= c; qf[u].y *= c; qf[u].z *= c; qf[u].w *= c;
+        }
+    };
+    if constexpr (!SK) load_q();
 
     f32x16 oacc[NT];
     // Softmax state of this lane's query row, all in the exp2 domain:
@@ -763,6 +790,20 @@ __global__ __launch_bounds__(256, (DK + DV > 256) ? 1 : 2) void fused_pipelined_
     //  loop is instruction for instruction the loop of the kernel without a second pass -- hipcc's
     //  allocation of these full-register-file kernels shifts with any liveness change around the loop;
     //  tests/test_kernel_isa.py holds it in place)
+    do {                                      // SK: one trip per piece of this workgroup's run; otherwise one trip
+    if constexpr (SK) {
+        // (integer division runs on the VALU: readfirstlane tells hipcc the quotients are wave-uniform -- the
+        //  DMA's base address must sit in SGPRs, and a "divergent" one costs a waterfall loop per piece)
+        qblock = __builtin_amdgcn_readfirstlane(sk_pos / sk_ntiles);
+        const int t0 = sk_pos - qblock * sk_ntiles;
+        const int t1 = min(sk_ntiles, t0 + (sk_end - sk_pos));
+        split = work - __builtin_amdgcn_readfirstlane((qblock * sk_ntiles) / kv_per_split);   // pieces of this query block before this one
+        qrow = qblock * kQRowsPerBlock + wave * 32 + li;
+        kv_begin = t0 * kKvTile;
+        kv_end = min(a.n_local, t1 * kKvTile);
+        T = t1 - t0;
+        load_q();
+    }
     run_pass();
 #if SDPA_RANGE_REDO
     {   // range check of the deferred-rescale pass (see `defer` above).  The LDS tiles are dead here:
@@ -785,7 +826,22 @@ __global__ __launch_bounds__(256, (DK + DV > 256) ? 1 : 2) void fused_pipelined_
     }
 #endif
     store_mine();
-    if (a.kv_splits <= 1) return;
+    if constexpr (SK) {
+        if (kv_begin + T * kKvTile >= sk_ntiles * kKvTile) {
+            // the last piece of its query block: the slabs this block does not use get the empty triple
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[tt][r] = 0.f;
+            for (int sp = split + 1; sp < a.kv_splits; ++sp)
+                store_rows(a.ws_contrib + (size_t)sp * a.ws_rows * a.ws_ld, a.ws_ld, a.ws_lmax + (size_t)sp * a.ws_rows,
+                           a.ws_lsum + (size_t)sp * a.ws_rows, oacc, -INFINITY, 0.f);
+        }
+        sk_pos += T;
+        if (sk_pos < sk_end) __syncthreads();  // the range-check votes are read before the next piece's first DMA lands on them
+    }
+    } while (SK && sk_pos < sk_end);
+    if (SK || a.kv_splits <= 1) return;
     if constexpr (!MERGE) {
         return;                               // the slots are merged by a later pass (split_merge_kernel)
     } else {
@@ -976,9 +1032,23 @@ static inline bool uses_dksplit(int dk, int dv) {
     return dk <= kMaxDkSplit && (dk > kMaxMfmaDk || (dk > kMaxFastDim && dv > kMaxFastDim));
 }
 
-int pick_kv_splits(int m, int n_local, int dk, int dv) {
-    if (dk > kMaxDkSplit) return 1;              // VALU-only fallback kernel: no splits
-    if (m <= 0 || n_local <= 0) return 1;
+// dense head dims whose operand images run fused_pipelined_kernel (launch_shard_partial below): both in
+// (32, 128], or one in (128, 256] with the other in (64, 256]
+static inline bool pipelined_dims(int dk, int dv) {
+    if (dk <= 32 || dv <= 32 || dk > 256 || dv > 256) return false;
+    const int kp = dense_ld(dk), vp = dense_ld(dv);
+    return !(kp == 256 && vp == 64) && !(kp == 64 && vp == 256);
+}
+// ... and of those the ones with a stream-K instantiation: dk <= 128.  The 256-wide-dk kernels hold a 128-register
+// Q fragment beside the full accumulator file; the piece loop's few extra live values make hipcc spill inside
+// their steady-state loop (tests/test_kernel_isa.py), so they keep the classic grid.
+static inline bool streamk_dims(int dk, int dv) { return pipelined_dims(dk, dv) && dk <= kMaxFastDim; }
+
+F32Plan plan_f32_launch(int m, int n_local, int dk, int dv, int cus) {
+    F32Plan p = {1, 0, 0, 0};
+    if (dk > kMaxDkSplit) return p;              // VALU-only fallback kernel: no splits
+    if (m <= 0 || n_local <= 0) return p;
+    if (cus <= 0) cus = kChipCus;
     const int ntiles = (n_local + kKvTile - 1) / kKvTile;
     int cap = ntiles / 4;                        // >= 4 tiles a split
     if (cap < 1) cap = 1;
@@ -990,13 +1060,14 @@ int pick_kv_splits(int m, int n_local, int dk, int dv) {
     double rate;
     if (uses_dksplit(dk, dv) && !wide256) {      // 64-row workgroups (32 at dk > 512), one per CU
         blocks = (long)((m + dksplit_rows(dk) - 1) / dksplit_rows(dk)) * dksplit_chunks(dk, dv);
-        slots = 256;
+        slots = cus;
         rate = 1.0e14;
     } else {
         blocks = (long)((m + kQRowsPerBlock - 1) / kQRowsPerBlock) * (wide256 ? 1 : dv_chunks(dv));
-        slots = (dk > kMaxFastDim || wide256) ? 256 : 512;   // 2 resident workgroups per CU, 1 beyond 128-wide operands
-        rate = slots == 512 ? 1.4e14 : 1.3e14;
+        slots = (dk > kMaxFastDim || wide256) ? cus : 2 * cus;   // 2 resident workgroups per CU, 1 beyond 128-wide operands
+        rate = slots == 2 * cus ? 1.4e14 : 1.3e14;
     }
+    rate *= (double)cus / kChipCus;
     int want = (int)((slots + blocks - 1) / blocks);
     if (want > cap) want = cap;
     if (want > 64) want = 64;
@@ -1004,15 +1075,52 @@ int pick_kv_splits(int m, int n_local, int dk, int dv) {
     // more than one round of workgroups: a fuller last round (sdpa_internal.h)
     const double kernel_s = 2.0 * m * (double)n_local * (dk + dv) / rate;
     const double slab_s = 2.0 * m * (double)dense_ld(dv) * sizeof(float) / 3.0e12;
-    return splits_for_full_rounds(blocks, slots, want, cap, kernel_s, slab_s);
+    p.splits = splits_for_full_rounds(blocks, slots, want, cap, kernel_s, slab_s);
+
+    // ---- stream-K instead?  (pipelined kernels only; $SDPA_STREAMK = 0 / 1 / auto)
+    const int knob = launch_knobs().streamk;
+    if (knob == 0 || !streamk_dims(dk, dv)) return p;
+    const long total = blocks * ntiles;          // tile steps of the launch (blocks = query blocks here)
+    if (total >= (1L << 31) - 4096 || blocks > 65536) return p;
+    int workers = (int)std::min<long>(slots, std::max<long>(1, total / 4));
+    int run = (int)((total + workers - 1) / workers);
+    run = std::max(run, (ntiles + 61) / 62);     // at most 64 pieces (slabs) per query block, as the classic splits
+    workers = (int)((total + run - 1) / run);
+    int pieces = 1;                              // the most pieces a query block is cut into
+    for (long q = 0; q < blocks; ++q) {
+        const int first = (int)(q * ntiles / run), last = (int)(((q + 1) * ntiles - 1) / run);
+        pieces = std::max(pieces, last - first + 1);
+    }
+    // cost in tile steps per workgroup slot (+3: a piece's prologue and epilogue, a worker has at most
+    // run / ntiles + 2 pieces), then the slabs the merge reads back
+    const double step_s = kernel_s * slots / (double)total;
+    const long wg = blocks * p.splits, rounds = (wg + slots - 1) / slots;
+    const double t_classic = rounds * ((ntiles + p.splits - 1) / p.splits) * step_s + (p.splits > 1 ? p.splits * slab_s : 0.0);
+    const double t_sk = (run + 3.0 * (run / ntiles + 1)) * step_s + (pieces > 1 ? pieces * slab_s : 0.0);
+    if (knob == 1 || t_sk < t_classic) {
+        p.splits = pieces;
+        p.streamk = 1;
+        p.workers = workers;
+        p.run = run;
+    }
+    return p;
 }
 
-size_t workspace_bytes(int m, int n_local, int dk, int dv) {
-    const int s = pick_kv_splits(m, n_local, dk, dv);
-    if (s <= 1) return 0;
+int pick_kv_splits(int m, int n_local, int dk, int dv, int cus) { return plan_f32_launch(m, n_local, dk, dv, cus).splits; }
+
+size_t workspace_bytes_for(int m, int dv, int splits) {
+    if (splits <= 1) return 0;
     const size_t ws_ld = (size_t)dense_ld(dv);         // the padded kernels write whole 64/128/256-column rows
     const size_t tickets = (size_t)((m + kQRowsPerBlock - 1) / kQRowsPerBlock) * sizeof(unsigned long long);
-    return (size_t)s * (size_t)m * (ws_ld + 2) * sizeof(float) + tickets;
+    return (size_t)splits * (size_t)m * (ws_ld + 2) * sizeof(float) + tickets;
+}
+
+// Scratch for the launch on ANY stream: the most slabs the plan asks for over the whole chip and every CU mask
+// create_masked_stream() can produce (8, 16, ... CUs left out, up to half the chip).
+size_t workspace_bytes(int m, int n_local, int dk, int dv) {
+    int s = 1;
+    for (int cus = kChipCus; cus >= kChipCus / 2; cus -= 8) s = std::max(s, pick_kv_splits(m, n_local, dk, dv, cus));
+    return workspace_bytes_for(m, dv, s);
 }
 
 void carve_workspace(PartialArgs &a, void *ws, int ws_ld) {
@@ -1051,15 +1159,15 @@ static hipError_t launch_fast(const PartialArgs &a, hipStream_t s) {
     const int kv_per_split = tiles_per_split > 0 ? tiles_per_split * kKvTile : kKvTile;
     const int chunks = dv_chunks(a.dv);
     const size_t lds = (size_t)2 * kKvTile * ((DKP + 4) + DVP) * sizeof(float);
-    static bool attr_done[64] = {};
+    static std::atomic<bool> attr_done[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!attr_done[dev]) {
+    if (!attr_done[dev].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(
             reinterpret_cast<const void *>(&fused_partial_kernel<DKP, DVP>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_done[dev] = true;
+        attr_done[dev].store(true, std::memory_order_release);
     }
     const float scale = 1.0f / sqrtf((float)a.dk);   // attention-mpi.c:208
     hipLaunchKernelGGL((fused_partial_kernel<DKP, DVP>), dim3(nqb * chunks * a.kv_splits), dim3(256), lds,
@@ -1070,6 +1178,19 @@ static hipError_t launch_fast(const PartialArgs &a, hipStream_t s) {
     return e;
 }
 
+// per-device "dynamic LDS size raised" flags of one kernel instantiation (set from any enqueue thread)
+struct AttrOnce {
+    std::atomic<bool> done[64];
+    AttrOnce() { for (auto &d : done) d.store(false); }
+    template <typename K> hipError_t ensure(K kernel, int dev, size_t lds) {
+        if (done[dev].load(std::memory_order_acquire)) return hipSuccess;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) done[dev].store(true, std::memory_order_release);
+        return e;
+    }
+};
+
 template <int DK, int DV, int ABL = 0>
 static hipError_t launch_pipelined(const PartialArgs &a, hipStream_t s) {
     const int nqb = (a.m + kQRowsPerBlock - 1) / kQRowsPerBlock;
@@ -1077,44 +1198,47 @@ static hipError_t launch_pipelined(const PartialArgs &a, hipStream_t s) {
     const int tiles_per_split = (ntiles + a.kv_splits - 1) / a.kv_splits;
     const int kv_per_split = tiles_per_split > 0 ? tiles_per_split * kKvTile : kKvTile;
     const size_t lds = (size_t)2 * kKvTile * (DK + DV) * sizeof(float);
-    static bool attr_done[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&fused_pipelined_kernel<DK, DV, ABL>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done[dev] = true;
-    }
     const float scale = 1.0f / sqrtf((float)a.dk);   // attention-mpi.c:208
     // kv_splits > 1: the partial triples are merged by split_merge_kernel right behind.  The kernel can
-    // also merge them itself ($SDPA_SPLIT_MERGE=kernel, read per launch: the last workgroup of a query
+    // also merge them itself ($SDPA_SPLIT_MERGE=kernel: the last workgroup of a query
     // block to arrive does it, one launch per step) -- same sums in the same order, bit for bit
     // (tests/test_gpu_parity.py) -- but measured SLOWER on MI355X (profiles/r03/split_merge_forms_ab.log:
     // config 2 0.301 vs 0.273 ms per step, a 1/8 rank share 1.013 vs 0.993): the separate pass spreads
     // the 34 MB of slab reads over every CU, the last arrivers are 64 workgroups in a latency-bound tail.
     PartialArgs k = a;
-    const char *form = getenv("SDPA_SPLIT_MERGE");
     if (k.kv_splits <= 1 || k.defer_merge || (reinterpret_cast<uintptr_t>(k.tickets) & 7) != 0 ||
-        !(form && strcmp(form, "kernel") == 0))
+        !launch_knobs().split_merge_kernel)
         k.tickets = nullptr;
-    if (k.tickets) {
-        k.ticket_tag = next_ticket_tag();
-        static bool attr_merge[64] = {};
-        if (!attr_merge[dev]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_pipelined_kernel<DK, DV, ABL, 1>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            attr_merge[dev] = true;
+    hipError_t e;
+    // stream-K (sdpa_internal.h: F32Plan): the plan for THIS stream's compute units; taken when the caller gave
+    // the launch at least the slabs it needs (callers size a.kv_splits with the same function)
+    const F32Plan plan = ABL || k.tickets ? F32Plan{1, 0, 0, 0} : plan_f32_launch(a.m, a.n_local, a.dk, a.dv, stream_cus(s));
+    bool launched = false;
+    if constexpr (DK <= kMaxFastDim) {
+        if (plan.streamk && plan.splits <= a.kv_splits && (a.kv_splits <= 1 || a.ws_contrib)) {
+            static AttrOnce attr;
+            if ((e = attr.ensure(&fused_pipelined_kernel<DK, DV, 0, 0, 1>, dev, lds)) != hipSuccess) return e;
+            hipLaunchKernelGGL((fused_pipelined_kernel<DK, DV, 0, 0, 1>), dim3(plan.workers), dim3(256), lds, s, k,
+                               plan.run, nqb, scale);
+            launched = true;
         }
+    }
+    if (launched) {
+    } else if (k.tickets) {
+        k.ticket_tag = next_ticket_tag();
+        static AttrOnce attr;
+        if ((e = attr.ensure(&fused_pipelined_kernel<DK, DV, ABL, 1>, dev, lds)) != hipSuccess) return e;
         hipLaunchKernelGGL((fused_pipelined_kernel<DK, DV, ABL, 1>), dim3(nqb * k.kv_splits), dim3(256), lds, s,
                            k, kv_per_split, nqb, scale);
     } else {
+        static AttrOnce attr;
+        if ((e = attr.ensure(&fused_pipelined_kernel<DK, DV, ABL, 0>, dev, lds)) != hipSuccess) return e;
         hipLaunchKernelGGL((fused_pipelined_kernel<DK, DV, ABL, 0>), dim3(nqb * k.kv_splits), dim3(256), lds, s,
                            k, kv_per_split, nqb, scale);
     }
-    hipError_t e = hipGetLastError();
+    e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (k.kv_splits > 1 && !k.defer_merge && !k.tickets) e = launch_split_merge(k, s);
     return e;

@@ -5,6 +5,7 @@
 #include "sdpa_f32_device.h"
 
 #include <math.h>
+#include <atomic>
 #include <stdlib.h>
 #include <algorithm>
 #include <type_traits>
@@ -661,9 +662,8 @@ int dksplit_rows(int dk) { return dk > 512 ? 32 : 64; }      // query rows per w
 #ifndef SDPA_DKSPLIT_PIPE_DEFAULT
 #define SDPA_DKSPLIT_PIPE_DEFAULT 1
 #endif
-static bool dksplit_pipelined() {
-    const char *e = getenv("SDPA_DKSPLIT_PIPE");
-    return e && *e ? atoi(e) != 0 : SDPA_DKSPLIT_PIPE_DEFAULT != 0;
+static bool dksplit_pipelined() {       // (the knob comes from the launch-knob snapshot: no getenv on an enqueue thread)
+    return SDPA_DKSPLIT_PIPE_DEFAULT != 0 ? launch_knobs().dksplit_pipe != 0 : false;
 }
 
 template <int DKS, int DVS, int QB>
@@ -674,7 +674,7 @@ static hipError_t launch_one(const PartialArgs &a, hipStream_t s) {
     const int kv_per_split = tiles_per_split > 0 ? tiles_per_split * kKvTile : kKvTile;
     const int chunks = (a.dv + 4 * DVS - 1) / (4 * DVS);
     const size_t lds = (size_t)2 * 4 * QB * 64 * 20 * sizeof(float);
-    static bool attr_done[64] = {};
+    static std::atomic<bool> attr_done[64];   // (zero-initialised; set from any enqueue thread)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!attr_done[dev]) {

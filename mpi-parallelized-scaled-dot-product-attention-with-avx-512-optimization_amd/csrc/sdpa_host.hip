@@ -169,6 +169,7 @@ struct Engine {
     Collectives *coll = nullptr;
     Pool pool;                           // enqueue threads, one per rank (empty with one rank)
     sdpa::HostConverter *hc = nullptr;   // $SDPA_HOST_CVT=1: fp64 -> operand images on host threads (sdpa_hostcvt.h)
+    int run_cus = 0;                     // compute units of a rank's compute stream (create_rank)
     sdpa_timing last = {};
 };
 // Heap-allocated and never destroyed on purpose: at process exit the order in which this library's
@@ -187,6 +188,22 @@ int env_int(const char *name, int dflt) {
     if (!v || !*v) return dflt;
     const int x = atoi(v);
     return x > 0 ? x : dflt;
+}
+
+// Compute units a rank's compute stream leaves to the other streams ($SDPA_COMM_CUS; unset = the default:
+// 8 -- one per XCD -- when the call merges over several ranks, so that a batch's collectives and merge
+// kernels run UNDER the next batch's fused kernels the way the reference's MPI_Ireduce stays in flight
+// (attention-mpi.c:364-380); 0 with one rank, where nothing runs beside the fused kernel).  The fused
+// launches size their stream-K grids by what is left, so the reservation costs its share of the chip
+// (8 / 256 = 3 %) and no more (round 3: a masked stream broke the exact fit of the grid: +55 %).
+int comm_cus_reserved(int cus, int ranks) {
+    const char *v = getenv("SDPA_COMM_CUS");
+    int want = (v && *v) ? atoi(v) : (ranks > 1 ? 8 : 0);
+    if (want <= 0) return 0;
+    const int xcds = cus >= 64 ? cus / 32 : 1;
+    int r = (want + xcds - 1) / xcds * xcds;
+    if (r > cus / 2) r = cus / 2 / xcds * xcds;
+    return r;
 }
 
 // RAII page-locking of caller-owned host arrays (best effort: a range that cannot be registered,
@@ -287,6 +304,7 @@ struct Plan {
                                       // sends its rows of the batch home over its own PCIe link;
                                       // false: the reference's reduce to the root (attention-mpi.c:380), $SDPA_EGRESS=root
     int P;
+    int cus;                          // compute units the ranks' compute streams may use ($SDPA_COMM_CUS leaves some out)
     int B, nb;                        // rows per Q batch, batches (over the largest row range)
     int row_pieces, piece_min_rows;   // row pieces of the first / last batch (1 = off)
     int ldq, ldk, ldv, ldo;           // leading dimensions of the operand images (elements)
@@ -304,12 +322,13 @@ int piece_rows_of(const Plan &pl, int bs) {
 
 int pick_splits(const Plan &pl, int rows, int keys) {
     return pl.bf16 ? sdpa::pick_kv_splits_bf16(rows, keys, pl.dk, pl.dv)
-                   : sdpa::pick_kv_splits(rows, keys, pl.dk, pl.dv);
+                   : sdpa::pick_kv_splits(rows, keys, pl.dk, pl.dv, pl.cus);
 }
 
 size_t launch_ws_bytes(const Plan &pl, int rows, int keys) {
-    return pl.bf16 ? sdpa_dev_workspace_bytes_bf16(rows, keys, pl.dk, pl.dv)
-                   : sdpa::workspace_bytes(rows, keys, pl.dk, pl.dv);
+    if (pl.bf16) return sdpa_dev_workspace_bytes_bf16(rows, keys, pl.dk, pl.dv);
+    return std::max(sdpa::workspace_bytes(rows, keys, pl.dk, pl.dv),
+                    sdpa::workspace_bytes_for(rows, pl.dv, sdpa::pick_kv_splits(rows, keys, pl.dk, pl.dv, pl.cus)));
 }
 
 // Chunk sizes of a streamed shard: small first (the kernel starts after cmin keys have crossed
@@ -349,6 +368,7 @@ bool want_bf16(int flags) {
 void make_plan(Plan &pl, int m, int n, int dk, int dv, int flags, int ranks = 0) {
     pl.m = m; pl.n = n; pl.dk = dk; pl.dv = dv;
     pl.P = ranks > 0 ? ranks : E.n;
+    pl.cus = (ranks > 0 || E.run_cus <= 0) ? sdpa::kChipCus - comm_cus_reserved(sdpa::kChipCus, pl.P) : E.run_cus;
     pl.bf16 = want_bf16(flags);
     pl.qrows = (flags & SDPA_F_PLAN_QROWS) != 0;
     if (const char *v = getenv("SDPA_PLAN")) pl.qrows = pl.qrows || strcmp(v, "qrows") == 0;
@@ -1156,13 +1176,16 @@ void destroy_rank(Rank &g) {
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     if (g.s_cp) (void)hipStreamDestroy(g.s_cp);
     if (g.s_in) (void)hipStreamDestroy(g.s_in);
-    if (g.s_run) (void)hipStreamDestroy(g.s_run);
+    if (g.s_run) {
+        sdpa::forget_stream_cus(g.s_run);
+        (void)hipStreamDestroy(g.s_run);
+    }
     if (g.s_out) (void)hipStreamDestroy(g.s_out);
     if (g.s_comm) (void)hipStreamDestroy(g.s_comm);
     g = Rank();
 }
 
-int create_rank(Rank &g, int dev) {
+int create_rank(Rank &g, int dev, int reserve) {
     g.dev = dev;
     HIP_TRY(hipSetDevice(dev));
     // converts go first when a fused launch retires: they feed the next one
@@ -1175,7 +1198,8 @@ int create_rank(Rank &g, int dev) {
     // every CU until it ends (two 64 KiB workgroups and the whole register file per CU), so a merge
     // collective, an RCCL kernel or a convert that becomes ready while it runs waits for its last
     // workgroup -- streams and priorities do not help a kernel that finds no CU (profiles/r03/).
-    const int reserve = env_int("SDPA_COMM_CUS", 0);
+    // Round 4: the fused kernels distribute their work by stream-K over whatever CUs the stream has, so the
+    // reservation no longer breaks the grid's fit -- it is ON (8 CUs) by default for engines of several ranks.
     if (reserve > 0) {
         SDPA_TRY(sdpa::create_masked_stream(&g.s_run, reserve));
     } else {
@@ -1233,7 +1257,8 @@ int init_impl(int n_gpus) {
                     prop.gcnArchName);
             return SDPA_ENODEV;
         }
-        SDPA_TRY(create_rank(E.r[i], dev));
+        SDPA_TRY(create_rank(E.r[i], dev, comm_cus_reserved(prop.multiProcessorCount, want)));
+        if (i == 0) E.run_cus = sdpa::stream_cus(E.r[0].s_run);
     }
     const bool force = getenv("SDPA_FORCE_COLLECTIVES") && atoi(getenv("SDPA_FORCE_COLLECTIVES")) != 0;
     if (want > 1 || force) {
@@ -1274,12 +1299,14 @@ void sdpa_shutdown(void) {
     delete E.coll;
     E.coll = nullptr;
     E.n = 0;
+    E.run_cus = 0;
     E.up = false;
     E.virtual_ranks = false;
 }
 
 int sdpa_init(int n_gpus) {
     if (n_gpus < 0) return SDPA_EINVAL;
+    sdpa::reload_launch_knobs();
     DeviceRestore restore;
     const int rc = init_impl(n_gpus);
     if (rc != SDPA_OK && !E.up) {        // a half-built engine is torn down, not leaked
@@ -1295,11 +1322,13 @@ int sdpa_init(int n_gpus) {
     return rc;
 }
 
-int sdpa_last_timing(struct sdpa_timing *out) {
-    if (!out) return SDPA_EINVAL;
-    *out = E.last;
+int sdpa_last_timing_sized(struct sdpa_timing *out, size_t size) {
+    if (!out || size == 0) return SDPA_EINVAL;
+    memcpy(out, &E.last, std::min(size, sizeof(sdpa_timing)));
     return SDPA_OK;
 }
+
+int sdpa_last_timing(struct sdpa_timing *out) { return sdpa_last_timing_sized(out, sizeof(sdpa_timing)); }
 
 // =============================================================================
 // host level
@@ -1308,6 +1337,7 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
                        int n, int dk, int dv, int flags) {
     SDPA_TRY(check_shape(Q, K, V, result, m, n, dk, dv, flags, true));
     const double t_enter = now_us();
+    sdpa::reload_launch_knobs();          // on the calling thread, before any enqueue thread runs
     DeviceRestore restore;
     SDPA_TRY(lazy_init());
 
@@ -1583,6 +1613,7 @@ void sdpa_host_free(void *p) {
 int sdpa_plan_describe(int m, int n, int dk, int dv, int flags, int ranks, char *buf, size_t len) {
     if (!buf || len == 0 || ranks < 1 || ranks > sdpa::kMaxRanks) return SDPA_EINVAL;
     if (m < 0 || n < 0 || dk < 1 || dv < 1) return SDPA_EINVAL;
+    sdpa::reload_launch_knobs();
     Plan pl;
     make_plan(pl, m, n, dk, dv, flags, ranks);
     std::string o;

@@ -132,8 +132,45 @@ inline int splits_for_full_rounds(long blocks, int slots, int s0, int cap, doubl
     return best;
 }
 
-int  pick_kv_splits(int m, int n_local, int dk, int dv);
+// ---- how one fp32 fused launch distributes its work (round 4) ------------------------------------------------
+// classic:   ceil(m/128) query blocks x `splits` equal K/V ranges = one workgroup each; fast when that count is a
+//            whole number of rounds of the stream's resident workgroup slots (every BASELINE shape on a whole chip)
+// stream-K:  `workers` = the resident slots; every workgroup walks `run` consecutive tile steps of the launch's
+//            (query block, K/V tile) space and leaves one partial triple per query block it touches; `splits` =
+//            the most pieces any query block is cut into = slabs of split scratch the launch needs.  Chosen when
+//            the classic grid would leave slots idle: a CU-masked stream, an odd m, a short shard.
+// `cus` = compute units the launch's stream may use (0 = a whole MI355X, kChipCus).
+constexpr int kChipCus = 256;
+struct F32Plan {
+    int splits;     // slabs of split scratch (1 = the launch writes the result rows itself)
+    int streamk;    // 1 = stream-K distribution (pipelined 64/128/256-wide kernels only)
+    int workers;    // stream-K: workgroups
+    int run;        // stream-K: tile steps per workgroup
+};
+F32Plan plan_f32_launch(int m, int n_local, int dk, int dv, int cus);
+int  pick_kv_splits(int m, int n_local, int dk, int dv, int cus = 0);
+// scratch that covers the launch on ANY stream (whole chip or CU-masked: the slab counts differ)
 size_t workspace_bytes(int m, int n_local, int dk, int dv);
+size_t workspace_bytes_for(int m, int dv, int splits);
+
+// Compute units a stream's kernels may use: what create_masked_stream() registered for it, otherwise the
+// current device's count (a stream this library did not create).  Thread-safe.
+int  stream_cus(hipStream_t s);
+void register_stream_cus(hipStream_t s, int cus);
+void forget_stream_cus(hipStream_t s);
+
+// Launch-path knobs.  The launchers run on the hosts' enqueue threads, and glibc's environment is not safe to
+// read while another thread may setenv(): the knobs are read ONCE (first use) into an immutable snapshot;
+// sdpa_reload_env() (and every host-level entry point, on the calling thread, before any worker thread
+// runs) takes a new snapshot.
+struct LaunchKnobs {
+    int split_merge_kernel;   // $SDPA_SPLIT_MERGE=kernel: the fp32 pipelined kernel merges its K/V splits itself
+    int dksplit_pipe;         // $SDPA_DKSPLIT_PIPE (default 1): software-pipelined dk-split kernel
+    int bf16_tandem;          // $SDPA_BF16_TANDEM (default 1): tandem kernel for dv > 256
+    int streamk;              // $SDPA_STREAMK: 0 = never, 1 = whenever eligible, unset/auto = -1: by the cost model
+};
+const LaunchKnobs &launch_knobs();
+void reload_launch_knobs();
 // Point a.ws_* (and a.tickets) into a scratch area of workspace_bytes(a.m, ...) bytes: kv_splits slabs of
 // a.m rows x ws_ld floats, the two statistics arrays, the arrival words.  Needs a.m, a.kv_splits.
 void carve_workspace(PartialArgs &a, void *ws, int ws_ld);

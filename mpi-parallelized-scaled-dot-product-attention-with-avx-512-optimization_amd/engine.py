@@ -109,7 +109,7 @@ def plan(m, n, dk, dv, flags=0, ranks=1):
 
 def last_timing():
     t = SdpaTiming()
-    check(_lib.load().sdpa_last_timing(ctypes.byref(t)), "sdpa_last_timing")
+    check(_lib.load().sdpa_last_timing_sized(ctypes.byref(t), ctypes.sizeof(t)), "sdpa_last_timing_sized")
     out = {k: getattr(t, k) for k, _ in SdpaTiming._fields_}
     out["enqueue_first_kernel_us"] = list(out["enqueue_first_kernel_us"])[:max(1, out["n_gpus"])]
     return out

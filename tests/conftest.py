@@ -55,6 +55,17 @@ def _gpu_memory_trace(request):
                 request.node.nodeid[-110:], free >> 20, total >> 20, torch.cuda.memory_reserved() >> 20))
 
 
+@pytest.fixture(autouse=True)
+def _launch_knob_snapshot():
+    """The library reads its launch-path knobs ($SDPA_STREAMK, $SDPA_SPLIT_MERGE, ...) from ONE snapshot of the
+    environment (sdpa_reload_env, include/sdpa_hip.h).  A test that changed them re-took it; when monkeypatch
+    has put the environment back, the snapshot follows -- otherwise one test's knob leaks into the next."""
+    yield
+    mod = sys.modules.get(PKG)
+    if mod is not None and mod._lib._lib is not None:
+        mod.reload_env()
+
+
 @pytest.fixture(scope="session")
 def pkg():
     return importlib.import_module(PKG)

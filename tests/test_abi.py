@@ -84,13 +84,50 @@ def test_bf16_image_geometry_helpers(pkg):
     assert s2 == 2 and lib.sdpa_dev_workspace_bytes_bf16(70000, 4096, 64, 64) == s2 * 70000 * (64 + 2) * 4 + 547 * s2 * 4
     assert lib.sdpa_dev_kv_splits_bf16(65536, 4096, 64, 64) == 1 and lib.sdpa_dev_workspace_bytes_bf16(65536, 4096, 64, 64) == 512 * 4
     # fp32: one round of workgroups keeps the count that fills the chip once; beyond one round the last round is filled
-    assert lib.sdpa_dev_kv_splits(40000, 65536, 128, 128) == 8       # 313 query blocks: 2 splits = 1.22 rounds (61 %), 8 = 4.9 (98 %)
-    assert lib.sdpa_dev_kv_splits(32768, 65536, 256, 256) == 1 and lib.sdpa_dev_kv_splits(40000, 65536, 256, 256) == 4
+    # (classic equal splits, $SDPA_STREAMK=0; the default since round 4 is stream-K for such shapes -- next test)
+    os.environ["SDPA_STREAMK"] = "0"
+    pkg.reload_env()
+    try:
+        assert lib.sdpa_dev_kv_splits(40000, 65536, 128, 128) == 8       # 313 query blocks: 2 splits = 1.22 rounds (61 %), 8 = 4.9 (98 %)
+        assert lib.sdpa_dev_kv_splits(32768, 65536, 256, 256) == 1 and lib.sdpa_dev_kv_splits(40000, 65536, 256, 256) == 4
+    finally:
+        os.environ.pop("SDPA_STREAMK", None)
+        pkg.reload_env()
     splits = lib.sdpa_dev_kv_splits_bf16(32768, 65536, 512, 512)
     assert splits == 1 and lib.sdpa_dev_workspace_bytes_bf16(32768, 65536, 512, 512) == 256 * 4
     s2 = lib.sdpa_dev_kv_splits_bf16(256, 8192, 512, 512)
     assert s2 > 1
     assert lib.sdpa_dev_workspace_bytes_bf16(256, 8192, 512, 512) == s2 * 256 * (512 + 2) * 4 + 2 * s2 * 4
+
+
+def test_stream_k_plan_arithmetic(pkg):
+    """Round 4: the fp32 pipelined kernels cut a launch's (query block, K/V tile) steps into equal runs, one per
+    resident workgroup slot, when the classic grid of equal splits would not fill whole rounds.  Pure host
+    arithmetic (sdpa_dev_kv_splits = slabs on a whole chip, sdpa_dev_workspace_bytes = scratch for ANY stream)."""
+    lib = pkg.load()
+    ws = lambda m, d, s: s * m * (d + 2) * 4 + (m + 127) // 128 * 8 if s > 1 else 0
+    # shapes whose classic grid is exactly one round keep it: 256 query blocks x 2, 64 x 8, 1024 x 1 (two rounds)
+    assert lib.sdpa_dev_kv_splits(32768, 65536, 128, 128) == 2
+    assert lib.sdpa_dev_kv_splits(8192, 8192, 128, 128) == 8
+    assert lib.sdpa_dev_kv_splits(131072, 65536, 128, 128) == 1
+    # ... but their scratch covers the launch on a CU-masked stream too, where the same shape is cut by stream-K
+    # into at most 3 pieces per query block (496 runs of 1058 tile steps over rows of 2048)
+    assert lib.sdpa_dev_workspace_bytes(32768, 65536, 128, 128) == ws(32768, 128, 3)
+    assert ws(131072, 128, 2) <= lib.sdpa_dev_workspace_bytes(131072, 65536, 128, 128) <= ws(131072, 128, 3)
+    # 258 query blocks (m = 33000): classic needs many splits to fill rounds, stream-K cuts 258 x 2048 steps into 512 runs of 1032
+    assert lib.sdpa_dev_kv_splits(33000, 65536, 128, 128) == 3
+    assert lib.sdpa_dev_kv_splits(40000, 65536, 128, 128) == 3
+    # head dims outside the pipelined kernels are untouched (dk-split kernel, bf16 has its own picker)
+    os.environ["SDPA_STREAMK"] = "0"
+    pkg.reload_env()
+    try:
+        classic = [lib.sdpa_dev_kv_splits(m, 65536, 512, 512) for m in (32768, 33000, 40000)]
+        assert lib.sdpa_dev_kv_splits(33000, 65536, 128, 128) > 3
+        assert lib.sdpa_dev_workspace_bytes(32768, 65536, 128, 128) >= ws(32768, 128, 2)    # (masked streams: many equal splits)
+    finally:
+        os.environ.pop("SDPA_STREAMK", None)
+        pkg.reload_env()
+    assert [lib.sdpa_dev_kv_splits(m, 65536, 512, 512) for m in (32768, 33000, 40000)] == classic
 
 
 def test_argument_validation_precedes_device_use(pkg):
@@ -113,7 +150,8 @@ def test_argument_validation_precedes_device_use(pkg):
     assert lib.sdpa_dev_kv_splits(512, 512, 64, 64) == 4
     assert lib.sdpa_dev_kv_splits(8192, 8192, 512, 512) == 2      # dk-split kernel: 128 workgroups of 64 rows
     assert lib.sdpa_dev_kv_splits(8192, 8192, 600, 64) == 1       # dk > 512: VALU kernel, no splits
-    assert lib.sdpa_dev_workspace_bytes(32768, 65536, 128, 128) == 2 * 32768 * 130 * 4 + 256 * 8   # + one arrival word per query block
+    # 2 slabs on a whole chip; the scratch also covers a CU-masked stream, where stream-K cuts a query block into up to 3
+    assert lib.sdpa_dev_workspace_bytes(32768, 65536, 128, 128) == 3 * 32768 * 130 * 4 + 256 * 8   # + one arrival word per query block
     assert lib.sdpa_dev_workspace_bytes(100000, 64, 128, 128) == 0
 
 

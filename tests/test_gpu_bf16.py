@@ -339,8 +339,10 @@ def test_bf16_tandem_kernel_equals_the_wide_kernel_bit_for_bit(m, n, dk, dv, dis
     qb = sa.convert_q(torch.from_numpy(np.ascontiguousarray(Q)).cuda())
     try:
         os.environ["SDPA_BF16_TANDEM"] = "0"
+        pkg.reload_env()
         want = tuple(t.clone() for t in sa.batch_partial(qb))
         os.environ["SDPA_BF16_TANDEM"] = "1"
+        pkg.reload_env()
         for it in range(5):
             got = sa.batch_partial(qb)
             for name, g, w in zip(("contrib", "lmax", "lsum"), got, want):
@@ -349,6 +351,7 @@ def test_bf16_tandem_kernel_equals_the_wide_kernel_bit_for_bit(m, n, dk, dv, dis
         res = be.finish_f64(got[0], got[2], dv).cpu().numpy()
     finally:
         os.environ.pop("SDPA_BF16_TANDEM", None)
+        pkg.reload_env()
     assert np.isfinite(res).all()
     assert np.abs(res - orc.attention_f64(Q, K, V)).max() <= bf16_tol(V)
 
@@ -364,8 +367,10 @@ def test_bf16_tandem_steep_scores_take_the_redo_pass(pkg, be, O):
     want = O.numpy_attention_f64(Q, K, V)
     try:
         os.environ["SDPA_BF16_TANDEM"] = "1"
+        pkg.reload_env()
         got = dev_attention_bf16(pkg, be, Q, K, V)
     finally:
         os.environ.pop("SDPA_BF16_TANDEM", None)
+        pkg.reload_env()
     assert np.isfinite(got).all()
     assert np.abs(got - want).max() <= bf16_tol(V)

@@ -439,11 +439,13 @@ def test_race_screen_repeatability(pkg, be, orc, O):
     for it in range(1, 100):
         if it == 50:
             os.environ["SDPA_SPLIT_MERGE"] = "kernel"
+            pkg.reload_env()
         for sa, qf, dv, first in runs:                 # interleaved: the scratch area changes hands every launch
             cur = sa.batch_partial(qf)
             assert all(torch.equal(a_[:, :dv] if a_.dim() == 2 else a_, b_[:, :dv] if b_.dim() == 2 else b_)
                        for a_, b_ in zip(cur, first)), "launch %d differs from launch 0" % it
     os.environ.pop("SDPA_SPLIT_MERGE", None)
+    pkg.reload_env()
 
 
 @pytest.mark.parametrize("m,n,dk,dv", [(8192, 8192, 128, 128),      # BASELINE config 2: 64 query blocks x 8 splits
@@ -462,8 +464,10 @@ def test_in_kernel_split_merge_equals_the_separate_pass_bitwise(m, n, dk, dv, pk
     sa.load_kv_from_root(K, V, n, dk, dv)
     qf = sa.convert_q(torch.from_numpy(Q).cuda())
     monkeypatch.delenv("SDPA_SPLIT_MERGE", raising=False)
+    pkg.reload_env()
     want = tuple(t.clone() for t in sa.batch_partial(qf))
     monkeypatch.setenv("SDPA_SPLIT_MERGE", "kernel")
+    pkg.reload_env()
     for it in range(20):
         got = sa.batch_partial(qf)
         for name, g, w in zip(("contrib", "lmax", "lsum"), got, want):
@@ -495,8 +499,10 @@ def test_f32_dksplit_pipelined_kernel_equals_the_serial_one_bit_for_bit(m, n, dk
     sa.load_kv_from_root(K, V, n, dk, dv)
     qf = sa.convert_q(torch.from_numpy(np.ascontiguousarray(Q)).cuda())
     monkeypatch.setenv("SDPA_DKSPLIT_PIPE", "0")
+    pkg.reload_env()
     want = tuple(t.clone() for t in sa.batch_partial(qf))
     monkeypatch.setenv("SDPA_DKSPLIT_PIPE", "1")
+    pkg.reload_env()
     for it in range(5):
         got = sa.batch_partial(qf)
         for name, g, w in zip(("contrib", "lmax", "lsum"), got, want):

@@ -11,6 +11,7 @@ be = pkg.HipBackend("cuda:0")
 
 def run(m, n, dk, dv, pipe, seed=1, scale=1.0):
     os.environ["SDPA_DKSPLIT_PIPE"] = "1" if pipe else "0"
+    pkg.reload_env()
     g = torch.Generator(device="cuda"); g.manual_seed(seed)
     Q = (torch.rand((m, dk), generator=g, device="cuda", dtype=torch.float64) * 2 - 1) * scale
     K = (torch.rand((n, dk), generator=g, device="cuda", dtype=torch.float64) * 2 - 1) * scale

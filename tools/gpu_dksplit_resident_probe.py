@@ -12,6 +12,7 @@ for n in (65536, 16384, 4096, 2048, 1024):
     m = min(m, 262144)
     for pipe in (0, 1):
         os.environ["SDPA_DKSPLIT_PIPE"] = str(pipe)
+        pkg.reload_env()
         os.environ["SDPA_KV_SPLITS"] = "1"
         g = torch.Generator(device="cuda"); g.manual_seed(1)
         Q = torch.rand((m, d), generator=g, device="cuda", dtype=torch.float64) * 2 - 1
