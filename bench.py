@@ -8,8 +8,10 @@ m=32768, n=65536, dk=dv=128 ("headline"), fp32 compute / fp64 in-out.  One "step
 pass of the hot path over the synthetic problem with the fp64 inputs already resident in HBM:
     K/V shard fp64->fp32 convert, then per Q batch: Q convert, fused online-softmax kernel,
     [N>1: all-gather of the (lmax,lsum) pairs + one merge pass (or --merge allreduce: the reference's
-     all-reduce(MAX), rescale, all-reduce(SUM), normalise), then reduce(SUM) over RCCL],
-    fp32->fp64 result on the root.
+     all-reduce(MAX), rescale, all-reduce(SUM), normalise), then reduce-scatter(SUM) over RCCL -- every rank
+     keeps and widens its 1/N of the batch's rows, the C host's schedule (--egress root: the reference's
+     reduce(SUM) to rank 0)],
+    fp32->fp64 result (on the rank that owns the rows).
 N>1 runs one rank per GPU over RCCL (torch.distributed backend "nccl").  Either the caller launches
 the ranks (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`, RANK /
 LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or -- like the reference, which is one
@@ -26,6 +28,19 @@ Q batches form a software pipeline that runs across steps: the RCCL reduce of a 
 flight under the converts and the fused kernel of the next one (the reference overlaps its
 MPI_Ireduce the same way, attention-mpi.c:364-380); every step's work, including the last reduce
 and the fp64 writeback, finishes inside the timed region.
+
+Since round 4 the line also says, outside the headline's timed region (every addition is fenced, a failure in one
+becomes {"error": ...} inside that record, never a lost line):
+  scaling_config3 -- the same step on north_star's scaling shape (m=32768, n=262144, d=128) at this N
+  phases        -- N > 1: where one batch's time goes on rank 0 (converts | fused kernel | statistics collective |
+                   merge kernel | reduce(-scatter) | fp32->fp64), HIP events, collectives synchronous
+  c_host        -- N > 1: after the ranks have exited, ONE process drives all N GPUs through the C ABI
+                   (sdpa_init(N) = RCCL communicators + known-answer self-test; sdpa_attention_f64, host fp64
+                   in/out): self-test verdict, boundary ms, merge/egress schedule, parity -- in a subprocess
+                   with a timeout
+  gpu_busy_extra -- untimed continuation of the step so that the GPU phase lasts --min-gpu-seconds (external
+                   utilisation samplers see it); `value` comes from the K timed steps only
+`--host c` times the C host's schedule itself (one process, page-locked host fp64 in/out, PCIe inclusive).
 
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   roofline      -- fused kernel: algorithmic FLOP per launch / average launch time (HIP events
@@ -171,7 +186,7 @@ def pmc_stamp(workload, precision):
     """PMC-derived figures of the dominant kernel for this workload (tools/gpu_profile.sh ->
     profiles/traffic_latest.json): HBM-side bytes per launch, HBM-side GB/s, MFMA utilisation.  A figure
     is only quoted for the kernel sources it was measured on; otherwise every field is null."""
-    none = {"traffic": None, "hbm_gbps": None, "mfma_util": None}
+    none = {"traffic": None, "hbm_gbps": None, "mfma_util": None, "provenance": None}
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
         e = tj.get("entries", {}).get("%s/%s" % (workload, precision))
@@ -179,7 +194,15 @@ def pmc_stamp(workload, precision):
             e = tj                                           # round-1/2 layout: one entry, the headline's
         if e is None or e.get("kernel_src_sha16") != kernel_source_stamp(precision):
             return none
-        return {"traffic": e.get("per_launch_bytes"), "hbm_gbps": e.get("hbm_gbps"), "mfma_util": e.get("mfma_util")}
+        # these three are COPIED from a committed profile of the same kernel sources, not measured by this run
+        # (ADVICE r3): say where and when they come from, next to them
+        prov = {"file": "profiles/traffic_latest.json", "entry": "%s/%s" % (workload, precision),
+                "kernel_src_sha16": e.get("kernel_src_sha16"), "measured": e.get("measured"), "box": e.get("box"),
+                "rocm": e.get("rocm"), "hipcc": e.get("hipcc"),
+                "note": "traffic / hbm_gbps / mfma_util are rocprofv3 PMC figures of a separate profiling run on the same "
+                        "kernel sources (tools/gpu_profile.sh), not of this run"}
+        return {"traffic": e.get("per_launch_bytes"), "hbm_gbps": e.get("hbm_gbps"), "mfma_util": e.get("mfma_util"),
+                "provenance": prov}
     except Exception:  # noqa: BLE001
         return none
 
@@ -325,6 +348,20 @@ class HostStagedDist:
         t.copy_(c)
         return None
 
+    def reduce_scatter_tensor(self, out, inp, op=None, group=None, async_op=False):
+        """rank r receives the r-th of `world` equal shares of the sum; summed in RANK ORDER like the C host's
+        loopback collectives (csrc/sdpa_coll.hip), so the two hosts agree bit for bit on a one-GPU box"""
+        world = self._d.get_world_size()
+        parts = [torch.empty(inp.shape, dtype=inp.dtype) for _ in range(world)]
+        self._d.all_gather(parts, inp.cpu().contiguous(), group=group)
+        n = out.shape[0]
+        r = self._d.get_rank()
+        acc = parts[0][r * n:(r + 1) * n].clone()
+        for p in parts[1:]:
+            acc += p[r * n:(r + 1) * n]
+        out.copy_(acc)
+        return None
+
     def gather(self, t, gather_list=None, dst=0, group=None):
         lst = [torch.empty(t.shape, dtype=t.dtype) for _ in gather_list] if gather_list is not None else None
         self._d.gather(t.cpu(), lst, dst=dst, group=group)
@@ -345,6 +382,361 @@ class HostStagedDist:
         self._d.destroy_process_group()
 
 
+def kernel_name_of(d, precision):
+    """the dominant kernel's name as rocprofv3 prints it (for the reader of the line and of profiles/)"""
+    if precision == "bf16":
+        pad = 512 if d > 256 else 256 if d > 128 else 128 if d > 64 else 64
+        tandem = os.environ.get("SDPA_BF16_TANDEM", "1") != "0"
+        return (("sdpa::fused_bf16_tandem_kernel<%d>" if tandem else "sdpa::fused_bf16_wide_kernel<%d,0>") % pad +
+                " (+ its redo pass)" if d > 256
+                else "sdpa::fused_bf16_duo_kernel<%d,%d> (+ its redo pass)" % (pad, pad))
+    if d in (64, 128, 256):
+        return "sdpa::fused_pipelined_kernel<%d,%d,0>" % (d, d)
+    if 128 < d <= 512:
+        dks = 128 if d > 384 else 96 if d > 256 else 64
+        piped = os.environ.get("SDPA_DKSPLIT_PIPE", "1") != "0"
+        return ("sdpa::fused_dksplit_pipe_kernel<%d,%d,2>" if piped else "sdpa::fused_dksplit_kernel<%d,%d,2>") % (
+            dks, 128 if d > 256 else 64)
+    return "sdpa::fused_partial_kernel / generic_partial_kernel"
+
+
+class Job:
+    """One workload on this rank: the seeded resident inputs, the step (attention-mpi.c:307-399 for one rank's
+    shard: converts, fused kernel, the shard merge and the egress of the rows), its timing and its parity leg.
+    The headline measurement, the config-3 scaling record and the per-phase record are three uses of it."""
+
+    def __init__(self, pkg, be, dist, world, rank, dev, m, n, d, args, q_batch=0):
+        self.pkg, self.be, self.dist, self.world, self.rank, self.dev = pkg, be, dist, world, rank, dev
+        self.m, self.n, self.d, self.args = m, n, d, args
+        self.qrows = args.plan == "qrows"
+        self.precision = args.precision
+        qrows = self.qrows
+        if qrows:      # every rank holds all of K/V and its own slice of the query rows
+            self.cnt = n
+            self.m_loc, self.m_off = pkg.owner_count(m, world, rank), pkg.owner_disp(m, world, rank)
+        else:
+            self.cnt = pkg.owner_count(n, world, rank)
+            self.m_loc, self.m_off = m, 0
+        if args.emulate_ranks > 1 and world == 1:
+            self.cnt = pkg.owner_count(n, args.emulate_ranks, 0)
+        # synthetic resident inputs, U(-1,1) (SURVEY.md 8d "D1"), fp64 as the boundary hands them over
+        g = torch.Generator(device=dev)
+        g.manual_seed(20240 + 0)
+        self.Q64 = torch.rand((m, d), generator=g, device=dev, dtype=torch.float64) * 2 - 1
+        g.manual_seed(20240 + 1 + (0 if qrows else rank))
+        self.K64 = torch.rand((self.cnt, d), generator=g, device=dev, dtype=torch.float64) * 2 - 1
+        self.V64 = torch.rand((self.cnt, d), generator=g, device=dev, dtype=torch.float64) * 2 - 1
+        self.gen = g
+        # one Q batch by default at every N: a dry run of one rank's share (tools/gpu_emulate_ranks.sh)
+        # showed per-rank step time 1.21 / 1.29 / 1.46 ms at N=8 for 1 / 2 / 4 batches -- shorter K/V
+        # ranges per launch cost more than overlapping the reduce with the next batch's kernel buys
+        B = q_batch if q_batch > 0 else m
+        self.B = min(B, m)
+        self.nb = (m + self.B - 1) // self.B
+        force_dist = os.environ.get("SDPA_BENCH_FORCE_DIST") == "1"
+        # how the merged rows leave (K/V plan, N > 1): "scatter" = reduce-scatter, every rank widens ITS rows of the
+        # batch (the C host's default, include/sdpa_hip.h) | "root" = the reference's reduce to rank 0 (:380)
+        self.egress = args.egress if (dist is not None and not qrows) else "root"
+        self.sa = pkg.ShardedAttention(be, 0 if qrows else rank, 1 if qrows else world, None if qrows else dist,
+                                       force_collectives=force_dist and not qrows, precision=args.precision,
+                                       merge=args.merge, egress=self.egress)
+        self.kernel_events = []
+        if qrows:
+            self.Q64 = self.Q64[self.m_off:self.m_off + self.m_loc].contiguous()
+            self.B, self.nb = max(1, self.m_loc), 1
+            self.m_max = pkg.owner_count(m, world, 0)
+        self.carry = {"pending": None, "outs": None, "res": None}
+
+    # ---- the step -------------------------------------------------------------------------------------
+    def step_qrows(self, record):
+        sa, be, d = self.sa, self.be, self.d
+        sa.load_kv_shard_f64(self.K64, self.V64, self.n, d, d)
+        qf = sa.convert_q(self.Q64)
+        if record:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        contrib, lmax, lsum = sa.batch_partial(qf)
+        if record:
+            e1.record()
+            self.kernel_events.append((e0, e1, qf.shape[0]))
+        out = be.empty((self.m_max, d), torch.float64)
+        out[:self.m_loc] = be.finish_f64(contrib, lsum, d)
+        if self.dist is None:
+            return [out]
+        parts = [be.empty((self.m_max, d), torch.float64) for _ in range(self.world)] if self.rank == 0 else None
+        self.dist.gather(out, parts, dst=0)
+        return parts
+
+    def finish_previous(self):
+        """Tail of the previous batch: wait for its reduce(-scatter), widen to fp64
+        (attention-mpi.c:365-376: 'wait prev Reduce & copy result')."""
+        c = self.carry
+        if c["pending"] is not None:
+            c["pending"].wait()
+            c["pending"] = None
+        if c["outs"] is not None:
+            rows_t, nrows = c["outs"]
+            if self.egress == "scatter":
+                c["res"] = [self.be.cvt_f2d(rows_t[:nrows], self.d) if nrows > 0 else None]   # this rank's share, :373
+            elif self.rank == 0:
+                c["res"] = [self.be.cvt_f2d(rows_t, self.d)]                                  # :373,:396
+            c["outs"] = None
+
+    def step(self, record):
+        # Every Q batch is one stage of a software pipeline that runs ACROSS steps: the reduce of
+        # a batch stays in flight under the converts and the fused kernel of the next batch --
+        # the reference's own pipelining of its MPI_Ireduce (attention-mpi.c:364-380: "wait prev
+        # Reduce & copy result", then "issue non-blocking Reduce"); with one batch per step the
+        # next batch is the next step's.  All K steps' work, including the last reduce and
+        # writeback, completes inside the timed region (flush() before the closing fence).
+        sa, m, B, d = self.sa, self.m, self.B, self.d
+        sa.load_kv_shard_f64(self.K64, self.V64, self.n, d, d)             # attention-mpi.c:224-225
+        for b in range(self.nb):
+            qf = sa.convert_q(self.Q64[b * B:min(m, (b + 1) * B)])         # :303,:325
+            if record:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            contrib, lmax, lsum = sa.batch_partial(qf)                     # :333-338
+            if record:
+                e1.record()
+                self.kernel_events.append((e0, e1, qf.shape[0]))
+            self.finish_previous()                                         # :365-376
+            rows_t, self.carry["pending"], nrows = sa.batch_merge_egress(contrib, lmax, lsum,
+                                                                         async_reduce=self.dist is not None)
+            self.carry["outs"] = (rows_t, nrows)                           # :379-380
+        return None
+
+    def flush(self):
+        self.finish_previous()
+        return self.carry["res"]
+
+    def fence(self):
+        torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+            torch.cuda.synchronize()
+
+    def run_once(self, record):
+        return self.step_qrows(record) if self.qrows else self.step(record)
+
+    # ---- timing ---------------------------------------------------------------------------------------
+    def prewarm_steps(self, prewarm_ms):
+        pkg, args = self.pkg, self.args
+        rows_est = pkg.owner_count(self.m, self.world, 0) if self.qrows else self.m
+        keys_est = self.n if self.qrows else (self.cnt if args.emulate_ranks > 1 else pkg.owner_count(self.n, self.world, 0))
+        return prewarm_step_count(rows_est, keys_est, self.d, self.precision, prewarm_ms)
+
+    def timed(self, steps, warmup, prewarm):
+        """W untimed steps (behind `prewarm` clock-warming ones), then EXACTLY `steps` steps between two fences;
+        returns (max-over-ranks seconds, result of the last step)"""
+        for _ in range(prewarm):
+            self.run_once(False)
+        for _ in range(warmup):
+            self.run_once(False)
+        if not self.qrows:
+            self.flush()
+        self.fence()
+        self.kernel_events = []
+        t0 = time.perf_counter()
+        res = None
+        for _ in range(steps):
+            res = self.run_once(True)
+        if not self.qrows:
+            res = self.flush()
+        self.fence()
+        elapsed = time.perf_counter() - t0
+        if self.dist is not None:
+            tmax = torch.tensor([elapsed], device=self.dev, dtype=torch.float64)
+            self.dist.all_reduce(tmax, op=self.dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        return elapsed, res
+
+    def kernel_stats(self):
+        k_ms = [e0.elapsed_time(e1) for e0, e1, _ in self.kernel_events]
+        k_rows = [r for _, _, r in self.kernel_events]
+        avg_ms = float(np.mean(k_ms))
+        flop_per_launch = 4.0 * float(np.mean(k_rows)) * self.cnt * self.d
+        return avg_ms, flop_per_launch, len(k_ms)
+
+    # ---- the run certifies its own output (checker leg, outside the timed region) ------------------------
+    def parity(self, res, nrows=64):
+        """`nrows` random rows of the LAST timed step's result against the fp64 restatement (collective: every
+        rank calls it; rank 0 gets (err, tol, rows), the others (None, None, 0))"""
+        pkg, dist, world, rank, dev, m, n, d = self.pkg, self.dist, self.world, self.rank, self.dev, self.m, self.n, self.d
+        g, B, nb = self.gen, self.B, self.nb
+        # (with --q-batch the K/V-sharded step keeps only its last batch's rows)
+        row_lo = 0 if self.qrows else (nb - 1) * B
+        bs = m - row_lo
+        if self.egress == "scatter" and dist is not None and not self.qrows:
+            # the finished rows of the batch are spread over the ranks, `share` each: bring them to rank 0
+            share = (bs + world - 1) // world
+            mine = self.be.empty((share, d), torch.float64).zero_()
+            if res is not None and res[0] is not None:
+                mine[:res[0].shape[0]] = res[0]
+            parts = [self.be.empty((share, d), torch.float64) for _ in range(world)] if rank == 0 else None
+            dist.gather(mine, parts, dst=0)
+            if rank == 0:
+                res = [torch.cat(parts)[:bs]]
+        if rank != 0:
+            return None, None, 0
+        prow = row_lo + np.sort(np.random.default_rng(4321).choice(bs, min(nrows, bs), replace=False))
+        if self.qrows:       # finished rows arrive per rank, padded to the largest slice
+            full = torch.cat([res[r][:pkg.owner_count(m, world, r)] for r in range(world)]) if dist is not None else res[0][:self.m_loc]
+            got_rows = full[torch.from_numpy(prow).to(dev)]
+            g.manual_seed(20240 + 0)
+            Qfull = torch.rand((m, d), generator=g, device=dev, dtype=torch.float64) * 2 - 1
+            shards = [(self.K64, self.V64)]
+        else:
+            got_rows = res[0][torch.from_numpy(prow - row_lo).to(dev)]
+            Qfull = self.Q64
+            shards = []
+            for r in range(world):     # every rank's shard is a seeded stream: rank 0 can re-draw it
+                c_r = pkg.owner_count(n, world, r) if self.args.emulate_ranks <= 1 else self.cnt
+                g.manual_seed(20240 + 1 + r)
+                k_r = torch.rand((c_r, d), generator=g, device=dev, dtype=torch.float64) * 2 - 1
+                v_r = torch.rand((c_r, d), generator=g, device=dev, dtype=torch.float64) * 2 - 1
+                shards.append((k_r, v_r))
+        err, tol = parity_check(got_rows, prow, Qfull, shards, self.precision)
+        return err, tol, len(prow)
+
+    # ---- where a step's time goes at N > 1 (rank 0; its own short pass, nothing overlapped) ----------------
+    def phases(self, steps=3):
+        """HIP events on rank 0's stream around each phase of one batch, every collective synchronous: converts |
+        fused kernel (+ split merge) | all-gather (or the two all-reduces + rescale) | merge kernel | reduce(-scatter) |
+        fp32->fp64.  A phase that waits for a peer contains that wait -- which is the point: an under-6x
+        scaling result names its phase.  Milliseconds, mean over `steps` steps (K/V plan only)."""
+        if self.qrows or self.dist is None:
+            return None
+        sa, d = self.sa, self.d
+        names = ["convert", "fused_kernel", "stat_collective", "merge_kernel", "reduce", "f2d"]
+        acc = {k: 0.0 for k in names}
+        for it in range(steps + 1):                       # the first pass is a warm-up of this code path
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
+            ev[0].record()
+            sa.load_kv_shard_f64(self.K64, self.V64, self.n, d, d)
+            qf = sa.convert_q(self.Q64[:self.B])
+            ev[1].record()
+            contrib, lmax, lsum = sa.batch_partial(qf)
+            ev[2].record()
+            marks = sa.batch_merge_egress(contrib, lmax, lsum, async_reduce=False, marks=(ev[3], ev[4], ev[5]))
+            rows_t, _, nrows = marks
+            if self.egress == "scatter":
+                if nrows > 0:
+                    self.be.cvt_f2d(rows_t[:nrows], d)
+            elif self.rank == 0:
+                self.be.cvt_f2d(rows_t, d)
+            ev[6].record()
+            self.fence()
+            if it > 0:
+                for i, k in enumerate(names):
+                    acc[k] += ev[i].elapsed_time(ev[i + 1])
+        out = {k + "_ms": v / steps for k, v in acc.items()}
+        out["sum_ms"] = sum(out.values())
+        out["what"] = ("rank 0, one Q batch of %d rows, %d K/V rows on this rank, every phase fenced by HIP events on the launch "
+                       "stream and the collectives synchronous (no overlap): mean of %d steps" % (self.B, self.cnt, steps))
+        return out
+
+    def release(self):
+        self.K64 = self.V64 = self.Q64 = None
+        self.sa = None
+        self.carry = {"pending": None, "outs": None, "res": None}
+        torch.cuda.empty_cache()
+
+
+def c_host_probe(n_gpus, workload, precision, timeout_s=240, extra_env=None):
+    """N > 1: what a maintainer actually links -- ONE process driving all N GPUs through the C ABI
+    (sdpa_init(N): RCCL communicators + their known-answer self-test; sdpa_attention_f64 with host fp64 in/out).
+    Run in a SUBPROCESS with a timeout after the torch ranks have let go of their GPUs: a crash or a hang in
+    there becomes {"error": ...} in the record, never a lost JSON line."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--c-host-probe", str(n_gpus), "--workload", workload,
+           "--precision", precision]
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE",
+              "GROUP_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "OMP_NUM_THREADS"):
+        env.pop(k, None)                              # the launcher's per-rank variables do not belong to this process
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(extra_env or {})
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+    except subprocess.TimeoutExpired as e:
+        return {"error": "timed out after %d s" % timeout_s, "stderr_tail": (e.stderr or b"")[-600:].decode("utf-8", "replace")
+                if isinstance(e.stderr, bytes) else str(e.stderr or "")[-600:]}
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": "exit code %d" % r.returncode, "stderr_tail": r.stderr[-800:]}
+    try:
+        return json.loads(lines[-1])
+    except Exception as e:  # noqa: BLE001
+        return {"error": "unparsable output: %s" % e, "stdout_tail": r.stdout[-400:]}
+
+
+def c_host_probe_main(n_gpus, workload, precision):
+    """the child of c_host_probe(): no torch.distributed, no torch tensors -- the C ABI alone"""
+    import ctypes
+    pkg = importlib.import_module(PKG)
+    lib = pkg.load()
+    w = WORKLOADS[workload]
+    m, n, d = w["m"], w["n"], w["d"]
+    virt = os.environ.get("SDPA_VIRTUAL_GPUS")
+    rec = {"gpus": n_gpus, "virtual_ranks": bool(virt), "workload": "%s: m=%d n=%d dk=dv=%d" % (workload, m, n, d),
+           "version": lib.sdpa_version().decode()}
+    t0 = time.perf_counter()
+    rc = lib.sdpa_init(n_gpus)
+    rec["init_s"] = time.perf_counter() - t0
+    if rc != 0:
+        rec["selftest"] = "sdpa_init(%d) failed: %s (the RCCL self-test's message is on stderr)" % (n_gpus, pkg._lib.strerror(rc))
+        print(json.dumps(rec), flush=True)
+        return 0
+    rec["selftest"] = "ok"
+    flags = 2 if precision == "bf16" else 0
+    rng = np.random.default_rng(99)
+    bufs = []
+
+    def pinned(shape, fill):
+        nbytes = int(np.prod(shape)) * 8
+        ptr = lib.sdpa_host_alloc(nbytes)
+        if not ptr:
+            raise MemoryError("sdpa_host_alloc")
+        bufs.append(ptr)
+        v = np.ctypeslib.as_array((ctypes.c_double * (nbytes // 8)).from_address(ptr)).reshape(shape)
+        if fill:
+            v[...] = rng.uniform(-1, 1, shape)
+        return v
+    try:
+        Q, K, V, R = pinned((m, d), True), pinned((n, d), True), pinned((n, d), True), pinned((m, d), False)
+        pkg._lib.check(lib.sdpa_prepare(m, n, d, d, flags), "sdpa_prepare")
+        best = None
+        for _ in range(5):
+            pkg._lib.check(lib.sdpa_attention_f64(Q.ctypes.data, K.ctypes.data, V.ctypes.data, R.ctypes.data, m, n, d, d, flags),
+                           "sdpa_attention_f64")
+            t = pkg.last_timing()
+            if best is None or t["total_us"] < best["total_us"]:
+                best = t
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle as O
+        rows = np.sort(np.random.default_rng(7).choice(m, 32, replace=False))
+        want = O.numpy_attention_f64(Q, K, V, rows)
+        err = float(np.abs(R[rows] - want).max()) if np.isfinite(R).all() else float("inf")
+        tol = (1e-2 if precision == "bf16" else 5e-5) * max(1.0, float(np.abs(V).max()))
+        rec.update({"boundary_ms": best["total_us"] / 1e3, "q_rows_per_s": m / (best["total_us"] * 1e-6),
+                    "fused_kernel_ms_rank0": best["kernel_us"] / 1e3, "head_ms": best["head_us"] / 1e3, "tail_ms": best["tail_us"] / 1e3,
+                    "merge_ms": best["merge_us"] / 1e3, "reduce_ms": best["reduce_us"] / 1e3, "egress_ms": best["egress_us"] / 1e3,
+                    "merge": {0: "none", 1: "all-gather", 2: "all-reduce x2"}[best["merge"]],
+                    "egress": {0: "own rows", 1: "reduce to root", 2: "reduce-scatter"}[best["egress"]],
+                    "ranks": best["n_gpus"], "q_batches": best["q_batches"], "compute_cus": best["compute_cus"],
+                    "stream_k": best["stream_k"], "rccl_selftest_ranks": best["rccl_selftest"],
+                    "enqueue_first_kernel_us": best["enqueue_first_kernel_us"],
+                    "parity_max_err": err, "parity_tol": tol, "parity_ok": bool(err <= tol),
+                    "what": "sdpa_attention_f64, host fp64 in/out incl. PCIe, caller arrays page-locked, best of 5 warm calls"})
+    except Exception as e:  # noqa: BLE001
+        rec["error"] = str(e)
+    finally:
+        for ptr in bufs:
+            lib.sdpa_host_free(ptr)
+    print(json.dumps(rec), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -362,6 +754,10 @@ def main():
     ap.add_argument("--merge", default="gather", choices=["allreduce", "gather"],
                     help="shard merge: one all-gather of the (lmax,lsum) pairs (default, as the C host: same "
                          "algebra, one collective fewer), or the reference's literal all-reduce(MAX)+all-reduce(SUM)")
+    ap.add_argument("--egress", default="scatter", choices=["scatter", "root"],
+                    help="N > 1, K/V plan: how the merged rows leave -- reduce-scatter, every rank widens its share of the "
+                         "batch (default: the C host's schedule, include/sdpa_hip.h), or the reference's reduce to rank 0 "
+                         "(attention-mpi.c:380)")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="single-GPU dry run of ONE rank's share of an N-rank K/V-sharded job "
                          "(K/V rows = n/N); a tuning aid, the printed line is not a benchmark result")
@@ -369,15 +765,32 @@ def main():
                     help="untimed steps run BEFORE the W warmup steps until about this much GPU work has been "
                          "issued, so that the core clock has finished ramping when the timed region starts "
                          "(0 = off; see the DVFS note in main())")
-    ap.add_argument("--reserve-cus", type=int, default=0,
+    ap.add_argument("--reserve-cus", type=int, default=-1,
                     help="launch the fused kernels on a stream that leaves this many compute units (multiple of 8) to "
                          "other streams, so that RCCL's kernels of step k can run UNDER step k+1's fused kernel instead "
-                         "of waiting for its last workgroup (a fused launch otherwise holds every wave slot of the chip); "
-                         "0 = off (default): it costs the fused kernel reserve/256 of its rate")
+                         "of waiting for its last workgroup (a fused launch otherwise holds every wave slot of the chip). "
+                         "-1 = the C host's default: 8 when N > 1, 0 at N = 1.  The fused kernel sizes its stream-K grid "
+                         "by the stream's compute units, so this costs reserve/256 of its rate and no more")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
                     help="operand precision of the fused kernel (the headline metric is f32)")
+    ap.add_argument("--min-gpu-seconds", type=float, default=2.0,
+                    help="after the K timed steps (the measurement), keep stepping UNTIMED until the GPU phase has lasted "
+                         "about this long, so that an external utilisation sampler sees it (0 = off); the extra steps' "
+                         "own per-step mean is reported as a cross-check")
+    ap.add_argument("--no-scaling-record", action="store_true",
+                    help="skip the config-3 (n = 262144) scaling record that follows the headline measurement")
+    ap.add_argument("--no-c-host", action="store_true", help="N > 1: skip the C-host probe (one process, SDPA_GPUS = N)")
+    ap.add_argument("--host", default="py", choices=["py", "c"],
+                    help="py = one process per GPU, torch.distributed over RCCL (the contract's launch); c = time the C "
+                         "host's own schedule: ONE process, sdpa_attention_f64 with page-locked host fp64 in/out on --gpus N "
+                         "(the product boundary; PCIe inclusive, so the line's metric says so)")
+    ap.add_argument("--c-host-probe", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.c_host_probe > 0:
+        raise SystemExit(c_host_probe_main(args.c_host_probe, args.workload, args.precision))
+    if args.host == "c":
+        raise SystemExit(host_c_main(args))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args.gpus)                   # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -438,102 +851,8 @@ def main():
     w = WORKLOADS[args.workload]
     m, n, d = w["m"], w["n"], w["d"]
     qrows = args.plan == "qrows"
-    if qrows:      # every rank holds all of K/V and its own slice of the query rows
-        cnt, off = n, 0
-        m_loc, m_off = pkg.owner_count(m, world, rank), pkg.owner_disp(m, world, rank)
-    else:
-        cnt, off = pkg.owner_count(n, world, rank), pkg.owner_disp(n, world, rank)
-        m_loc, m_off = m, 0
-    if args.emulate_ranks > 1 and world == 1:
-        cnt = pkg.owner_count(n, args.emulate_ranks, 0)
+    job = Job(pkg, be, dist, world, rank, dev, m, n, d, args, q_batch=args.q_batch)
 
-    # synthetic resident inputs, U(-1,1) (SURVEY.md 8d "D1"), fp64 as the boundary hands them over
-    g = torch.Generator(device=dev)
-    g.manual_seed(20240 + 0)
-    Q64 = torch.rand((m, d), generator=g, device=dev, dtype=torch.float64) * 2 - 1
-    g.manual_seed(20240 + 1 + (0 if qrows else rank))
-    K64 = torch.rand((cnt, d), generator=g, device=dev, dtype=torch.float64) * 2 - 1
-    V64 = torch.rand((cnt, d), generator=g, device=dev, dtype=torch.float64) * 2 - 1
-
-    # one Q batch by default at every N: a dry run of one rank's share (tools/gpu_emulate_ranks.sh)
-    # showed per-rank step time 1.21 / 1.29 / 1.46 ms at N=8 for 1 / 2 / 4 batches -- shorter K/V
-    # ranges per launch cost more than overlapping the reduce with the next batch's kernel buys
-    B = args.q_batch if args.q_batch > 0 else m
-    B = min(B, m)
-    nb = (m + B - 1) // B
-    sa = pkg.ShardedAttention(be, 0 if qrows else rank, 1 if qrows else world, None if qrows else dist,
-                              force_collectives=force_dist and not qrows, precision=args.precision,
-                              merge=args.merge)
-    kernel_events = []
-    if qrows:
-        Q64 = Q64[m_off:m_off + m_loc].contiguous()
-        B, nb = max(1, m_loc), 1
-        m_max = pkg.owner_count(m, world, 0)
-
-    def step_qrows(record):
-        sa.load_kv_shard_f64(K64, V64, n, d, d)
-        qf = sa.convert_q(Q64)
-        if record:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        contrib, lmax, lsum = sa.batch_partial(qf)
-        if record:
-            e1.record()
-            kernel_events.append((e0, e1, qf.shape[0]))
-        out = be.empty((m_max, d), torch.float64)
-        out[:m_loc] = be.finish_f64(contrib, lsum, d)
-        if dist is None:
-            return [out]
-        parts = [be.empty((m_max, d), torch.float64) for _ in range(world)] if rank == 0 else None
-        dist.gather(out, parts, dst=0)
-        return parts
-
-    carry = {"pending": None, "outs": None, "res": None}
-
-    def finish_previous():
-        """Root-side tail of the previous step: wait for its reduce, widen to fp64
-        (attention-mpi.c:365-376: 'wait prev Reduce & copy result')."""
-        if carry["pending"] is not None:
-            carry["pending"].wait()
-            carry["pending"] = None
-        if carry["outs"] is not None:
-            if rank == 0:
-                carry["res"] = [be.cvt_f2d(c, d) for c in carry["outs"]]    # :373,:396
-            carry["outs"] = None
-
-    def step(record):
-        # Every Q batch is one stage of a software pipeline that runs ACROSS steps: the reduce of
-        # a batch stays in flight under the converts and the fused kernel of the next batch --
-        # the reference's own pipelining of its MPI_Ireduce (attention-mpi.c:364-380: "wait prev
-        # Reduce & copy result", then "issue non-blocking Reduce"); with one batch per step the
-        # next batch is the next step's.  All K steps' work, including the last reduce and
-        # writeback, completes inside the timed region (flush() before the closing fence).
-        sa.load_kv_shard_f64(K64, V64, n, d, d)                          # attention-mpi.c:224-225
-        for b in range(nb):
-            qf = sa.convert_q(Q64[b * B:min(m, (b + 1) * B)])           # :303,:325
-            if record:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            contrib, lmax, lsum = sa.batch_partial(qf)                   # :333-338
-            if record:
-                e1.record()
-                kernel_events.append((e0, e1, qf.shape[0]))
-            finish_previous()                                            # :365-376
-            contrib, carry["pending"] = sa.batch_merge(contrib, lmax, lsum, async_reduce=dist is not None)
-            carry["outs"] = [contrib]                                    # :379-380
-        return None
-
-    def flush():
-        finish_previous()
-        return carry["res"]
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    run = step_qrows if qrows else step
     # DVFS: from an idle start the core clock of this part needs ~20 ms of continuous matrix work to
     # reach its plateau -- the same fused launch (8192 x 8192, d = 128) takes 290 us at the start and
     # 253 us from then on (profiles/r02/short_step_clock_ramp.log).  W = 3 warmup steps cover that at
@@ -541,89 +860,77 @@ def main():
     # rank's 1/8 share of the metric shape: 3.6 ms), where the whole timed region used to sit on the
     # ramp (-10..15 %).  So a fixed number of extra UNTIMED steps goes first; the count is derived from
     # the shape alone, so that every rank of an N-rank job runs the same number of collectives.
-    rows_est = pkg.owner_count(m, world, 0) if qrows else m
-    keys_est = n if qrows else (cnt if args.emulate_ranks > 1 else pkg.owner_count(n, world, 0))
-    prewarm_steps = prewarm_step_count(rows_est, keys_est, d, args.precision, args.prewarm_ms)
+    prewarm_steps = job.prewarm_steps(args.prewarm_ms)
     import contextlib
     compute = contextlib.nullcontext()
-    if args.reserve_cus > 0:
+    reserve = args.reserve_cus if args.reserve_cus >= 0 else (8 if (dist is not None and not qrows and world > 1) else 0)
+    if reserve > 0:
         import ctypes
         sp = ctypes.c_void_p()
-        pkg._lib.check(pkg.load().sdpa_dev_stream_create(args.reserve_cus, ctypes.byref(sp)), "sdpa_dev_stream_create")
+        pkg._lib.check(pkg.load().sdpa_dev_stream_create(reserve, ctypes.byref(sp)), "sdpa_dev_stream_create")
         torch.cuda.synchronize()                   # the inputs were drawn on the default stream
         compute = torch.cuda.stream(torch.cuda.ExternalStream(sp.value, device=dev))
+    extra = None
+    phases = None
+    scaling3 = None
     with compute:
-        for _ in range(prewarm_steps):
-            run(False)
-        for _ in range(args.warmup):
-            run(False)
-        if not qrows:
-            flush()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            res = run(True)
-        if not qrows:
-            res = flush()
-        fence()
-        elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    # fused-kernel launch durations on this rank (rank 0 reports)
-    k_ms = [e0.elapsed_time(e1) for e0, e1, _ in kernel_events]
-    k_rows = [r for _, _, r in kernel_events]
-    avg_ms = float(np.mean(k_ms))
-    flop_per_launch = 4.0 * float(np.mean(k_rows)) * cnt * d
+        elapsed, res = job.timed(args.steps, args.warmup, prewarm_steps)
+        avg_ms, flop_per_launch, n_launches = job.kernel_stats()
+        # ---- visibility: the timed region above is the measurement; these untimed steps only make the GPU phase long
+        #      enough for an external sampler (the driver's gpu_busy) and cross-check the per-step mean
+        if args.min_gpu_seconds > 0 and not dry_run:
+            more = int(min(2000, max(0, np.ceil((args.min_gpu_seconds - elapsed) / max(elapsed / args.steps, 1e-6)))))
+            if more > 0:
+                e2, _ = job.timed(more, 0, 0)
+                extra = {"steps": more, "ms_per_step": e2 / more * 1e3,
+                         "what": "untimed continuation of the same step after the K timed ones (--min-gpu-seconds %.1f): "
+                                 "makes the GPU phase visible to external samplers; not part of value" % args.min_gpu_seconds}
+                job.kernel_events = []
+        parity_err, parity_tol, parity_rows = job.parity(res)
+        if world > 1:
+            phases = job.phases()
     achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
 
+    if rank == 0 and not (parity_err <= parity_tol):
+        raise SystemExit("bench: PARITY FAILURE: max|err| %.3e > tol %.3e on %d rows of the last timed step"
+                         % (parity_err, parity_tol, parity_rows))
+
+    # ---- north_star's scaling shape (configs[2]: m=32768, n=262144, d=128, K/V-sharded) at THIS N, outside the headline's
+    #      timed region: the driver's N = 1, 2, 4, 8 runs then yield the curve the >= 6x target is stated on
+    kv_rows_headline, B_headline, nb_headline = job.cnt, job.B, job.nb
+    if (args.workload == "headline" and args.precision == "f32" and not qrows and not args.no_scaling_record
+            and args.emulate_ranks <= 1):
+        job.release()
+        w3 = WORKLOADS["config3"]
+        try:
+            with compute:
+                j3 = Job(pkg, be, dist, world, rank, dev, w3["m"], w3["n"], w3["d"], args, q_batch=0)
+                steps3 = max(2, min(args.steps, 5 if world == 1 else 10))
+                e3, r3 = j3.timed(steps3, 1, j3.prewarm_steps(min(args.prewarm_ms, 40.0)))
+                k3_ms, k3_flop, _ = j3.kernel_stats()
+                p3_err, p3_tol, p3_rows = j3.parity(r3, nrows=16)
+                ph3 = j3.phases(2) if world > 1 else None
+            scaling3 = {"workload": "config3: m=%d n=%d dk=dv=%d" % (w3["m"], w3["n"], w3["d"]), "n_gpus": world,
+                        "steps": steps3, "ms_per_step": e3 / steps3 * 1e3, "q_rows_per_s": w3["m"] / (e3 / steps3),
+                        "tflops": 4.0 * w3["m"] * w3["n"] * w3["d"] / (e3 / steps3) / 1e12,
+                        "kernel_ms_avg": k3_ms, "kernel_frac_of_peak": k3_flop / (k3_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                        "kv_rows_per_gpu": j3.cnt, "parity_max_err": p3_err, "parity_tol": p3_tol, "parity_rows": p3_rows,
+                        "phases": ph3,
+                        "what": "same step as the headline (resident fp64 inputs, max over ranks) on north_star's scaling shape"}
+            if rank == 0 and not (p3_err <= p3_tol):
+                scaling3["error"] = "PARITY FAILURE"
+            j3.release()
+        except Exception as e:  # noqa: BLE001  (never lose the headline line to the extra record)
+            scaling3 = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    line = None
     if rank == 0:
-        # ---- the run certifies its own output (checker leg, outside the timed region) ----
-        # (with --q-batch the K/V-sharded step keeps only its last batch's rows)
-        row_lo = 0 if qrows else (nb - 1) * B
-        prow = row_lo + np.sort(np.random.default_rng(4321).choice(m - row_lo, min(64, m - row_lo), replace=False))
-        if qrows:       # finished rows arrive per rank, padded to the largest slice
-            full = torch.cat([res[r][:pkg.owner_count(m, world, r)] for r in range(world)]) if dist is not None else res[0][:m_loc]
-            got_rows = full[torch.from_numpy(prow).to(dev)]
-            g.manual_seed(20240 + 0)
-            Qfull = torch.rand((m, d), generator=g, device=dev, dtype=torch.float64) * 2 - 1
-            shards = [(K64, V64)]
-        else:
-            got_rows = res[0][torch.from_numpy(prow - row_lo).to(dev)]
-            Qfull = Q64
-            shards = []
-            for r in range(world):     # every rank's shard is a seeded stream: rank 0 can re-draw it
-                c_r = pkg.owner_count(n, world, r) if args.emulate_ranks <= 1 else cnt
-                g.manual_seed(20240 + 1 + r)
-                k_r = torch.rand((c_r, d), generator=g, device=dev, dtype=torch.float64) * 2 - 1
-                v_r = torch.rand((c_r, d), generator=g, device=dev, dtype=torch.float64) * 2 - 1
-                shards.append((k_r, v_r))
-        parity_err, parity_tol = parity_check(got_rows, prow, Qfull, shards, args.precision)
-        del shards
-        if not (parity_err <= parity_tol):
-            raise SystemExit("bench: PARITY FAILURE: max|err| %.3e > tol %.3e on %d rows of the last timed step"
-                             % (parity_err, parity_tol, len(prow)))
         ms_per_step = elapsed / args.steps * 1e3
         peak = BF16_MFMA_PEAK_TFLOPS if args.precision == "bf16" else F32_MFMA_PEAK_TFLOPS
-        if args.precision == "bf16":
-            pad = 512 if d > 256 else 256 if d > 128 else 128 if d > 64 else 64
-            tandem = os.environ.get("SDPA_BF16_TANDEM", "1") != "0"
-            kernel_name = (("sdpa::fused_bf16_tandem_kernel<%d>" if tandem else "sdpa::fused_bf16_wide_kernel<%d,0>") % pad +
-                           " (+ its redo pass)" if d > 256
-                           else "sdpa::fused_bf16_duo_kernel<%d,%d> (+ its redo pass)" % (pad, pad))
-        elif d in (64, 128, 256):
-            kernel_name = "sdpa::fused_pipelined_kernel<%d,%d,0>" % (d, d)
-        elif 128 < d <= 512:
-            dks = 128 if d > 384 else 96 if d > 256 else 64
-            piped = os.environ.get("SDPA_DKSPLIT_PIPE", "1") != "0"
-            kernel_name = ("sdpa::fused_dksplit_pipe_kernel<%d,%d,2>" if piped else "sdpa::fused_dksplit_kernel<%d,%d,2>") % (
-                dks, 128 if d > 256 else 64)
-        else:
-            kernel_name = "sdpa::fused_partial_kernel / generic_partial_kernel"
+        kernel_name = kernel_name_of(d, args.precision)
         total_flop = 4.0 * m * n * d
-        pmc = pmc_stamp(args.workload, args.precision) if world == 1 else {"traffic": None, "hbm_gbps": None, "mfma_util": None}
+        pmc = pmc_stamp(args.workload, args.precision) if world == 1 else {"traffic": None, "hbm_gbps": None, "mfma_util": None,
+                                                                           "provenance": None}
         line = {
             "metric": ("DRY RUN of 1 of %d ranks, not a result: " % args.emulate_ranks if args.emulate_ranks > 1 else "") +
                       ("DRY RUN (%s%s), not a result: " % ("gloo, host-staged collectives" if gloo else "rccl",
@@ -642,26 +949,31 @@ def main():
             "data": "synthetic U(-1,1) fp64 Q/K/V resident in HBM (%s)" %
                     ("Q row-sharded, K/V replicated" if qrows else "Q replicated, K/V row-sharded"),
             "config": {"workload": "%s: m=%d n=%d dk=dv=%d, %s compute / fp64 in-out" % (args.workload, m, n, d, args.precision),
-                       "q_batch": B, "q_batches": nb, **({"reserve_cus": args.reserve_cus} if args.reserve_cus else {}),
-                       "kv_rows_per_gpu": cnt,
+                       "q_batch": B_headline, "q_batches": nb_headline, **({"reserve_cus": reserve} if reserve else {}),
+                       "kv_rows_per_gpu": kv_rows_headline,
                        "kv_splits_in_gpu": (pkg.load().sdpa_dev_kv_splits_bf16 if args.precision == "bf16"
-                                            else pkg.load().sdpa_dev_kv_splits)(min(B, m), cnt, d, d),
+                                            else pkg.load().sdpa_dev_kv_splits)(min(B_headline, m), kv_rows_headline, d, d),
                        "parallelism": ("single GPU" if world == 1 else
                                        "q-row shard x%d (K/V replicated, gather of finished rows)" % world if qrows else
-                                       ("kv-shard x%d (all-reduce MAX, all-reduce SUM, reduce SUM over RCCL)" % world if args.merge == "allreduce"
-                                        else "kv-shard x%d (all-gather of (lmax,lsum), reduce SUM over RCCL)" % world))},
+                                       ("kv-shard x%d (all-reduce MAX, all-reduce SUM, %s over RCCL)" if args.merge == "allreduce"
+                                        else "kv-shard x%d (all-gather of (lmax,lsum), %s over RCCL)") %
+                                       (world, "reduce-scatter SUM" if args.egress == "scatter" else "reduce SUM"))},
             "tflops": total_flop / (elapsed / args.steps) / 1e12,
             "parity_max_err": parity_err, "parity_tol": parity_tol,
-            "parity": "%d random rows of the last timed step vs fp64 numpy restatement of attention.c:20-75" % len(prow),
+            "parity": "%d random rows of the last timed step vs fp64 numpy restatement of attention.c:20-75" % parity_rows,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": pmc["traffic"],
-                         # from the committed rocprofv3 PMC passes of THIS kernel build (null otherwise):
-                         # HBM-side GB/s (8 TB/s peak) and SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs)
+                         # NOT measured by this run: copied from the committed rocprofv3 PMC passes of THIS kernel
+                         # build (null otherwise) -- see pmc_from_profile for where and when they were taken
                          "hbm_gbps": pmc["hbm_gbps"], "mfma_util": pmc["mfma_util"],
+                         "pmc_from_profile": pmc["provenance"],
                          "kernel": kernel_name,
-                         "kernel_ms_avg": avg_ms, "launches": len(k_ms),
+                         "kernel_ms_avg": avg_ms, "launches": n_launches,
                          "flop_per_launch": flop_per_launch},
+            "gpu_busy_extra": extra,
+            "phases": phases,
+            "scaling_config3": scaling3,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(m, n, d)
@@ -669,15 +981,103 @@ def main():
             line["cpu_baseline"] = None
         if world == 1 and not qrows and args.emulate_ranks <= 1 and not force_dist and not args.no_boundary:
             try:
-                del Q64, K64, V64
-                torch.cuda.empty_cache()
+                job.release()
                 line["boundary"] = boundary_timing(pkg, m, n, d, args.precision)
             except Exception as e:  # noqa: BLE001
                 line["boundary"] = {"error": str(e)}
-        print(json.dumps(line), flush=True)
+    job.release()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        if world > 1 and not qrows and not args.no_c_host:
+            # the other ranks are exiting: give them a moment to let go of their GPUs, then ONE process drives all N
+            del be
+            torch.cuda.empty_cache()
+            time.sleep(2.0)
+            # (dry run on one GPU: the C host's loopback ranks stand in for the N devices)
+            line["c_host"] = c_host_probe(world, args.workload, args.precision,
+                                          extra_env={"SDPA_VIRTUAL_GPUS": str(world)} if share_gpu else None)
+        else:
+            line["c_host"] = None
+        print(json.dumps(line), flush=True)
+
+
+def host_c_main(args):
+    """--host c: the C host's schedule as the thing timed.  ONE process (under a launcher only rank 0 works), the
+    engine on --gpus N devices (sdpa_init: RCCL communicators and their self-test for N > 1), K timed calls of
+    sdpa_attention_f64 on page-locked host fp64 arrays.  The line's metric names the boundary: this is the
+    reference's own timed region (attention-mpi.c:519-524), PCIe inclusive."""
+    if int(os.environ.get("RANK", "0")) != 0:
+        return 0
+    import ctypes
+    pkg = importlib.import_module(PKG)
+    lib = pkg.load()
+    w = WORKLOADS[args.workload]
+    m, n, d = w["m"], w["n"], w["d"]
+    flags = (2 if args.precision == "bf16" else 0) | (4 if args.plan == "qrows" else 0) | (8 if args.merge == "allreduce" else 0)
+    if args.egress == "root":
+        os.environ["SDPA_EGRESS"] = "root"
+    pkg._lib.check(lib.sdpa_init(args.gpus), "sdpa_init")
+    rng = np.random.default_rng(99)
+    bufs = []
+
+    def pinned(shape, fill):
+        nbytes = int(np.prod(shape)) * 8
+        ptr = lib.sdpa_host_alloc(nbytes)
+        if not ptr:
+            raise MemoryError("sdpa_host_alloc")
+        bufs.append(ptr)
+        v = np.ctypeslib.as_array((ctypes.c_double * (nbytes // 8)).from_address(ptr)).reshape(shape)
+        if fill:
+            v[...] = rng.uniform(-1, 1, shape)
+        return v
+    Q, K, V, R = pinned((m, d), True), pinned((n, d), True), pinned((n, d), True), pinned((m, d), False)
+    pkg._lib.check(lib.sdpa_prepare(m, n, d, d, flags), "sdpa_prepare")
+    call = lambda: pkg._lib.check(lib.sdpa_attention_f64(Q.ctypes.data, K.ctypes.data, V.ctypes.data, R.ctypes.data, m, n, d, d,
+                                                         flags), "sdpa_attention_f64")
+    for _ in range(args.warmup + prewarm_step_count(m, n // max(1, args.gpus), d, args.precision, args.prewarm_ms) // 4):
+        call()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        call()
+        kernel_ms.append(pkg.last_timing()["kernel_us"] / 1e3)
+    elapsed = time.perf_counter() - t0
+    t = pkg.last_timing()
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    rows = np.sort(np.random.default_rng(4321).choice(m, min(64, m), replace=False))
+    want = O.numpy_attention_f64(Q, K, V, rows)
+    err = float(np.abs(R[rows] - want).max()) if np.isfinite(R).all() else float("inf")
+    tol = (1e-2 if args.precision == "bf16" else 5e-5) * max(1.0, float(np.abs(V).max()))
+    for ptr in bufs:
+        lib.sdpa_host_free(ptr)
+    if not (err <= tol):
+        raise SystemExit("bench --host c: PARITY FAILURE: max|err| %.3e > tol %.3e" % (err, tol))
+    peak = BF16_MFMA_PEAK_TFLOPS if args.precision == "bf16" else F32_MFMA_PEAK_TFLOPS
+    k_ms = float(np.mean(kernel_ms))
+    flop_rank0 = 4.0 * m * pkg.owner_count(n, t["n_gpus"], 0) * d
+    line = {"metric": "BOUNDARY (C host, host fp64 in/out incl. PCIe): Q-rows/sec, fused online-softmax attention m=%d n=%d dk=dv=%d"
+                      % (m, n, d),
+            "value": m / (elapsed / args.steps), "unit": "Q-rows/s", "n_gpus": t["n_gpus"], "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": args.precision,
+            "data": "synthetic U(-1,1) fp64 Q/K/V in page-locked HOST memory (sdpa_host_alloc)",
+            "config": {"workload": "%s: m=%d n=%d dk=dv=%d, %s compute / fp64 in-out" % (args.workload, m, n, d, args.precision),
+                       "host": "c: one process, sdpa_attention_f64 (attention-mpi.c:519-524's timed region)",
+                       "virtual_ranks": bool(t["virtual_ranks"]), "q_batches": t["q_batches"], "compute_cus": t["compute_cus"],
+                       "merge": t["merge"], "egress": t["egress"], "stream_k": t["stream_k"]},
+            "tflops": 4.0 * m * n * d / (elapsed / args.steps) / 1e12,
+            "parity_max_err": err, "parity_tol": tol, "parity": "%d random rows of the last call" % len(rows),
+            "roofline": {"bound": "mfma", "achieved": flop_rank0 / (k_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                         "frac": flop_rank0 / (k_ms * 1e-3) / 1e12 / peak, "traffic": None,
+                         "kernel": kernel_name_of(d, args.precision), "kernel_ms_avg": k_ms,
+                         "what": "rank 0's fused launches of one call (HIP events on its compute stream), summed"},
+            "last_call": {k: (v if not isinstance(v, list) else v) for k, v in t.items()},
+            "cpu_baseline": None}
+    print(json.dumps(line), flush=True)
+    return 0
 
 
 if __name__ == "__main__":

@@ -114,10 +114,9 @@ struct sdpa_timing {
 /* Create the engine on `n_gpus` devices (0 = every visible device).  Separate
  * from the compute call so a bench can keep one-time HIP/RCCL start-up out of
  * the timed region (the reference's timer brackets attention() itself,
- * attention.c:179-182).  sdpa_attention_f64() calls it lazily with $SDPA_GPUS
- * when it has not been called; WITHOUT $SDPA_GPUS the lazy default is ONE GPU:
- * driving several GPUs from this process is opt-in ($SDPA_GPUS=8, or =0 / =all
- * for every visible device).
+ * attention.c:179-182).  sdpa_attention_f64() creates the engine lazily when
+ * none exists: see sdpa_init_default() below (every visible device whose RCCL
+ * transport passes the self-test; $SDPA_GPUS=N forces a count).
  * $SDPA_VIRTUAL_GPUS=P makes the engine P logical ranks that all live on
  * device 0 (own streams and buffers each, loopback collectives): the P > 1
  * pipeline on a one-GPU machine.  $SDPA_FORCE_COLLECTIVES=1 runs the merge
@@ -128,6 +127,13 @@ struct sdpa_timing {
  * single-threaded, attention.c:179-182).  They restore the calling thread's
  * current HIP device before returning.                                        */
 SDPA_API int sdpa_init(int n_gpus);
+/* The engine sdpa_attention_f64() creates lazily, created now: $SDPA_GPUS devices when set; otherwise EVERY visible
+ * device, on the evidence of this node -- creating an engine on P > 1 devices runs each collective of the pipeline
+ * once over RCCL on known data (a deadline of $SDPA_RCCL_SELFTEST_TIMEOUT_S, default 60 s): passed = P GPUs; failed
+ * with an error = one line on stderr and ONE GPU; did not finish = SDPA_ERCCL (set SDPA_GPUS=1).  A no-op when an
+ * engine exists.  sdpa_engine_ranks(): ranks of the current engine (0 = none).                                    */
+SDPA_API int sdpa_init_default(void);
+SDPA_API int sdpa_engine_ranks(void);
 SDPA_API void sdpa_shutdown(void);
 SDPA_API int sdpa_device_count(void);          /* visible HIP devices, <0 on error */
 SDPA_API const char *sdpa_strerror(int code);
@@ -234,16 +240,16 @@ SDPA_API int sdpa_owner_disp(int n, int size, int rank);
  * sdpa_dev_shard_partial_f32 must be zero (sdpa_dev_cvt_d2f writes them so).
  * Operand base pointers must be 16-byte aligned (SDPA_EINVAL otherwise).        */
 
-/* A stream for the fused kernels that leaves `reserve_cus` compute units (rounded up to a multiple of
- * the 8 XCDs, the same number from each) to other streams' kernels; 0 = an ordinary non-blocking
- * stream.  Why: a fused launch holds every wave slot of every CU until its last workgroup ends, so a
- * collective (RCCL) or merge kernel that becomes ready while it runs cannot start -- whatever its
- * stream or priority.  A host that wants batch b's reduce to run UNDER batch b+1's fused kernel
- * (attention-mpi.c:364-380) launches the fused kernels on such a stream (the C host: $SDPA_COMM_CUS,
- * default 8 when it drives several ranks; bench.py: --reserve-cus).  It costs the fused kernel
- * reserve_cus/256 of the chip and no more: sdpa_dev_shard_partial_f32 sizes its stream-K grid by the
- * compute units of the stream it is given.  The stream is a BLOCKING stream (the mask API has no flags):
- * it synchronises with the legacy NULL stream, so keep the NULL stream idle beside it.              */
+/* A stream for the fused kernels that leaves `reserve_cus` compute units' worth of the chip (rounded up to a
+ * multiple of the 8 XCDs) to other streams' kernels; 0 = an ordinary non-blocking stream.  Why: a fused launch
+ * otherwise holds every workgroup slot of every CU until its last workgroup ends, so a collective (RCCL) or merge
+ * kernel that becomes ready while it runs cannot start -- whatever its stream or priority.  A host that wants
+ * batch b's reduce to run UNDER batch b+1's fused kernel (attention-mpi.c:364-380) launches the fused kernels on
+ * such a stream (the C host: $SDPA_COMM_CUS, default 8 when it drives several ranks; bench.py: --reserve-cus).
+ * The reservation is made by grid size: the stream is an ordinary non-blocking stream that this library remembers
+ * as having (256 - reserve) CUs, and sdpa_dev_shard_partial_f32 sizes its stream-K grid by that -- 2 x reserve of
+ * the 512 workgroup slots stay free on CUs that hold one fused workgroup.  It costs the fused kernel reserve/256
+ * of its rate and no more.  (Head dims whose kernels have no stream-K form -- dk > 128, bf16 -- ignore it.)      */
 SDPA_API int sdpa_dev_stream_create(int reserve_cus, void **stream);
 SDPA_API int sdpa_dev_stream_destroy(void *stream);
 
@@ -264,9 +270,9 @@ SDPA_API int sdpa_dev_cvt_f2d(const float *src, int ld, double *dst, long rows,
                               int cols, void *stream);
 
 /* Number of in-GPU K/V splits (slabs of partial triples) the fused kernel uses for this shape on a
- * stream that owns the whole chip, and the scratch a launch needs on ANY stream -- a CU-masked stream
- * cuts the work differently (stream-K over its resident workgroup slots) and may use a slab more;
- * the byte count covers both (0 bytes when the answer is 1 split everywhere).     */
+ * stream that owns the whole chip, and the scratch a launch needs on ANY stream -- one created with
+ * sdpa_dev_stream_create(reserve > 0) cuts the work differently (stream-K over fewer workgroup slots)
+ * and may use a slab more; the byte count covers both (0 bytes when the answer is 1 split everywhere). */
 SDPA_API int    sdpa_dev_kv_splits(int m, int n_local, int dk, int dv);
 SDPA_API size_t sdpa_dev_workspace_bytes(int m, int n_local, int dk, int dv);
 

@@ -48,6 +48,8 @@ class SdpaError(RuntimeError):
 _PROTOS = {
     "sdpa_init": (_c_int, [_c_int]),
     "sdpa_shutdown": (None, []),
+    "sdpa_init_default": (_c_int, []),
+    "sdpa_engine_ranks": (_c_int, []),
     "sdpa_device_count": (_c_int, []),
     "sdpa_strerror": (ctypes.c_char_p, [_c_int]),
     "sdpa_version": (ctypes.c_char_p, []),

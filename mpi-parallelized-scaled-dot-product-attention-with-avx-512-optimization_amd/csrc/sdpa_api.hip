@@ -20,7 +20,7 @@
 
 namespace sdpa {
 
-// ---- CU budget of the streams this library created with a CU mask ---------------------------------------------
+// ---- CU budget of the streams this library created with a reservation -------------------------------------------
 namespace {
 std::mutex &cus_mu() { static std::mutex *m = new std::mutex; return *m; }
 std::vector<std::pair<hipStream_t, int>> &cus_tab() { static auto *t = new std::vector<std::pair<hipStream_t, int>>; return *t; }
@@ -200,12 +200,12 @@ int sdpa_dev_shard_partial_f32(const float *Qf, int ldq, const float *Kf, int ld
     a.Q = Qf; a.ldq = ldq; a.K = Kf; a.ldk = ldk; a.V = Vf; a.ldv = ldv;
     a.contrib = contrib; a.ldo = ldo; a.lmax = lmax; a.lsum = lsum;
     a.m = m; a.n_local = n_local; a.dk = dk; a.dv = dv;
-    // the split count belongs to the STREAM: a CU-masked one has fewer resident workgroup slots, and the
+    // the split count belongs to the STREAM: one with a reservation has fewer workgroup slots to fill, and the
     // stream-K cuts (sdpa_internal.h) follow them.  sdpa_dev_workspace_bytes() covers either.
     a.kv_splits = sdpa::pick_kv_splits(m, n_local, dk, dv, sdpa::stream_cus((hipStream_t)stream));
     if (a.kv_splits > 1 && workspace && workspace_bytes < sdpa::workspace_bytes_for(m, dv, a.kv_splits) &&
         workspace_bytes >= sdpa::workspace_bytes(m, n_local, dk, dv)) {
-        // a masked stream with stream-K switched off wants more equal splits than the documented scratch
+        // a reserving stream with stream-K switched off wants more equal splits than the documented scratch
         // holds: any smaller count is as correct (only less evenly spread), so take what fits
         while (a.kv_splits > 1 && workspace_bytes < sdpa::workspace_bytes_for(m, dv, a.kv_splits)) --a.kv_splits;
     }

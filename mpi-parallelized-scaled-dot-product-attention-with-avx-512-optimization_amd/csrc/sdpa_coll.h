@@ -45,13 +45,18 @@ public:
                                    hipStream_t const *streams) = 0;
     // last error text of the underlying library ("" when none)
     virtual const char *last_error() const { return ""; }
+    // ranks whose transport passed the known-answer self-test when the object was created (0 = none was run:
+    // loopback ranks compute their collectives with this library's own kernels)
+    virtual int selftested_ranks() const { return 0; }
 
 protected:
     int P_ = 0;
 };
 
-// devs[r] = HIP device ordinal of rank r.  Returns nullptr (message on stderr) on failure.
-Collectives *make_rccl_collectives(int P, const int *devs);
+// devs[r] = HIP device ordinal of rank r.  Returns nullptr (message on stderr) on failure.  *hung (optional) is
+// set when the self-test did not FINISH within its deadline ($SDPA_RCCL_SELFTEST_TIMEOUT_S, default 60): kernels
+// of the transport may then still sit on the devices, and the caller must not fall back to computing on them.
+Collectives *make_rccl_collectives(int P, const int *devs, bool *hung = nullptr);
 Collectives *make_loopback_collectives(int P, int dev);
 
 }  // namespace sdpa

@@ -7,8 +7,11 @@
 #include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
+#include <thread>
 #include <vector>
 
 namespace sdpa {
@@ -68,6 +71,7 @@ class RcclCollectives final : public Collectives {
 public:
     RcclCollectives() {}
     ~RcclCollectives() override {
+        if (hung_) return;                   // (destroying a communicator whose kernels never finished can hang in turn)
         for (ncclComm_t c : comms_)
             if (c && api_.CommDestroy) api_.CommDestroy(c);
     }
@@ -113,9 +117,25 @@ public:
             for (size_t i = 0; i < n * P_; ++i) host[i] = (float)(r + 1);
             if (hipMemcpy(a[r], host.data(), n * P_ * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) fail("upload");
         }
+        // wait with a DEADLINE: this is the first time these communicators move data, and a transport that does
+        // not work on this node typically does not fail -- it hangs.  The engine must then say so, not hang too.
+        const char *tv = getenv("SDPA_RCCL_SELFTEST_TIMEOUT_S");
+        const double limit_s = (tv && atof(tv) > 0) ? atof(tv) : 60.0;
         auto sync_all = [&]() {
-            for (int r = 0; r < P_; ++r)
-                if (hipSetDevice(devs[r]) != hipSuccess || hipStreamSynchronize(st[r]) != hipSuccess) return false;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int r = 0; r < P_; ++r) {
+                if (hipSetDevice(devs[r]) != hipSuccess) return false;
+                for (;;) {
+                    const hipError_t q = hipStreamQuery(st[r]);
+                    if (q == hipSuccess) break;
+                    if (q != hipErrorNotReady) return false;
+                    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s) {
+                        hung_ = true;
+                        return false;
+                    }
+                    std::this_thread::sleep_for(std::chrono::microseconds(200));
+                }
+            }
             return true;
         };
         auto expect = [&](int r, float *dev, size_t count, auto want, const char *what) {
@@ -145,14 +165,23 @@ public:
         for (int r = 0; r < P_; ++r) expect(r, b[r], n, [&](size_t) { return sum; }, "reduce_scatter");
         if (ok && (reduce_sum_to_root(a.data(), b[0], n, st.data()) || !sync_all())) fail("reduce to root");
         expect(0, b[0], n, [&](size_t) { return sum; }, "reduce to root");
+        if (hung_) {
+            // (nothing is freed or destroyed: the hung kernels still own the buffers and the streams)
+            snprintf(err_, sizeof err_, "RCCL self-test: a collective over %d ranks did not finish within %.0f s", P_, limit_s);
+            fprintf(stderr, "sdpa: %s\n", err_);
+            return false;
+        }
         for (int r = 0; r < P_; ++r) {
             if (hipSetDevice(devs[r]) != hipSuccess) continue;
             if (a[r]) (void)hipFree(a[r]);
             if (b[r]) (void)hipFree(b[r]);
             if (st[r]) (void)hipStreamDestroy(st[r]);
         }
+        if (ok) tested_ = P_;
         return ok;
     }
+    bool hung() const { return hung_; }
+    int selftested_ranks() const override { return tested_; }
 
     int all_reduce(float *const *send, float *const *recv, size_t count, RedOp op,
                    hipStream_t const *streams) override {
@@ -203,6 +232,8 @@ private:
     RcclApi api_;
     std::vector<ncclComm_t> comms_;
     char err_[160] = "";
+    bool hung_ = false;
+    int tested_ = 0;
 };
 
 // =============================================================================
@@ -330,10 +361,12 @@ private:
 
 }  // namespace
 
-Collectives *make_rccl_collectives(int P, const int *devs) {
+Collectives *make_rccl_collectives(int P, const int *devs, bool *hung) {
+    if (hung) *hung = false;
     if (P < 1 || P > kMaxRanks) return nullptr;
     RcclCollectives *c = new RcclCollectives;
     if (!c->init(P, devs) || !c->selftest(devs)) {
+        if (hung) *hung = c->hung();
         delete c;
         return nullptr;
     }

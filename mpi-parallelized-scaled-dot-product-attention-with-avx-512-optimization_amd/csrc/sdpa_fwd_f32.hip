@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256, (DKP > 128) ? 1 : 2) void fused_partial_kernel
 // workgroup slot of the stream's compute units; a workgroup walks its run piece by piece (a piece = the part
 // of one query block's K/V range inside the run) and writes each piece's partial triple into slab
 // (workgroup - first workgroup of that query block) of the split scratch.  Every workgroup then does the
-// same number of tile steps whatever m, n and the number of compute units are -- a CU mask that leaves
+// same number of tile steps whatever m, n and the number of compute units are -- a reservation that leaves
 // room for RCCL's kernels, an odd m or a short shard no longer break "the grid is exactly one round".
 // Slabs a query block does not use are filled with the empty triple (0, -inf, 0) by its last piece, so
 // that the merge passes (split_merge_kernel, the hosts' slot merge) stay what they are.  When the cuts
@@ -1115,8 +1115,8 @@ size_t workspace_bytes_for(int m, int dv, int splits) {
     return (size_t)splits * (size_t)m * (ws_ld + 2) * sizeof(float) + tickets;
 }
 
-// Scratch for the launch on ANY stream: the most slabs the plan asks for over the whole chip and every CU mask
-// create_masked_stream() can produce (8, 16, ... CUs left out, up to half the chip).
+// Scratch for the launch on ANY stream: the most slabs the plan asks for over the whole chip and every reservation
+// create_masked_stream() accepts (8, 16, ... CUs left out, up to half the chip).
 size_t workspace_bytes(int m, int n_local, int dk, int dv) {
     int s = 1;
     for (int cus = kChipCus; cus >= kChipCus / 2; cus -= 8) s = std::max(s, pick_kv_splits(m, n_local, dk, dv, cus));

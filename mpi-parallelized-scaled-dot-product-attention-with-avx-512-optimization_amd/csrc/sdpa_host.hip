@@ -94,6 +94,7 @@ struct Rank {
     std::vector<hipEvent_t> ev_kv;       // K/V chunk c is converted into the operand image
     std::vector<hipEvent_t> ev_k;        // fused-kernel timing brackets (rank 0)
     hipEvent_t ev_t0 = nullptr, ev_kv_done = nullptr, ev_end = nullptr;
+    hipEvent_t ev_tail[4] = {};          // rank 0, last batch's collective tail: start | merged | reduced | widened (comm stream)
 };
 
 // One enqueue thread per rank (P > 1 only).  A job is a function of the rank index; run() hands it to
@@ -170,6 +171,7 @@ struct Engine {
     Pool pool;                           // enqueue threads, one per rank (empty with one rank)
     sdpa::HostConverter *hc = nullptr;   // $SDPA_HOST_CVT=1: fp64 -> operand images on host threads (sdpa_hostcvt.h)
     int run_cus = 0;                     // compute units of a rank's compute stream (create_rank)
+    bool rccl_hung = false;              // the last RCCL self-test did not finish (lazy_init does not fall back then)
     sdpa_timing last = {};
 };
 // Heap-allocated and never destroyed on purpose: at process exit the order in which this library's
@@ -195,7 +197,7 @@ int env_int(const char *name, int dflt) {
 // kernels run UNDER the next batch's fused kernels the way the reference's MPI_Ireduce stays in flight
 // (attention-mpi.c:364-380); 0 with one rank, where nothing runs beside the fused kernel).  The fused
 // launches size their stream-K grids by what is left, so the reservation costs its share of the chip
-// (8 / 256 = 3 %) and no more (round 3: a masked stream broke the exact fit of the grid: +55 %).
+// (8 / 256 = 3 %) and no more (round 3: a CU-masked stream broke the exact fit of the grid: +55 %).
 int comm_cus_reserved(int cus, int ranks) {
     const char *v = getenv("SDPA_COMM_CUS");
     int want = (v && *v) ? atoi(v) : (ranks > 1 ? 8 : 0);
@@ -743,6 +745,8 @@ struct Call {
     std::atomic<int> failed{0};                    // first error of any thread
     double first_kernel_us[sdpa::kMaxRanks] = {};  // entry -> rank g's first fused launch enqueued (host clock)
     int n_brackets = 0, last_splits = 1;           // rank 0's enqueue thread only
+    int last_rows = 0, last_keys = 0;              // shape of rank 0's last fused launch
+    bool tail_marked = false;                      // the last batch's collective tail recorded root.ev_tail[0..3]
     Call() { for (auto &e : enq) e.store(0); }
     int fail(int code) {
         int none = 0;
@@ -962,7 +966,11 @@ int rank_batch(Call &c, int g, int b) {
             SDPA_TRY(launch_fused(pl, rk, rp, s, bs, j0, jr, k0, keys, sp, slot0));
             SDPA_TRY(bracket());
             if (c.first_kernel_us[g] == 0.0) c.first_kernel_us[g] = now_us() - c.t_enter;
-            if (g == 0) c.last_splits = sp;
+            if (g == 0) {
+                c.last_splits = sp;
+                c.last_rows = jr;
+                c.last_keys = keys;
+            }
             if (last) {
                 if (streamed) SDPA_TRY(merge_slots(pl, rk, rp, s, bs, j0, jr));
                 if (finisher) SDPA_TRY(finish_rows(in_pieces ? j : 0, j0, jr));
@@ -993,6 +1001,15 @@ int tail_batch(Call &c, int b) {
         HIP_TRY(hipStreamWaitEvent(rk.s_comm, rk.ev_run[s], 0));     // the rank's partial triple of batch b
         if (b >= 2) HIP_TRY(hipStreamWaitEvent(rk.s_comm, rk.ev_out[s], 0));   // out64[s] of batch b-2 still leaving
     }
+    // rank 0, last batch: where the tail's time goes (sdpa_timing.merge_us / reduce_us / egress_us)
+    const bool mark = b == pl.nb - 1;
+    auto mark_tail = [&](int i) -> int {
+        if (!mark) return SDPA_OK;
+        HIP_TRY(hipSetDevice(root.dev));
+        HIP_TRY(hipEventRecord(root.ev_tail[i], root.s_comm));
+        return SDPA_OK;
+    };
+    SDPA_TRY(mark_tail(0));
     if (pl.merge_allreduce) {
         // :342 gmax = allreduce MAX(lmax); :346-351 rescale; :354 gsum = allreduce SUM(lsum);
         // :358-362 normalise
@@ -1031,8 +1048,10 @@ int tail_batch(Call &c, int b) {
                                                 P, g, bs, dv, rk.s_comm));
         }
     }
+    SDPA_TRY(mark_tail(1));
     need_pin(c, 3);
     for (int g = 0; g < P; ++g) send[g] = (float *)E.r[g].contrib[s].p;
+    c.tail_marked = mark;
     if (pl.egress_scatter) {
         // sum of the normalised contributions, SCATTERED: rank r receives rows [r*share, (r+1)*share) of the
         // batch, widens them (:373/:396) and sends them home over its own PCIe link -- P links instead of
@@ -1040,6 +1059,7 @@ int tail_batch(Call &c, int b) {
         const int share = (bs + P - 1) / P;
         for (int g = 0; g < P; ++g) recv[g] = (float *)E.r[g].red[s].p;
         if (E.coll->reduce_scatter_sum(send.data(), recv.data(), (size_t)share * pl.ldo, comm.data())) return coll_fail();
+        SDPA_TRY(mark_tail(2));
         for (int g = 0; g < P; ++g) {
             Rank &rk = E.r[g];
             const int r0 = g * share, rows = std::min(share, bs - r0);
@@ -1047,6 +1067,7 @@ int tail_batch(Call &c, int b) {
             if (rows > 0)
                 HIP_TRY(sdpa::launch_cvt_f2d((const float *)rk.red[s].p, pl.ldo, (double *)rk.out64[s].p, rows, dv,
                                              rk.s_comm));
+            if (g == 0 && mark) HIP_TRY(hipEventRecord(root.ev_tail[3], root.s_comm));
             HIP_TRY(hipEventRecord(rk.ev_comm[s], rk.s_comm));
             HIP_TRY(hipStreamWaitEvent(rk.s_out, rk.ev_comm[s], 0));
             if (rows > 0)
@@ -1058,9 +1079,11 @@ int tail_batch(Call &c, int b) {
         // :380 reduce(SUM) of the normalised contributions to rank 0, :373/:396 widen, D2H
         if (E.coll->reduce_sum_to_root(send.data(), (float *)root.red[s].p, (size_t)bs * pl.ldo, comm.data()))
             return coll_fail();
+        SDPA_TRY(mark_tail(2));
         HIP_TRY(hipSetDevice(root.dev));
         HIP_TRY(sdpa::launch_cvt_f2d((const float *)root.red[s].p, pl.ldo, (double *)root.out64[s].p, bs, dv,
                                      root.s_comm));
+        SDPA_TRY(mark_tail(3));
         for (int g = 0; g < P; ++g) {
             HIP_TRY(hipSetDevice(E.r[g].dev));
             HIP_TRY(hipEventRecord(E.r[g].ev_comm[s], E.r[g].s_comm));
@@ -1124,11 +1147,29 @@ int ensure_host_converter() {
     return E.hc ? SDPA_OK : SDPA_ENOMEM;
 }
 
+// The lazy default (no sdpa_init, no $SDPA_GPUS): EVERY visible device, as the reference uses every rank it is
+// given (attention-mpi.c:199) -- on the evidence of this very node: creating the engine on P > 1 devices runs
+// every collective of the pipeline once over RCCL on known data (sdpa_coll.hip: selftest).  Passed: P GPUs.
+// Failed with an error: one line on stderr and ONE GPU (the round-3 default).  Did not finish (a transport
+// that hangs): SDPA_ERCCL with the advice to set SDPA_GPUS=1 -- the devices may still hold its kernels.
 int lazy_init() {
     if (E.up) return SDPA_OK;
-    int want = 1;                       // several GPUs from one process is opt-in
-    if (const char *env = getenv("SDPA_GPUS")) want = strcmp(env, "all") == 0 ? 0 : atoi(env);
-    return sdpa_init(want < 0 ? 1 : want);
+    if (const char *env = getenv("SDPA_GPUS")) {
+        const int want = (strcmp(env, "all") == 0 || strcmp(env, "0") == 0) ? 0 : atoi(env);
+        return sdpa_init(want < 0 ? 1 : want);
+    }
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) (void)hipGetLastError();
+    if (cnt <= 1 || getenv("SDPA_VIRTUAL_GPUS")) return sdpa_init(1);
+    const int rc = sdpa_init(cnt > sdpa::kMaxRanks ? sdpa::kMaxRanks : cnt);
+    if (rc == SDPA_OK) return rc;
+    if (E.rccl_hung) {
+        fprintf(stderr, "sdpa: the RCCL self-test over %d GPUs did not finish; set SDPA_GPUS=1 to run on one GPU\n", cnt);
+        return rc;
+    }
+    fprintf(stderr, "sdpa: engine on all %d visible GPUs failed (%s); using ONE GPU (SDPA_GPUS=N forces a count)\n", cnt,
+            sdpa_strerror(rc));
+    return sdpa_init(1);
 }
 
 int check_shape(const void *Q, const void *K, const void *V, const void *result, int m, int n, int dk,
@@ -1172,7 +1213,7 @@ void destroy_rank(Rank &g) {
     for (hipEvent_t e : g.ev_qh) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : g.ev_qp) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : g.ev_k) (void)hipEventDestroy(e);
-    hipEvent_t evs[] = {g.ev_t0, g.ev_kv_done, g.ev_end};
+    hipEvent_t evs[] = {g.ev_t0, g.ev_kv_done, g.ev_end, g.ev_tail[0], g.ev_tail[1], g.ev_tail[2], g.ev_tail[3]};
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     if (g.s_cp) (void)hipStreamDestroy(g.s_cp);
     if (g.s_in) (void)hipStreamDestroy(g.s_in);
@@ -1221,6 +1262,7 @@ int create_rank(Rank &g, int dev, int reserve) {
     HIP_TRY(hipEventCreate(&g.ev_t0));
     HIP_TRY(hipEventCreate(&g.ev_kv_done));
     HIP_TRY(hipEventCreate(&g.ev_end));
+    for (hipEvent_t &e : g.ev_tail) HIP_TRY(hipEventCreate(&e));
     return SDPA_OK;
 }
 
@@ -1267,7 +1309,7 @@ int init_impl(int n_gpus) {
         } else {
             std::vector<int> devs(want);
             for (int i = 0; i < want; ++i) devs[i] = i;
-            E.coll = sdpa::make_rccl_collectives(want, devs.data());
+            E.coll = sdpa::make_rccl_collectives(want, devs.data(), &E.rccl_hung);
         }
         if (!E.coll) return SDPA_ERCCL;
     }
@@ -1321,6 +1363,14 @@ int sdpa_init(int n_gpus) {
     }
     return rc;
 }
+
+int sdpa_init_default(void) {
+    sdpa::reload_launch_knobs();
+    DeviceRestore restore;
+    return lazy_init();
+}
+
+int sdpa_engine_ranks(void) { return E.up ? E.n : 0; }
 
 int sdpa_last_timing_sized(struct sdpa_timing *out, size_t size) {
     if (!out || size == 0) return SDPA_EINVAL;
@@ -1540,6 +1590,19 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
     T.egress = !pl.collectives ? 0 : (pl.egress_scatter ? 2 : 1);
     T.enqueue_threads = c.threaded ? P : 1;
     T.host_convert_threads = c.hostcvt ? E.hc->threads() : 0;
+    T.compute_cus = pl.cus;
+    T.stream_k = (!pl.bf16 && c.last_keys > 0 &&
+                  sdpa::plan_f32_launch(c.last_rows, c.last_keys, dk, dv, pl.cus).streamk) ? 1 : 0;
+    T.host_widen = 0;
+    T.rccl_selftest = E.coll ? E.coll->selftested_ranks() : 0;
+    if (c.tail_marked) {
+        HIP_TRY(hipEventElapsedTime(&ms, root.ev_tail[0], root.ev_tail[1]));
+        T.merge_us = ms * 1e3;
+        HIP_TRY(hipEventElapsedTime(&ms, root.ev_tail[1], root.ev_tail[2]));
+        T.reduce_us = ms * 1e3;
+        HIP_TRY(hipEventElapsedTime(&ms, root.ev_tail[2], root.ev_end));
+        T.egress_us = ms * 1e3;
+    }
     return SDPA_OK;
 }
 

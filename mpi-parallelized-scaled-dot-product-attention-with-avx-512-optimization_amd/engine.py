@@ -287,10 +287,14 @@ class ShardedAttention:
     single rank)."""
 
     def __init__(self, backend, rank=0, world=1, dist=None, group=None, root=0, force_collectives=False,
-                 precision="f32", merge="allreduce"):
-        assert precision in ("f32", "bf16") and merge in ("allreduce", "gather")
+                 precision="f32", merge="allreduce", egress="root"):
+        assert precision in ("f32", "bf16") and merge in ("allreduce", "gather") and egress in ("root", "scatter")
         self.precision = precision
         self.merge = merge        # "allreduce": the reference's two-phase merge; "gather": one all-gather
+        # how the merged rows of a batch leave (batch_merge_egress): "root" = reduce to the root
+        # (attention-mpi.c:380); "scatter" = reduce-scatter, rank r keeps rows [r*share, (r+1)*share) of the batch
+        # and widens them itself -- the C host's default schedule (csrc/sdpa_host.hip: tail_batch)
+        self.egress = egress
         self.be = backend
         self.rank, self.world, self.root = rank, world, root
         self.dist = dist if (world > 1 or force_collectives) else None
@@ -391,6 +395,68 @@ class ShardedAttention:
         work = dist.reduce(contrib, dst=self.root, op=dist.ReduceOp.SUM, group=self.group,
                            async_op=async_reduce)                         # :380
         return contrib, work
+
+    def _merge_stats(self, contrib, lmax, lsum, marks=None):
+        """Steps 2-5 of the reference loop (attention-mpi.c:340-362) in place on `contrib`: the statistics collective(s)
+        and the merge kernel(s).  marks = (after the collective, after the merge kernel, ...) HIP events, optional."""
+        be, dist = self.be, self.dist
+        if self.merge == "gather":
+            mine = torch.stack((lmax, lsum))                              # [2, m]
+            stats = be.empty((self.world if self.world > 1 else 1, 2, lmax.shape[0]), torch.float32)
+            dist.all_gather_into_tensor(stats.view(-1, lmax.shape[0]), mine, group=self.group)
+            if marks:
+                marks[0].record()
+            be.merge_gathered(contrib, stats, self.rank if self.world > 1 else 0, self.dv)   # :342-362
+        else:
+            gmax = lmax.clone()
+            dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=self.group)     # :342
+            be.merge_rescale(contrib, lsum, lmax, gmax, self.dv)              # :346-351
+            gsum = lsum.clone()
+            dist.all_reduce(gsum, op=dist.ReduceOp.SUM, group=self.group)     # :354
+            if marks:
+                marks[0].record()
+            be.merge_normalise(contrib, gsum, self.dv)                        # :358-362
+        if marks:
+            marks[1].record()
+
+    def batch_merge_egress(self, contrib, lmax, lsum, async_reduce=False, marks=None):
+        """batch_merge with the egress this object was created with.  Returns (rows, work, nrows): once `work`
+        (if any) has completed, `rows[:nrows]` holds normalised, shard-summed fp32 rows --
+          egress "root":    all rows of the batch on the root (nrows = rows of the batch; elsewhere the tensor is
+                            this rank's send buffer),
+          egress "scatter": rows [rank*share, rank*share + nrows) of the batch on EVERY rank, share = ceil(bs / world):
+                            ncclReduceScatter instead of ncclReduce -- each rank then widens and owns its share
+                            (the C host sends them home over P PCIe links, sdpa_host.hip:tail_batch)."""
+        be, dist = self.be, self.dist
+        bs = contrib.shape[0]
+        if dist is None:
+            be.merge_normalise(contrib, lsum, self.dv)
+            if marks:
+                for mk in marks:
+                    mk.record()
+            return contrib, None, bs
+        self._merge_stats(contrib, lmax, lsum, marks)
+        if self.egress == "root":
+            work = dist.reduce(contrib, dst=self.root, op=dist.ReduceOp.SUM, group=self.group,
+                               async_op=async_reduce)                         # :380
+            if marks:
+                marks[2].record()
+            return contrib, work, bs
+        world = self.world if self.world > 1 else 1
+        share = (bs + world - 1) // world
+        send = contrib
+        if share * world != bs:                       # pad to P equal shares (the C host's contrib buffers carry +P rows)
+            send = be.empty((share * world, contrib.shape[1]), torch.float32)
+            send[:bs] = contrib
+            send[bs:].zero_()
+        out = be.empty((share, contrib.shape[1]), torch.float32)
+        work = dist.reduce_scatter_tensor(out, send, op=dist.ReduceOp.SUM, group=self.group, async_op=async_reduce)
+        if marks:
+            marks[2].record()
+        r0 = (self.rank if self.world > 1 else 0) * share
+        # (`send` must outlive the collective: keep it referenced by the returned tensor's owner)
+        out._sdpa_send_keepalive = send
+        return out, work, max(0, min(share, bs - r0))
 
     def forward_batches(self, q_batches):
         """Run a sequence of fp32 Q batches (each already on every rank) through partial + merge,

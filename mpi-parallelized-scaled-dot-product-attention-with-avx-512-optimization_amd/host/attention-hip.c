@@ -15,7 +15,8 @@
  *                                                     double*,int,int,int,int)
  *
  * Built by gcc; sees nothing but the C header.  Environment:
- *   SDPA_GPUS=N        GPUs to shard K/V over (default 1; 0 or "all" = every visible device)
+ *   SDPA_GPUS=N        GPUs to shard K/V over (0 or "all" = every visible device; default: every visible
+ *                      device when the RCCL self-test passes on this node, else 1)
  *   SDPA_PLAN=qrows    shard the query rows instead (K/V replicated, no merge collective)
  *   SDPA_MERGE=allreduce  the reference's literal two all-reduces instead of one all-gather
  *   SDPA_TIME_INIT=1   create and size the engine inside the timed region (default: before
@@ -55,7 +56,7 @@ int main(int argc, char **argv)
      * (attention.c:102-114) */
     if (!time_init) {
         precheck_file(argv[1]);
-        die_if(sdpa_init(gpus_from_env()), "sdpa_init");
+        die_if(cli_engine_up(), "sdpa_init");
         note_unused_gpus();
         const char *pin = getenv("SDPA_PINNED_IO");
         use_pinned = !(pin && pin[0] == '0');

@@ -67,7 +67,7 @@ int main(int argc, char **argv)
          * attention-hip.c */
         if (!time_init) {
             precheck_file(argv[1]);
-            die_if(sdpa_init(gpus_from_env()), "sdpa_init");
+            die_if(cli_engine_up(), "sdpa_init");
             note_unused_gpus();
             if (size > 1)       /* the reference would compute on every rank; here they wait */
                 fprintf(stderr, "%s: %d MPI ranks: rank 0 drives the GPU(s), ranks 1..%d only take part in the "

@@ -223,7 +223,7 @@ static bool check_answer(const char *path, const double *result, double *worst, 
 static void report_verbose(int m, int n, int dk, int dv, double worst)
 {
     struct sdpa_timing t;
-    if (sdpa_last_timing(&t) != SDPA_OK) return;
+    if (sdpa_last_timing_sized(&t, sizeof t) != SDPA_OK) return;
     fprintf(stderr,
             "%s: m=%d n=%d dk=%d dv=%d gpus=%d%s plan=%s merge=%s q_batches=%d kv_chunks=%d fused_launches=%d kv_splits=%d\n"
             "%s: total %.1f us | head %.1f us (page-lock %.1f) | fused kernels %.1f us | tail %.1f us | kv stage (overlapped) %.1f us\n"
@@ -234,26 +234,28 @@ static void report_verbose(int m, int n, int dk, int dv, double worst)
             t.kv_stage_us, cli_name, worst);
 }
 
-/* GPUs to drive: $SDPA_GPUS (a count, or 0 / "all" for every visible device); without it ONE --
- * several GPUs from one process is opt-in */
-static int gpus_from_env(void)
+/* The engine on the GPUs this run drives: $SDPA_GPUS (a count, or 0 / "all"), otherwise the library's default --
+ * every visible device once its RCCL transport has passed the known-answer self-test on this node, ONE GPU
+ * when that test fails (sdpa_init_default(), include/sdpa_hip.h); like the reference, which uses every rank it
+ * is given (attention-mpi.c:199).  Also checks that the library is the one this host was compiled against. */
+static int cli_engine_up(void)
 {
-    const char *g = getenv("SDPA_GPUS");
-    if (!g || !*g) return 1;
-    if (g[0] == 'a') return 0;
-    return atoi(g) < 0 ? 1 : atoi(g);
+    if (sdpa_abi_version() != SDPA_ABI_VERSION) {
+        fprintf(stderr, "%s: libsdpa_hip.so has ABI %d, this host was built for %d\n", cli_name, sdpa_abi_version(),
+                SDPA_ABI_VERSION);
+        return SDPA_EINVAL;
+    }
+    return sdpa_init_default();
 }
 
 /* One line on stderr when the node has more GPUs than this run drives (stdout is the graded
- * channel and stays untouched).  The default is ONE GPU: driving several from this process is
- * opt-in (include/sdpa_hip.h, sdpa_init). */
+ * channel and stays untouched). */
 static void note_unused_gpus(void)
 {
-    const int visible = sdpa_device_count();
-    const char *g = getenv("SDPA_GPUS");
-    if (visible > 1 && (!g || !*g) && !getenv("SDPA_VIRTUAL_GPUS"))
-        fprintf(stderr, "%s: %d GPUs visible, using 1 (SDPA_GPUS=%d or SDPA_GPUS=all drives them all)\n", cli_name,
-                visible, visible);
+    const int visible = sdpa_device_count(), used = sdpa_engine_ranks();
+    if (visible > 1 && used < visible && !getenv("SDPA_VIRTUAL_GPUS"))
+        fprintf(stderr, "%s: %d GPUs visible, using %d (SDPA_GPUS=%d or SDPA_GPUS=all drives them all)\n", cli_name,
+                visible, used, visible);
 }
 
 #endif /* SDPA_CLI_H */

@@ -102,10 +102,12 @@ def test_traffic_stamp_names_the_shipped_kernel_sources():
     head = entries.get("headline/f32")
     got = bench.pmc_stamp("headline", "f32")
     if head is None or head["kernel_src_sha16"] != stamp:
-        assert got == {"traffic": None, "hbm_gbps": None, "mfma_util": None}
+        assert got == {"traffic": None, "hbm_gbps": None, "mfma_util": None, "provenance": None}
         pytest.skip("profiles/traffic_latest.json was measured on older kernel sources: bench.py prints "
                     "traffic: null until tools/gpu_profile.sh has been re-run")
     assert got["traffic"] == head["per_launch_bytes"]
+    # the figures are copied from a committed profile, and the line says so next to them
+    assert got["provenance"]["file"] == "profiles/traffic_latest.json" and got["provenance"]["kernel_src_sha16"] == stamp
     assert bench.pmc_stamp("config1", "f32")["traffic"] is None          # never profiled: never quoted
 
 

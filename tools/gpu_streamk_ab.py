@@ -1,5 +1,5 @@
 """Stream-K work distribution of the fp32 pipelined kernels against the classic equal-split grid (round 4).
-Per shape and stream (whole chip / CU-masked with 8 or 16 CUs left out): kernel + split-merge ms per launch with
+Per shape and stream (whole chip / 8 or 16 CUs reserved by grid size / 8 reserved by CU mask, round 3's way): kernel + split-merge ms per launch with
 $SDPA_STREAMK=0 (classic), =1 (stream-K forced), unset (the cost model's choice), the slab counts, whether the
 triples equal the classic ones bit for bit, and the error of 48 rows against the fp64 restatement.
     python tools/gpu_streamk_ab.py [quick]"""
@@ -17,18 +17,21 @@ quick = "quick" in sys.argv
 shapes = [(32768, 65536, 128), (33000, 65536, 128), (40000, 65536, 128), (32768, 8192, 128), (8192, 8192, 128),
           (8320, 8192, 128), (32768, 65536, 64), (32768, 32768, 256), (131072, 16384, 128), (4096, 262144, 128)]
 if quick:
-    shapes = shapes[:3]
+    shapes = [shapes[0], shapes[1], shapes[3], shapes[4]]
 
 
-def masked_stream(reserve):
+def reserving_stream(reserve, by_mask=False):
+    """sdpa_dev_stream_create(reserve): the reservation by grid size (round 4) or, for A/B, by CU mask (round 3)"""
     if reserve == 0:
         return torch.cuda.Stream(device=dev)
+    os.environ["SDPA_RESERVE_BY_MASK"] = "1" if by_mask else "0"
     sp = ctypes.c_void_p()
     pkg._lib.check(lib.sdpa_dev_stream_create(reserve, ctypes.byref(sp)), "sdpa_dev_stream_create")
+    os.environ.pop("SDPA_RESERVE_BY_MASK", None)
     return torch.cuda.ExternalStream(sp.value, device=dev)
 
 
-streams = {0: masked_stream(0), 8: masked_stream(8), 16: masked_stream(16)}
+streams = {"0": reserving_stream(0), "8": reserving_stream(8), "16": reserving_stream(16), "8 (CU mask)": reserving_stream(8, True)}
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 rng = np.random.default_rng(3)
 for m, n, d in shapes:
@@ -42,7 +45,7 @@ for m, n, d in shapes:
     qf = sa.convert_q(Q)
     torch.cuda.synchronize()
     base = None
-    for reserve in (0, 8, 16):
+    for reserve in streams:
         st = streams[reserve]
         for knob in ("0", "1", None):
             if knob is None:
