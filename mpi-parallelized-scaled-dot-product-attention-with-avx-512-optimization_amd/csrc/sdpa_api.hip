@@ -117,6 +117,18 @@ int sdpa_abi_version(void) { return SDPA_ABI_VERSION; }
 
 void sdpa_reload_env(void) { sdpa::reload_launch_knobs(); }
 
+// audit builds (-DSDPA_DMA_ASSERT on the kernel translation units, tools/build_variant.sh): out[0] = source addresses
+// of LDS-DMA pieces / clamped fragment loads found outside their operand image, out[1] = audited launches; both 0
+// in the shipped library.  Not in include/sdpa_hip.h: a debugging hook for tests/conftest.py and tools/.
+SDPA_API int sdpa_debug_dma_audit(unsigned long long out[2]) {
+    unsigned long long a[2], b[2];
+    sdpa::dma_audit_read_bf16(a);
+    sdpa::dma_audit_read_dksplit(b);
+    out[0] = a[0] + b[0];
+    out[1] = a[1] + b[1];
+    return SDPA_OK;
+}
+
 const char *sdpa_strerror(int code) {
     switch (code) {
         case SDPA_OK:     return "ok";

@@ -33,7 +33,24 @@
 #include <atomic>
 #include <type_traits>
 
+SDPA_AUDIT_COUNTER(g_bf16_audit)
+
 namespace sdpa {
+
+#ifdef SDPA_DMA_ASSERT
+// a DMA source of 16 bytes must lie inside the K image or inside the Vt image of the launch
+__device__ inline void bf16_audit_src(const Bf16Args &a, const char *src) {
+    const char *k0 = reinterpret_cast<const char *>(a.K), *k1 = k0 + (size_t)a.n_local * a.ldk * 2;
+    const int ch = a.dv <= 64 ? 64 : a.dv <= 128 ? 128 : a.dv <= 256 ? 256 : 512;
+    const char *v0 = reinterpret_cast<const char *>(a.Vt), *v1 = v0 + (size_t)((a.dv + ch - 1) / ch * ch) * a.ldvt * 2;
+    const bool in_k = src >= k0 && src + 16 <= k1, in_v = src >= v0 && src + 16 <= v1;
+    if (!(in_k || in_v) || (reinterpret_cast<unsigned long long>(src) & 15ull) != 0) atomicAdd(&g_bf16_audit[0], 1ull);
+}
+#define SDPA_BF16_AUDIT(a, src) bf16_audit_src(a, src)
+#else
+#define SDPA_BF16_AUDIT(a, src) ((void)0)
+#endif
+
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -107,6 +124,7 @@ __device__ __forceinline__ float bpin_max3(float a, float b, float c) {
 template <int DK, int DVC, int ABL = 0>
 __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_pipe_kernel(
     Bf16Args a, int kv_per_split, int n_qblocks, int n_chunks, float scale) {
+    SDPA_AUDIT_LAUNCH(g_bf16_audit);
     constexpr int NKS = DK / 16;               // QK^T k-steps = MFMAs per score tile
     constexpr int NT = DVC / 32;
     constexpr int KCH = DK / 8;                // 16-byte chunks per K row
@@ -186,6 +204,7 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
     const unsigned lds_base = __builtin_amdgcn_readfirstlane(
         (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)smem16);
     auto dma_piece = [&](const char *gbase, unsigned lane_off, unsigned lds_byte) __attribute__((always_inline)) {
+        SDPA_BF16_AUDIT(a, gbase + lane_off);
         if constexpr (ABL & 1) return;
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\t"
@@ -552,6 +571,7 @@ __device__ __forceinline__ float halfwave_max(float x) {
 template <int DK, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
     Bf16Args a, int kv_per_split, int n_qblocks, int n_chunks, float scale) {
+    SDPA_AUDIT_LAUNCH(g_bf16_audit);
     constexpr int DVC = 512;
     constexpr int NKS = DK / 16;               // QK^T k-steps = MFMAs per score tile
     constexpr int NT = DVC / 32;               // 32-row blocks of O^T
@@ -622,6 +642,7 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
     // the single wave of a SIMD counts in this kernel.  One independent instruction has to sit
     // between the M0 write and the load that reads it (s_nop, or the address XOR below).
     auto dma_piece = [&](const char *gbase, unsigned lane_off, unsigned lds_byte) __attribute__((always_inline)) {
+        SDPA_BF16_AUDIT(a, gbase + lane_off);
         if constexpr (ABL & 1) return;
         asm volatile("s_mov_b32 m0, %1\n\t"
                      "s_nop 0\n\t"
@@ -632,6 +653,7 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
     };
     // same, lane offset = lane_part ^ swz computed in the wait slot
     auto dma_piece_xor = [&](const char *gbase, unsigned lane_part, unsigned swz, unsigned lds_byte) __attribute__((always_inline)) {
+        SDPA_BF16_AUDIT(a, gbase + (lane_part ^ swz));
         if constexpr (ABL & 1) return;
         unsigned off;
         asm volatile("s_mov_b32 m0, %2\n\t"
@@ -921,6 +943,7 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
 template <int DK>
 __global__ __launch_bounds__(256, 1) void fused_bf16_tandem_kernel(
     Bf16Args a, int kv_per_split, int n_qblocks, int n_chunks, float scale) {
+    SDPA_AUDIT_LAUNCH(g_bf16_audit);
     constexpr int DVC = 512;                   // value columns per workgroup (one chunk)
     constexpr int NKS = DK / 16;               // QK^T k-steps = MFMAs per score tile
     constexpr int NTW = 8;                     // 32-column blocks of O^T per wave (256 of the chunk's 512 columns)
@@ -988,6 +1011,7 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_tandem_kernel(
     const unsigned lds_base = __builtin_amdgcn_readfirstlane(
         (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)smem16);
     auto dma_piece = [&](const char *gbase, unsigned lane_off, unsigned lds_byte) __attribute__((always_inline)) {
+        SDPA_BF16_AUDIT(a, gbase + lane_off);
         asm volatile("s_mov_b32 m0, %1\n\t"
                      "s_nop 0\n\t"
                      "global_load_lds_dwordx4 %0, %2"
@@ -996,6 +1020,7 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_tandem_kernel(
                      : "memory" SDPA_M0_CLOBBER);
     };
     auto dma_piece_xor = [&](const char *gbase, unsigned lane_part, unsigned swz, unsigned lds_byte) __attribute__((always_inline)) {
+        SDPA_BF16_AUDIT(a, gbase + (lane_part ^ swz));
         unsigned off;
         asm volatile("s_mov_b32 m0, %2\n\t"
                      "v_xor_b32 %0, %3, %1\n\t"
@@ -1330,6 +1355,7 @@ struct DuoCfg {
 template <int DK, int DV>
 __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
     Bf16Args a, int kv_per_split, int n_qblocks, int n_qblocks128, float scale) {
+    SDPA_AUDIT_LAUNCH(g_bf16_audit);
     constexpr int NKS = DK / 16;               // QK^T k-steps: MFMAs per score tile and block
     constexpr int NT = DV / 32;                // 32-row blocks of O^T per query block
     constexpr int KCH = DK / 8;                // 16-byte chunks per K row
@@ -1424,6 +1450,7 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
     const unsigned lds_base = __builtin_amdgcn_readfirstlane(
         (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)smem16);
     auto dma_piece = [&](const char *gbase, unsigned lane_off, unsigned lds_byte) __attribute__((always_inline)) {
+        SDPA_BF16_AUDIT(a, gbase + lane_off);
         if constexpr (SDPA_DUO_ABL & 4) return;
         asm volatile("s_mov_b32 m0, %1\n\t"
                      "s_nop 0\n\t"
@@ -2072,6 +2099,14 @@ hipError_t launch_cvt_bf_t_part(const unsigned short *src, unsigned short *dst, 
 hipError_t launch_cvt_d2bf_t(const double *src, unsigned short *dst, long rows, int cols,
                              int cols_pad, long ldt, hipStream_t s) {
     return launch_cvt_d2bf_t_part(src, dst, rows, ldt, cols, cols_pad, ldt, s);
+}
+
+void dma_audit_read_bf16(unsigned long long out[2]) {
+    out[0] = out[1] = 0;
+#ifdef SDPA_DMA_ASSERT
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bf16_audit), 2 * sizeof(unsigned long long));
+#endif
 }
 
 }  // namespace sdpa

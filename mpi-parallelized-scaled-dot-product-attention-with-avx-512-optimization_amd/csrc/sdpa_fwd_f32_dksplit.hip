@@ -10,6 +10,8 @@
 #include <algorithm>
 #include <type_traits>
 
+SDPA_AUDIT_COUNTER(g_dks_audit)
+
 namespace sdpa {
 
 // ---------------------------------------------------------------------------
@@ -36,6 +38,7 @@ namespace sdpa {
 template <int DKS, int DVS, int QB>
 __global__ __launch_bounds__(256, 1) void fused_dksplit_kernel(
     PartialArgs a, int kv_per_split, int n_qblocks, int n_chunks, float scale) {
+    SDPA_AUDIT_LAUNCH(g_dks_audit);
     // DKS: dk slice of one wave (dk is treated as padded to 4*DKS = 256, 384, 512, 768 or 1024)
     static_assert(QB == 1 || QB == 2, "one or two query blocks");
     constexpr int ROWS = 32 * QB;
@@ -131,11 +134,11 @@ __global__ __launch_bounds__(256, 1) void fused_dksplit_kernel(
         for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }     // (s1: second block only, dead for QB = 1)
         f32x4 kq[PD];
 #pragma unroll
-        for (int i = 0; i < PD; ++i) kq[i] = *reinterpret_cast<const f32x4 *>(kb + (krow + kcolb(i)));
+        for (int i = 0; i < PD; ++i) kq[i] = *reinterpret_cast<const f32x4 *>(SDPA_AUDITED_PTR(g_dks_audit, kb + (krow + kcolb(i)), 16, a.K, a.K + (size_t)a.n_local * a.ldk));
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const f32x4 kf = kq[u % PD];
-            if (u + PD < NU) kq[u % PD] = *reinterpret_cast<const f32x4 *>(kb + (krow + kcolb(u + PD)));
+            if (u + PD < NU) kq[u % PD] = *reinterpret_cast<const f32x4 *>(SDPA_AUDITED_PTR(g_dks_audit, kb + (krow + kcolb(u + PD)), 16, a.K, a.K + (size_t)a.n_local * a.ldk));
             __builtin_amdgcn_sched_barrier(0);
             s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[0][u].x, s0, 0, 0, 0);
             if constexpr (QB == 2) s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[QB - 1][u].x, s1, 0, 0, 0);
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(256, 1) void fused_dksplit_kernel(
 #pragma unroll
         for (int i = 0; i < PD; ++i)
             vq[i] = VRun<NT>::load(reinterpret_cast<const float *>(
-                vb + ((unsigned)min(crow(i, 0) + 4 * hi, last) * (unsigned)a.ldv * 4u + vcolb)));
+                SDPA_AUDITED_PTR(g_dks_audit, vb + ((unsigned)min(crow(i, 0) + 4 * hi, last) * (unsigned)a.ldv * 4u + vcolb), NT * 4, a.V, a.V + (size_t)a.n_local * a.ldv)));
 
         // ---- exchange: every wave ends up with the same full S^T (fixed summation order)
         float *xb = smem + (t & 1) * XBUF;
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(256, 1) void fused_dksplit_kernel(
             const VRun<NT> vf = vq[r % PD];
             if (r + PD < 16)
                 vq[r % PD] = VRun<NT>::load(reinterpret_cast<const float *>(
-                    vb + ((unsigned)min(crow(r + PD, 0) + 4 * hi, last) * (unsigned)a.ldv * 4u + vcolb)));
+                SDPA_AUDITED_PTR(g_dks_audit, vb + ((unsigned)min(crow(r + PD, 0) + 4 * hi, last) * (unsigned)a.ldv * 4u + vcolb), NT * 4, a.V, a.V + (size_t)a.n_local * a.ldv)));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
@@ -300,6 +303,7 @@ __device__ __forceinline__ void static_for(F &&f) {
 template <int DKS, int DVS, int QB>
 __global__ __launch_bounds__(256, 1) void fused_dksplit_pipe_kernel(
     PartialArgs a, int kv_per_split, int n_qblocks, int n_chunks, float scale) {
+    SDPA_AUDIT_LAUNCH(g_dks_audit);
     static_assert(QB == 1 || QB == 2, "one or two query blocks");
     constexpr int ROWS = 32 * QB;
     constexpr int NU = DKS / 8;
@@ -396,7 +400,7 @@ __global__ __launch_bounds__(256, 1) void fused_dksplit_pipe_kernel(
         const char *kb = reinterpret_cast<const char *>(a.K + (size_t)base * a.ldk);
         const unsigned krow = (unsigned)min(li, last) * (unsigned)a.ldk * 4u;
 #pragma unroll
-        for (int i = 0; i < PD; ++i) kq[i] = *reinterpret_cast<const f32x4 *>(kb + (krow + kcolb(i)));
+        for (int i = 0; i < PD; ++i) kq[i] = *reinterpret_cast<const f32x4 *>(SDPA_AUDITED_PTR(g_dks_audit, kb + (krow + kcolb(i)), 16, a.K, a.K + (size_t)a.n_local * a.ldk));
     };
     // ---- A: partial S^T of tile `tile` over this wave's dk slice -> n0 / n1 (first_k(tile) went out a phase ago)
     auto partial_scores = [&](int tile) __attribute__((always_inline)) {
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(256, 1) void fused_dksplit_pipe_kernel(
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const f32x4 kf = kq[u % PD];
-            if (u + PD < NU) kq[u % PD] = *reinterpret_cast<const f32x4 *>(kb + (krow + kcolb(u + PD)));
+            if (u + PD < NU) kq[u % PD] = *reinterpret_cast<const f32x4 *>(SDPA_AUDITED_PTR(g_dks_audit, kb + (krow + kcolb(u + PD)), 16, a.K, a.K + (size_t)a.n_local * a.ldk));
             __builtin_amdgcn_sched_barrier(0);
             n0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[0][u].x, u == 0 ? zero : n0, 0, 0, 0);
             if constexpr (QB == 2) n1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[QB - 1][u].x, u == 0 ? zero : n1, 0, 0, 0);
@@ -440,7 +444,7 @@ __global__ __launch_bounds__(256, 1) void fused_dksplit_pipe_kernel(
 #pragma unroll
         for (int i = 0; i < PD; ++i)
             vq[i] = VRun<NT>::load(reinterpret_cast<const float *>(
-                vb + ((unsigned)min(crow(i, 0) + 4 * hi, last) * (unsigned)a.ldv * 4u + vcolb)));
+                SDPA_AUDITED_PTR(g_dks_audit, vb + ((unsigned)min(crow(i, 0) + 4 * hi, last) * (unsigned)a.ldv * 4u + vcolb), NT * 4, a.V, a.V + (size_t)a.n_local * a.ldv)));
     };
 
     // ---- the exchange sums and the online softmax of the tile in n0 / n1, in UNITS pieces (k in order)
@@ -523,7 +527,7 @@ __global__ __launch_bounds__(256, 1) void fused_dksplit_pipe_kernel(
             const VRun<NT> vf = vq[r % PD];
             if constexpr (r + PD < 16)
                 vq[r % PD] = VRun<NT>::load(reinterpret_cast<const float *>(
-                    vb + ((unsigned)min(crow(r + PD, 0) + 4 * hi, last) * (unsigned)a.ldv * 4u + vcolb)));
+                SDPA_AUDITED_PTR(g_dks_audit, vb + ((unsigned)min(crow(r + PD, 0) + 4 * hi, last) * (unsigned)a.ldv * 4u + vcolb), NT * 4, a.V, a.V + (size_t)a.n_local * a.ldv)));
             __builtin_amdgcn_sched_barrier(0);
             static_for<0, MPS>([&](auto I) __attribute__((always_inline)) {
                 constexpr int i = decltype(I)::value, tt = i / QB, qb = i % QB;
@@ -734,6 +738,14 @@ hipError_t launch_dksplit(const PartialArgs &a, hipStream_t s) {
         case 96: return launch_one<64, 96, 2>(a, s);
         default: return launch_one<64, 128, 2>(a, s);
     }
+}
+
+void dma_audit_read_dksplit(unsigned long long out[2]) {
+    out[0] = out[1] = 0;
+#ifdef SDPA_DMA_ASSERT
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dks_audit), 2 * sizeof(unsigned long long));
+#endif
 }
 
 }  // namespace sdpa

@@ -12,7 +12,41 @@
 #define SDPA_M0_CLOBBER , "m0"
 #endif
 
+// -DSDPA_DMA_ASSERT (tools/build_variant.sh, never shipped): every global source address of an LDS-DMA piece and of
+// a clamped fragment load is checked against the operand image it must lie in; a violation bumps a per-translation-
+// unit device counter that sdpa_debug_dma_audit() reads (tests/conftest.py fails the session on a non-zero count).
+// The fp32 pipelined kernel's older audit poisons its row sums instead (sdpa_fwd_f32.hip).
+#ifdef SDPA_DMA_ASSERT
+#define SDPA_AUDIT_COUNTER(name) static __device__ unsigned long long name[2] = {0ull, 0ull};
+#define SDPA_AUDIT(counter, src, bytes, lo, hi)                                                                  \
+    do {                                                                                                         \
+        const char *s_ = reinterpret_cast<const char *>(src);                                                    \
+        if (s_ < reinterpret_cast<const char *>(lo) || s_ + (bytes) > reinterpret_cast<const char *>(hi) ||      \
+            (reinterpret_cast<unsigned long long>(s_) & 3ull) != 0)                                              \
+            atomicAdd(&counter[0], 1ull);                                                                        \
+    } while (0)
+#define SDPA_AUDIT_LAUNCH(counter) do { if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&counter[1], 1ull); } while (0)
+// the pointer itself, checked on the way (expands to the bare pointer in the shipped build: same code as without it)
+__device__ inline const char *sdpa_audited_ptr(unsigned long long *counter, const char *p, unsigned bytes, const void *lo,
+                                               const void *hi) {
+    if (p < reinterpret_cast<const char *>(lo) || p + bytes > reinterpret_cast<const char *>(hi) ||
+        (reinterpret_cast<unsigned long long>(p) & 3ull) != 0)
+        atomicAdd(&counter[0], 1ull);
+    return p;
+}
+#define SDPA_AUDITED_PTR(counter, p, bytes, lo, hi) sdpa_audited_ptr(counter, p, bytes, lo, hi)
+#else
+#define SDPA_AUDITED_PTR(counter, p, bytes, lo, hi) (p)
+#define SDPA_AUDIT_COUNTER(name)
+#define SDPA_AUDIT(counter, src, bytes, lo, hi) ((void)0)
+#define SDPA_AUDIT_LAUNCH(counter) ((void)0)
+#endif
+
 namespace sdpa {
+
+// audit builds: [0] = violations, [1] = audited launches of the translation unit's kernels (0, 0 otherwise)
+void dma_audit_read_bf16(unsigned long long out[2]);
+void dma_audit_read_dksplit(unsigned long long out[2]);
 
 constexpr int kQRowsPerBlock = 128;   // 4 waves x 32 query rows
 constexpr int kKvTile        = 32;    // K/V rows per LDS tile

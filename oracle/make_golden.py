@@ -27,6 +27,13 @@ CASES = [
     ("d128_D1",        40, 160, 128, 128, "D1", 7),
 ]
 
+# mid-size cases (round 4): multi-tile, multi-split launches checked against REFERENCE bytes.
+# Only the answer block is committed; the inputs are the seeded draw (oracle.load_golden checks their sha256).
+SEEDED_CASES = [
+    ("mid_d128_D3",   256, 8192, 128, 128, "D3", 8),     # 2 query blocks x 256 K/V tiles: in-GPU splits / stream-K pieces
+    ("mid_d512_D3",   256, 8192, 512, 512, "D3", 9),     # the dk-split fp32 kernel and the bf16 tandem kernel
+]
+
 
 def main():
     if not O.RefSerial.available():
@@ -43,6 +50,17 @@ def main():
         index.append(dict(name=name, m=m, n=n, dk=dk, dv=dv, dist=dist, seed=seed,
                           file=name + ".bin", answer="reference attention.c:20-75"))
         print(name, os.path.getsize(path), "bytes")
+    import hashlib
+    for name, m, n, dk, dv, dist, seed in SEEDED_CASES:
+        Q, K, V = O.make_inputs(m, n, dk, dv, dist, seed)
+        ans = ref.attention(Q, K, V)
+        path = os.path.join(out_dir, name + ".ans.f64")
+        ans.astype("<f8").tofile(path)
+        sha = {k: hashlib.sha256(a.astype("<f8").tobytes()).hexdigest() for k, a in (("Q", Q), ("K", K), ("V", V))}
+        index.append(dict(name=name, m=m, n=n, dk=dk, dv=dv, dist=dist, seed=seed, file=None,
+                          answer_file=name + ".ans.f64", inputs="oracle.make_inputs(m, n, dk, dv, dist, seed)",
+                          inputs_sha256=sha, answer="reference attention.c:20-75"))
+        print(name, os.path.getsize(path), "bytes (answer block only)")
     with open(os.path.join(out_dir, "INDEX.json"), "w") as f:
         json.dump(index, f, indent=1)
 

@@ -158,6 +158,41 @@ def make_inputs(m, n, dk, dv, dist="D1", seed=1):
     return (np.ascontiguousarray(Q), np.ascontiguousarray(K), np.ascontiguousarray(V))
 
 
+# ---- golden cases (tests/golden/INDEX.json) -------------------------------------------------------------------
+# Two kinds.  "file": the whole case in the reference's on-disk format, inputs and reference-produced answer.
+# "answer_file" (mid-size cases, round 4): ONLY the reference-produced answer block is committed (a quarter to one
+# megabyte instead of 17-70); the inputs are the seeded make_inputs() draw named by the entry, checked against the
+# sha256 of the bytes the reference was run on.
+def golden_dir():
+    return os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def load_golden(case):
+    """(Q, K, V, answer) of one INDEX.json entry"""
+    if case.get("file"):
+        return read_case(os.path.join(golden_dir(), case["file"]))
+    import hashlib
+    Q, K, V = make_inputs(case["m"], case["n"], case["dk"], case["dv"], case["dist"], case["seed"])
+    for name, a in (("Q", Q), ("K", K), ("V", V)):
+        got = hashlib.sha256(np.ascontiguousarray(a, dtype="<f8").tobytes()).hexdigest()
+        if got != case["inputs_sha256"][name]:
+            raise RuntimeError("golden case %s: the seeded %s differs from the array the reference was run on "
+                               "(numpy's generator changed?)" % (case["name"], name))
+    ans = np.fromfile(os.path.join(golden_dir(), case["answer_file"]), dtype="<f8").reshape(case["m"], case["dv"])
+    return Q, K, V, ans
+
+
+def golden_file(case, tmp_dir):
+    """path of the case in the reference's file format (written into tmp_dir for an answer-only case)"""
+    if case.get("file"):
+        return os.path.join(golden_dir(), case["file"])
+    path = os.path.join(str(tmp_dir), case["name"] + ".bin")
+    if not os.path.exists(path):
+        Q, K, V, ans = load_golden(case)
+        write_case(path, Q, K, V, ans)
+    return path
+
+
 def write_case(path, Q, K, V, answer):
     m, dk = Q.shape
     n, dv = V.shape

@@ -55,6 +55,22 @@ def _gpu_memory_trace(request):
                 request.node.nodeid[-110:], free >> 20, total >> 20, torch.cuda.memory_reserved() >> 20))
 
 
+def pytest_sessionfinish(session, exitstatus):
+    """An audit build of the library ($SDPA_HIP_LIB=.../libsdpa_hip_audit.so, tools/build_audit.sh) counts every LDS-DMA
+    piece / clamped fragment load whose global source lies outside its operand image: report the counters, and turn
+    a clean-looking session into a failure when there were violations."""
+    mod = sys.modules.get(PKG)
+    lib = getattr(getattr(mod, "_lib", None), "_lib", None) if mod is not None else None
+    if lib is None or not hasattr(lib, "sdpa_debug_dma_audit") or "audit" not in os.environ.get("SDPA_HIP_LIB", ""):
+        return
+    import ctypes
+    out = (ctypes.c_ulonglong * 2)()
+    lib.sdpa_debug_dma_audit(out)
+    sys.__stderr__.write("\nDMA bounds audit (bf16 + dk-split kernels): %d violations in %d audited launches\n" % (out[0], out[1]))
+    if out[0]:
+        session.exitstatus = 1
+
+
 @pytest.fixture(autouse=True)
 def _launch_knob_snapshot():
     """The library reads its launch-path knobs ($SDPA_STREAMK, $SDPA_SPLIT_MERGE, ...) from ONE snapshot of the

@@ -374,3 +374,17 @@ def test_bf16_tandem_steep_scores_take_the_redo_pass(pkg, be, O):
         pkg.reload_env()
     assert np.isfinite(got).all()
     assert np.abs(got - want).max() <= bf16_tol(V)
+
+
+def test_bf16_path_on_the_mid_size_reference_golden(pkg, be, O):
+    """tests/golden/mid_d512_D3 (m = 256, n = 8192, d = 512; answer block = output of the reference's own attention(),
+    oracle/make_golden.py): the tandem kernel over 256 K/V tiles with in-GPU splits, against reference bytes at
+    the bf16 path's tolerance."""
+    import json
+    case = [c for c in json.load(open(os.path.join(O.golden_dir(), "INDEX.json"))) if c["name"] == "mid_d512_D3"][0]
+    Q, K, V, ans = O.load_golden(case)
+    got = dev_attention_bf16(pkg, be, Q, K, V)
+    assert np.isfinite(got).all()
+    err = np.abs(got - ans).max()
+    print("mid_d512_D3 bf16: max|err| %.3e (tol %.3e)" % (err, bf16_tol(V)))
+    assert err <= bf16_tol(V)

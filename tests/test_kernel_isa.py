@@ -215,3 +215,40 @@ def test_f32_stream_k_instantiation_keeps_the_classic_hot_loop(dk, dv, f32_asm):
         assert sk[op] == classic[op], (op, sk[op], classic[op])
     # the DMA pieces of the steady state (the cold ragged-tile block may be laid out inside the loop: <= 2x)
     assert classic["global_load_lds_dwordx4"] <= sk["global_load_lds_dwordx4"] <= 2 * classic["global_load_lds_dwordx4"], sk
+
+
+def _m0_uses_outside_asm(k):
+    """instructions that mention M0 outside an inline-asm block (;;#ASMSTART ... ;;#ASMEND)"""
+    inside, hits = False, []
+    for l in k:
+        if "#ASMSTART" in l:
+            inside = True
+        elif "#ASMEND" in l:
+            inside = False
+        elif not inside and re.search(r"\bm0\b", l) and re.match(r"^\t[a-z]", l):
+            hits.append(l.strip())
+    return hits
+
+
+def test_nothing_but_the_dma_asm_touches_m0(f32_asm, bf16_asm):
+    """The LDS-DMA statements write M0 (the DMA's LDS destination) and do not restore it (only the bf16 general kernel's
+    does): the asm lists M0 as clobbered, so hipcc may not keep a value of its own there.  What makes that SAFE rather
+    than assumed: in every kernel with such a statement, no compiler-generated instruction reads
+    or writes M0 at all -- there is nothing the DMA's leftover address could be mistaken for.  A compiler that starts
+    using M0 in these kernels (LDS-direct loads, s_movrel, GWS) trips this test, and build() with it."""
+    names = [(f32_asm, r"fused_pipelined_kernelILi\d+ELi\d+ELi0ELi\dELi\dE"),
+             (bf16_asm, r"fused_bf16_(wide|tandem|duo|pipe)_kernelI")]
+    seen = 0
+    for lines, pat in names:
+        for i, l in enumerate(lines):
+            m = re.match(r"^(_ZN4sdpa\S*):", l)
+            if not m or not re.search(pat, m.group(1)):
+                continue
+            end = next(j for j in range(i, len(lines)) if lines[j].startswith(".Lfunc_end"))
+            k = lines[i:end]
+            if not any("global_load_lds" in x for x in k):
+                continue
+            seen += 1
+            hits = _m0_uses_outside_asm(k)
+            assert not hits, "%s: compiler-generated M0 use beside the DMA asm: %s" % (m.group(1), hits[:4])
+    assert seen >= 12, seen          # 7 + 5 fp32 instantiations and the bf16 kernels were looked at

@@ -9,7 +9,10 @@ for f in glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursi
         rows.append((r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Stream_Id", "?")))
 rows.sort(key=lambda r: r[1])
 fused = [r for r in rows if "fused_" in r[0]]
-coll = [r for r in rows if "loop_reduce" in r[0] or "loop_gather" in r[0]]
+# the merge tail of a batch: loopback collectives (SDPA_VIRTUAL_GPUS), RCCL's kernels (ncclDevKernel_*, forced one-rank
+# communicator or real ranks), the merge kernels and the fp32 -> fp64 widening that follow them on the comm stream
+coll = [r for r in rows if any(k in r[0] for k in ("loop_reduce", "loop_gather", "nccl", "merge_gathered", "merge_rescale",
+                                                    "merge_normalise", "cvt_f2d"))]
 t0 = rows[0][1] if rows else 0
 print("%d dispatches, %d fused launches, %d collective kernels" % (len(rows), len(fused), len(coll)))
 n_over = 0
@@ -19,7 +22,7 @@ for name, a, b, st in coll:
     n_over += 1 if over else 0
     if (name, a, b, st) in tail:
         import re
-        mm = re.search(r"(loop_\w+)", name)
+        mm = re.search(r"(loop_\w+|ncclDevKernel\w*|merge_\w+|cvt_f2d\w*)", name)
         short = mm.group(1) if mm else name[:28]
         print("%-28s stream %-4s %9.1f .. %9.1f us (%6.1f us)  concurrent fused launches: %s" % (
             short, st, (a - t0) / 1e3, (b - t0) / 1e3, (b - a) / 1e3,

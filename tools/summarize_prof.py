@@ -124,6 +124,23 @@ if disp:
     for fn in srcs:                           # the fused kernels' sources (bench.py quotes the figures only for this build)
         h.update(open(os.path.join(root, "mpi-parallelized-scaled-dot-product-attention-with-avx-512-optimization_amd", "csrc", fn), "rb").read())
     entry["kernel_src_sha16"] = h.hexdigest()[:16]
+    # provenance: bench.py copies these figures into its line -- say when, where and with what they were measured
+    import datetime, subprocess
+    entry["measured"] = datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ")
+    try:
+        entry["box"] = subprocess.run("rocminfo | grep -m1 'Marketing Name' | sed 's/.*: *//'; hostname", shell=True,
+                                      capture_output=True, text=True).stdout.strip().replace("\n", " / ")
+        entry["rocm"] = open("/opt/rocm/.info/version").read().strip()
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        import ctypes
+        lib = ctypes.CDLL(os.path.join(root, "mpi-parallelized-scaled-dot-product-attention-with-avx-512-optimization_amd", "lib",
+                                       "libsdpa_hip.so"))
+        lib.sdpa_version.restype = ctypes.c_char_p
+        entry["hipcc"] = lib.sdpa_version().decode()
+    except Exception:  # noqa: BLE001
+        pass
     entry["correction"] = "FETCH_SIZE KiB x1024 x2 (gfx950 wide-read under-count) + WRITE_SIZE KiB x1024"
     entry["source"] = "tools/gpu_profile.sh: rocprofv3 --kernel-trace --stats (steady avg), --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes; python bench.py --no-boundary %s" % bench_args
     json.dump(entry, open(os.path.join(out, "traffic.json"), "w"), indent=1)
