@@ -170,6 +170,7 @@ struct Engine {
     Collectives *coll = nullptr;
     Pool pool;                           // enqueue threads, one per rank (empty with one rank)
     sdpa::HostConverter *hc = nullptr;   // $SDPA_HOST_CVT=1: fp64 -> operand images on host threads (sdpa_hostcvt.h)
+    char *bounce = nullptr;              // 8 KiB page-locked: the partial first / last page of `result` travels through here
     int run_cus = 0;                     // compute units of a rank's compute stream (create_rank)
     bool rccl_hung = false;              // the last RCCL self-test did not finish (lazy_init does not fall back then)
     sdpa_timing last = {};
@@ -213,11 +214,21 @@ int comm_cus_reserved(int cus, int ranks) {
 struct HostPins {
     std::vector<void *> ptr;
     double us = 0.0;                                        // host time spent registering
+    // Only the WHOLE PAGES inside [p, p + bytes) are registered (round 4).  A registration maps its pages into the
+    // GPU's address space at their host addresses; two caller arrays that are neighbours in the heap share the page
+    // their boundary falls in, and a page that belongs to two mappings -- ours and ours, or ours and the transient one
+    // the HIP runtime makes for an unregistered (pageable) neighbour's copy -- is unmapped for BOTH when the first of
+    // them goes away.  The one GPU memory fault this library has ever produced was a read of exactly such an
+    // address (a page-aligned HOST heap address, profiles/r04/gpu_memory_fault_on_a_host_heap_page.log).  The
+    // partial pages at the two ends are copied as pageable slivers (copy_h2d_cuts / copy_d2h_cuts split there).
+    static const char *page_up(const void *p) { return (const char *)(((uintptr_t)p + 4095) & ~(uintptr_t)4095); }
+    static const char *page_down(const void *p) { return (const char *)((uintptr_t)p & ~(uintptr_t)4095); }
     void add(const void *p, size_t bytes) {
-        if (bytes < (1u << 20)) return;                     // small ranges: not worth the call
+        const char *lo = page_up(p), *hi = page_down((const char *)p + bytes);
+        if (hi <= lo || (size_t)(hi - lo) < (1u << 20)) return;   // small ranges: not worth the call
         const double t0 = now_us();
-        if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) == hipSuccess)
-            ptr.push_back(const_cast<void *>(p));
+        if (hipHostRegister(const_cast<char *>(lo), (size_t)(hi - lo), hipHostRegisterDefault) == hipSuccess)
+            ptr.push_back(const_cast<char *>(lo));
         else
             (void)hipGetLastError();
         us += now_us() - t0;
@@ -248,9 +259,11 @@ hipError_t copy_h2d_cuts(void *dst, const void *src, size_t bytes, const std::ve
     return hipMemcpyAsync(d0, s0, (size_t)(end - s0), hipMemcpyHostToDevice, st);
 }
 
-// the registration boundaries of the call in flight (set before any copy is enqueued, read-only after)
+// the registration boundaries of the call in flight (set before any copy is enqueued, read-only after): inside
+// every caller array the first and the last page boundary (the partial pages at its ends are never registered),
+// and for K and V the boundaries between the progressive registrations
 struct PinCuts {
-    std::vector<const char *> k, v;
+    std::vector<const char *> k, v, q;
 };
 PinCuts &CUT = *new PinCuts;
 
@@ -702,8 +715,7 @@ int stage_q_rows(const Plan &pl, Rank &rk, const double *Q, int s, size_t i0, in
         return SDPA_OK;
     }
     double *q64 = (double *)rk.q64[s].p + (size_t)j0 * pl.dk;
-    HIP_TRY(hipMemcpyAsync(q64, Q + (i0 + j0) * pl.dk, (size_t)jr * pl.dk * sizeof(double), hipMemcpyHostToDevice,
-                           rk.s_cp));
+    HIP_TRY(copy_h2d_cuts(q64, Q + (i0 + j0) * pl.dk, (size_t)jr * pl.dk * sizeof(double), CUT.q, rk.s_cp));
     HIP_TRY(hipEventRecord(copied, rk.s_cp));
     HIP_TRY(hipStreamWaitEvent(rk.s_in, copied, 0));
     if (pl.bf16)
@@ -747,6 +759,10 @@ struct Call {
     int n_brackets = 0, last_splits = 1;           // rank 0's enqueue thread only
     int last_rows = 0, last_keys = 0;              // shape of rank 0's last fused launch
     bool tail_marked = false;                      // the last batch's collective tail recorded root.ev_tail[0..3]
+    // bytes of `result` that lie in its partial first / last page: copied into E.bounce by the device, into place after the wait
+    struct Sliver { char *dst; const char *src; size_t bytes; };
+    std::vector<Sliver> slivers;
+    std::mutex sliver_mu;
     Call() { for (auto &e : enq) e.store(0); }
     int fail(int code) {
         int none = 0;
@@ -754,6 +770,34 @@ struct Call {
         return code;
     }
 };
+
+// Finished rows -> the caller's `result`.  The whole pages inside `result` are registered (true asynchronous DMA); the
+// partial page at its start and at its end is not (HostPins::add), and a device-to-host copy into pageable memory
+// would BLOCK the enqueuing thread until the rows exist.  Those few bytes (< 4 KiB each) go into a page-locked bounce
+// buffer instead and are put in place by the host after the call's one wait.
+int copy_result_rows(Call &c, double *dst_rows, const void *src, size_t bytes, hipStream_t st) {
+    char *d0 = (char *)dst_rows, *end = d0 + bytes;
+    const char *s0 = (const char *)src;
+    char *r0 = (char *)c.result, *r1 = r0 + (size_t)c.m * c.dv * sizeof(double);
+    char *a0 = (char *)HostPins::page_up(r0), *a1 = (char *)HostPins::page_down(r1);
+    if (!c.do_pin || !E.bounce || a1 <= a0) {                 // nothing is registered: one plain copy
+        HIP_TRY(hipMemcpyAsync(d0, s0, bytes, hipMemcpyDeviceToHost, st));
+        return SDPA_OK;
+    }
+    auto sliver = [&](char *lo, char *hi, char *edge_base, int slot) -> int {     // [lo, hi) inside the partial page
+        if (hi <= lo) return SDPA_OK;
+        char *b = E.bounce + slot * 4096 + (lo - edge_base);
+        HIP_TRY(hipMemcpyAsync(b, s0 + (lo - d0), (size_t)(hi - lo), hipMemcpyDeviceToHost, st));
+        std::lock_guard<std::mutex> lk(c.sliver_mu);
+        c.slivers.push_back({lo, b, (size_t)(hi - lo)});
+        return SDPA_OK;
+    };
+    SDPA_TRY(sliver(d0, std::min(end, a0), r0, 0));                            // head: [r0, a0)
+    char *m0 = std::max(d0, a0), *m1 = std::min(end, a1);
+    if (m1 > m0) HIP_TRY(hipMemcpyAsync(m0, s0 + (m0 - d0), (size_t)(m1 - m0), hipMemcpyDeviceToHost, st));
+    SDPA_TRY(sliver(std::max(d0, a1), end, a1, 1));                            // tail: [a1, r1)
+    return SDPA_OK;
+}
 
 // Page-lock the caller's arrays for the duration of the call.  Copies from pages the driver has never
 // seen run at ~11 GB/s on this platform (tools/probes/h2d_probe.cpp); registered ones at ~57 GB/s and
@@ -934,8 +978,8 @@ int rank_batch(Call &c, int g, int b) {
                                         (double *)rk.out64[s].p + (size_t)j0 * dv, jr, dv, rk.s_run));
         HIP_TRY(hipEventRecord(rk.ev_sub[s][ev], rk.s_run));
         HIP_TRY(hipStreamWaitEvent(rk.s_out, rk.ev_sub[s][ev], 0));
-        HIP_TRY(hipMemcpyAsync(c.result + (i0 + j0) * dv, (double *)rk.out64[s].p + (size_t)j0 * dv,
-                               (size_t)jr * dv * sizeof(double), hipMemcpyDeviceToHost, rk.s_out));
+        SDPA_TRY(copy_result_rows(c, c.result + (i0 + j0) * dv, (double *)rk.out64[s].p + (size_t)j0 * dv,
+                                  (size_t)jr * dv * sizeof(double), rk.s_out));
         return SDPA_OK;
     };
 
@@ -1071,8 +1115,8 @@ int tail_batch(Call &c, int b) {
             HIP_TRY(hipEventRecord(rk.ev_comm[s], rk.s_comm));
             HIP_TRY(hipStreamWaitEvent(rk.s_out, rk.ev_comm[s], 0));
             if (rows > 0)
-                HIP_TRY(hipMemcpyAsync(c.result + (i0 + r0) * dv, rk.out64[s].p, (size_t)rows * dv * sizeof(double),
-                                       hipMemcpyDeviceToHost, rk.s_out));
+                SDPA_TRY(copy_result_rows(c, c.result + (i0 + r0) * dv, rk.out64[s].p, (size_t)rows * dv * sizeof(double),
+                                          rk.s_out));
             HIP_TRY(hipEventRecord(rk.ev_out[s], rk.s_out));
         }
     } else {
@@ -1091,8 +1135,7 @@ int tail_batch(Call &c, int b) {
         }
         HIP_TRY(hipSetDevice(root.dev));
         HIP_TRY(hipStreamWaitEvent(root.s_out, root.ev_comm[s], 0));
-        HIP_TRY(hipMemcpyAsync(c.result + i0 * dv, root.out64[s].p, (size_t)bs * dv * sizeof(double),
-                               hipMemcpyDeviceToHost, root.s_out));
+        SDPA_TRY(copy_result_rows(c, c.result + i0 * dv, root.out64[s].p, (size_t)bs * dv * sizeof(double), root.s_out));
         HIP_TRY(hipEventRecord(root.ev_out[s], root.s_out));
     }
     return SDPA_OK;
@@ -1126,6 +1169,12 @@ int host_cvt_mode() {
     return atoi(v) > 0 ? 1 : 0;
 }
 
+int host_convert_thread_count() {
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int dflt = std::max(1, std::min(32, hw > 4 ? hw - 2 : 1));
+    return env_int("SDPA_HOST_CVT_THREADS", dflt);
+}
+
 bool want_host_cvt(const Plan &pl) {
     const int mode = host_cvt_mode();
     if (mode != 2) return mode == 1;
@@ -1135,15 +1184,20 @@ bool want_host_cvt(const Plan &pl) {
     const double t_link = elems * 8.0 / 55e9;                        // fp64 over PCIe Gen5 x16, as measured
     const double rate = pl.bf16 ? 1.0e15 : (pl.dk <= 256 ? 1.3e14 : 1.0e14);
     const double t_kernel = 2.0 * pl.m * (double)pl.n * (pl.dk + pl.dv) / rate;
-    return t_link > 1.4 * t_kernel;
+    // ... and only where the HOST can do it faster than the link would have carried the fp64 bytes: the
+    // convert threads read 8 B and write 2-4 B per element at ~3 GB/s of source per thread, ~100 GB/s for the whole
+    // pool on the box this was measured on (profiles/r03/host_convert_numa_probe.log); a host with few hardware
+    // threads keeps the device converts
+    const int threads = host_convert_thread_count();
+    if ((int)std::thread::hardware_concurrency() < 16 || threads < 8) return false;
+    const double t_host = elems * 8.0 / std::min(100e9, threads * 3.2e9);
+    return t_link > 1.4 * t_kernel && t_host < t_link;
 }
 
 // the converter pool is created on first use (32 threads, $SDPA_HOST_CVT_THREADS)
 int ensure_host_converter() {
     if (E.hc) return SDPA_OK;
-    const int hw = (int)std::thread::hardware_concurrency();
-    const int dflt = std::max(1, std::min(32, hw > 4 ? hw - 2 : 1));
-    E.hc = sdpa::HostConverter::create(env_int("SDPA_HOST_CVT_THREADS", dflt));
+    E.hc = sdpa::HostConverter::create(host_convert_thread_count());
     return E.hc ? SDPA_OK : SDPA_ENOMEM;
 }
 
@@ -1318,6 +1372,10 @@ int init_impl(int n_gpus) {
         for (int i = 0; i < want; ++i) devs[i] = E.r[i].dev;
         E.pool.start(want, devs);
     }
+    if (!E.bounce && hipHostMalloc((void **)&E.bounce, 2 * 4096, hipHostMallocPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        E.bounce = nullptr;              // (the result's edge pages then travel as pageable copies)
+    }
     E.n = want;
     E.up = true;
     return SDPA_OK;
@@ -1340,6 +1398,8 @@ void sdpa_shutdown(void) {
     E.r.clear();
     delete E.coll;
     E.coll = nullptr;
+    if (E.bounce) (void)hipHostFree(E.bounce);
+    E.bounce = nullptr;
     E.n = 0;
     E.run_cus = 0;
     E.up = false;
@@ -1437,6 +1497,24 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
     c.v_bytes = (size_t)n * dv * sizeof(double);
     const bool want_progressive = !getenv("SDPA_PROGRESSIVE_PIN") || atoi(getenv("SDPA_PROGRESSIVE_PIN")) != 0;
     if (c.do_pin && !PF.active && want_progressive) c.progressive = plan_progressive_pins(c);
+    // every caller array: the partial pages at its two ends are never registered (HostPins::add), so a copy that
+    // touches them is split at the first / last page boundary inside the array
+    auto edge_cuts = [](const void *base, size_t bytes, std::vector<const char *> &cuts) {
+        const char *b0 = (const char *)base, *end = b0 + bytes;
+        const char *a0 = HostPins::page_up(b0), *a1 = HostPins::page_down(end);
+        if (a1 <= a0) return;
+        if (a0 > b0) cuts.push_back(a0);
+        if (a1 < end) cuts.push_back(a1);
+        std::sort(cuts.begin(), cuts.end());
+        cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+    };
+    auto set_edge_cuts = [&]() {
+        if (!c.do_pin) return;
+        edge_cuts(K, c.k_bytes, CUT.k);
+        edge_cuts(V, c.v_bytes, CUT.v);
+        edge_cuts(Q, (size_t)m * dk * sizeof(double), CUT.q);
+    };
+    set_edge_cuts();
     c.threaded = P > 1 && !E.pool.th.empty();
 
     // $SDPA_HOST_CVT=1: host threads write the operand images; submit every conversion now, in the order
@@ -1454,6 +1532,7 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
             c.hostcvt = true;
             c.progressive = false;
             CUT = PinCuts();
+            set_edge_cuts();                 // (only `result` is registered in this mode; K / V / Q travel from the staging images)
             HI.cv = E.hc;
             HI.k = hk; HI.v = hv; HI.q = hq;
             HI.ldv_host = ldv_h;
@@ -1548,6 +1627,7 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
         HIP_TRY(hipStreamSynchronize(E.r[g].s_in));
         HIP_TRY(hipStreamSynchronize(E.r[g].s_cp));
     }
+    for (const Call::Sliver &sv : c.slivers) memcpy(sv.dst, sv.src, sv.bytes);     // result's partial first / last page
     drain.armed = false;
     const double t_exit = now_us();
 
