@@ -75,7 +75,8 @@ struct sdpa_timing {
     int    q_batches;     /* Q batches the pipeline ran                                         */
     int    kv_splits;     /* in-GPU K/V splits of the last fused launch                         */
     /* -- fields added in 0.2 (appended: older readers of the struct stay valid) -------------- */
-    double register_us;   /* page-locking the caller's arrays (host clock, inside total_us)     */
+    double register_us;   /* page-locking the caller's arrays (host clock, inside total_us);     */
+                          /* 0 unless $SDPA_HOST_REGISTER=1 (round 4: off by default)            */
     double head_us;       /* entry -> first fused kernel starts (what is NOT overlapped at the  */
                           /* front: registration, Q batch 0 and K/V chunk 0 over PCIe)          */
     double tail_us;       /* last fused kernel ends -> exit (merge, collectives, last D2H)      */
@@ -213,9 +214,11 @@ SDPA_API int sdpa_kv_prefetch(const double *K, const double *V, int m, int n, in
 
 /* Optional: page-locked host memory for the caller's Q/K/V/result arrays -- what the reference's
  * read_matrix() mallocs (attention.c:84-90) and main() frees (:191-194).  Arrays allocated here
- * need no per-call registration inside sdpa_attention_f64 and move at the full PCIe rate from the
- * first touch.  Returns NULL when there is no usable device or the allocation fails (the host then
- * uses malloc; sdpa_attention_f64 accepts any host pointer).  SURVEY.md 8(f)-2.                 */
+ * are used in place by sdpa_attention_f64 (fp64 straight over PCIe at the full rate, device
+ * converts).  Any other host pointer is accepted as well: since round 4 a pageable array is NEVER
+ * registered behind the caller's back ($SDPA_HOST_REGISTER=1 opts in; INTEGRATION.md says why
+ * not to) -- its rows go through the library's page-locked staging on host threads instead.
+ * Returns NULL when there is no usable device or the allocation fails.  SURVEY.md 8(f)-2.       */
 SDPA_API void *sdpa_host_alloc(size_t bytes);
 SDPA_API void  sdpa_host_free(void *p);
 
@@ -227,6 +230,12 @@ SDPA_API void  sdpa_host_free(void *p);
  * sdpa_attention_f64 (the reference's own placement of the converts, :224-225, :303); it needs no GPU.  */
 SDPA_API int sdpa_host_cvt_rows(const double *src, void *dst, long rows, int cols, int ld, int kind,
                                 double mult, int flags);
+
+/* The host-side widening of result rows: dst[i] = (double)src[i] for i < n (cvt_f2d_avx512, attention-mpi.c:68-101,
+ * called on the root at :373 / :396), exact.  threads <= 1: on the calling thread; threads > 1: on a pool of that many
+ * threads plus the calling one, the way $SDPA_HOST_WIDEN runs it inside sdpa_attention_f64 (fp32 rows cross PCIe, the
+ * host widens them into `result`).  flags bit 0: the plain C loop instead of the AVX-512 one.  Needs no GPU.     */
+SDPA_API int sdpa_host_widen(const float *src, double *dst, size_t n, int threads, int flags);
 
 /* K/V row partition, attention-mpi.c:19-27. */
 SDPA_API int sdpa_owner_count(int n, int size, int rank);

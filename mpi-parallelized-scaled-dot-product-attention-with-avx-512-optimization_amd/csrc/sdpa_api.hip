@@ -239,6 +239,20 @@ int sdpa_host_cvt_rows(const double *src, void *dst, long rows, int cols, int ld
     return SDPA_OK;
 }
 
+int sdpa_host_widen(const float *src, double *dst, size_t n, int threads, int flags) {
+    if (n == 0) return SDPA_OK;
+    if (!src || !dst) return SDPA_EINVAL;
+    if (threads <= 1) {
+        sdpa::host_widen(src, dst, n, (flags & 1) != 0);
+        return SDPA_OK;
+    }
+    sdpa::HostConverter *pool = sdpa::HostConverter::create(threads);
+    if (!pool) return SDPA_ENOMEM;
+    pool->widen(src, dst, n);
+    delete pool;
+    return SDPA_OK;
+}
+
 int sdpa_dev_stream_create(int reserve_cus, void **stream) {
     if (!stream || reserve_cus < 0) return SDPA_EINVAL;
     SDPA_TRY(require_device());

@@ -146,6 +146,28 @@ __global__ void finish_f64_kernel(const float *__restrict__ contrib, int ldo,
     }
 }
 
+// out[r*dv + c] = contrib[r*ldo + c] * (lsum==0 ? 0 : 1/lsum): finish_f64_kernel without the widening -- the rows go home
+// as fp32 and the host widens them (cvt_f2d_avx512 on the root, attention-mpi.c:373/:396).  Same fp32 product, so the
+// widened value is finish_f64_kernel's bit for bit.  lsum == nullptr: a plain repack of rows that are already normalised.
+__global__ void finish_f32_kernel(const float *__restrict__ contrib, int ldo,
+                                  const float *__restrict__ lsum, float *__restrict__ out,
+                                  int m, int dv) {
+    const long total = (long)m * dv;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(idx / dv);
+        const int c = (int)(idx - (long)r * dv);
+        const float x = contrib[(size_t)r * ldo + c];
+        if (lsum) {
+            const float g = lsum[r];
+            const float inv = (g == 0.f) ? 0.f : 1.0f / g;
+            out[idx] = x * inv;
+        } else {
+            out[idx] = x;
+        }
+    }
+}
+
 hipError_t launch_cvt_d2f(const double *src, float *dst, long rows, int cols, int ld, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
     const long work = rows * (ld / 4);
@@ -188,6 +210,14 @@ hipError_t launch_finish_f64(const float *contrib, int ldo, const float *lsum, d
     if (m <= 0) return hipSuccess;
     hipLaunchKernelGGL(finish_f64_kernel, dim3(stream_grid((long)m * dv)), dim3(256), 0, s, contrib,
                        ldo, lsum, result, m, dv);
+    return hipGetLastError();
+}
+
+hipError_t launch_finish_f32(const float *contrib, int ldo, const float *lsum, float *out, int m, int dv,
+                             hipStream_t s) {
+    if (m <= 0) return hipSuccess;
+    hipLaunchKernelGGL(finish_f32_kernel, dim3(stream_grid((long)m * dv)), dim3(256), 0, s, contrib, ldo, lsum, out,
+                       m, dv);
     return hipGetLastError();
 }
 

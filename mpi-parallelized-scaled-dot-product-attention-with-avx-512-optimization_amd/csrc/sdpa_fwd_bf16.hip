@@ -35,6 +35,11 @@
 
 SDPA_AUDIT_COUNTER(g_bf16_audit)
 
+// -DSDPA_BF16_MASK_EVERY_STEP=1: the ragged-tile mask in every step again (rounds 1-3), for the A/B of its cost
+#ifndef SDPA_BF16_MASK_EVERY_STEP
+#define SDPA_BF16_MASK_EVERY_STEP 0
+#endif
+
 namespace sdpa {
 
 #ifdef SDPA_DMA_ASSERT
@@ -320,8 +325,9 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
     constexpr int PPK = NKS >= 16 ? 1 : 16 / NKS;        // P values finished per QK^T MFMA slot
     constexpr int KPP = NKS >= 16 ? NKS / 16 : 1;        // QK^T MFMAs per P value
 
-    auto step = [&](auto has_next, f32x16 &su, f32x16 &sm, int t) __attribute__((always_inline)) {
+    auto step = [&](auto has_next, auto masked, f32x16 &su, f32x16 &sm, int t) __attribute__((always_inline)) {
         constexpr bool HAS_NEXT = decltype(has_next)::value;
+        constexpr bool MASKED = decltype(masked)::value;   // this step scores the shard's last (possibly ragged) tile
         const int vbuf = t & 1, kbuf = (t + 1) & 1;
         if (t + 2 < T) dma_k(t + 2, t & 1);
         if (t + 1 < T) v_gload(t + 1);
@@ -365,7 +371,7 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
         pb[1] = u32x4{pw[4], pw[5], pw[6], pw[7]};
 
         // [B] O^T += Vt(t).P(t)^T on the matrix pipe  ||  row max of S^T(t+1), Vt(t+1) -> LDS
-        if constexpr (HAS_NEXT) mask_ragged(sm, t + 1);
+        if constexpr (HAS_NEXT && (MASKED || SDPA_BF16_MASK_EVERY_STEP)) mask_ragged(sm, t + 1);
         const unsigned short *vt = Vs + vbuf * VTILE + li * VLD + 8 * hi;
         float tmax = -INFINITY;
         constexpr int SLOTS = 2 * NT;                     // P.V MFMAs of this step
@@ -434,15 +440,25 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
         __syncthreads();                                // K(0) fully consumed before K(2) lands on it
 
         int t = 0;
-        for (; t + 2 < T; t += 2) {
-            step(std::true_type(), sA, sB, t);
-            step(std::true_type(), sB, sA, t + 1);
+        using yes = std::true_type;
+        using no = std::false_type;
+        // Only the shard's LAST tile can be ragged, so only the step that scores it masks: the steady-state loop
+        // stops two tiles short of the end and the tail below runs the masking instantiation.  (Round 4: with the
+        // mask in every step hipcc turned its wave-uniform branch into ~45 selects per step, a third of the loop's
+        // VALU work, next to MFMAs that do not overlap with VALU issue -- profiles/r04/bf16_ragged_mask_hoist.log.)
+        for (; t + 3 < T; t += 2) {
+            step(yes(), no(), sA, sB, t);
+            step(yes(), no(), sB, sA, t + 1);
         }
-        if (T - t == 2) {
-            step(std::true_type(), sA, sB, t);
-            step(std::false_type(), sB, sA, t + 1);
+        if (T - t == 3) {
+            step(yes(), no(), sA, sB, t);
+            step(yes(), yes(), sB, sA, t + 1);
+            step(no(), no(), sA, sB, t + 2);
+        } else if (T - t == 2) {
+            step(yes(), yes(), sA, sB, t);
+            step(no(), no(), sB, sA, t + 1);
         } else {
-            step(std::false_type(), sA, sB, t);
+            step(no(), no(), sA, sB, t);
         }
     }
 
@@ -549,6 +565,20 @@ __device__ __forceinline__ float halfwave_max(float x) {
 #endif
 #ifndef SDPA_TANDEM_GROUP
 #define SDPA_TANDEM_GROUP 2
+#endif
+// tools/build_variant.sh -DSDPA_TANDEM_ABL=bits: TIMING-ONLY ablations of the tandem kernel's steady-state loop (results
+// are wrong), never in the shipped library: 1 = no softmax VALU (exp2 / row sum / pack), 2 = no LDS fragment reads
+// (operands taken from the Q registers), 4 = no LDS-DMA issue in the loop (the prologue's tiles stay in LDS),
+// 8 = no barriers, 16 = no P exchange.  profiles/r04/bf16_tandem_ablations.log
+#ifndef SDPA_TANDEM_ABL
+#define SDPA_TANDEM_ABL 0
+#endif
+// -DSDPA_TANDEM_KIMM=0: the steady-state K pieces with per-piece scalar address arithmetic again (rounds 1-3), for the A/B
+#ifndef SDPA_TANDEM_KIMM
+#define SDPA_TANDEM_KIMM 1
+#endif
+#ifndef SDPA_TANDEM_KIMM_LDS_PER_PIECE
+#define SDPA_TANDEM_KIMM_LDS_PER_PIECE 0
 #endif
 // which kernel dv > 256 takes when $SDPA_BF16_TANDEM is not set (0 = wide, 1 = tandem)
 #ifndef SDPA_BF16_TANDEM_DEFAULT
@@ -802,7 +832,7 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
         PIN_O_IN_LOOP(2);
 
         // [B]
-        if constexpr (HAS_NEXT) mask_ragged(sx, t + 1);
+        if constexpr (HAS_NEXT && (FENCED || SDPA_BF16_MASK_EVERY_STEP)) mask_ragged(sx, t + 1);    // (only a fenced step scores the last tile)
         constexpr int SLOTS = 2 * NT;                     // P.V MFMAs of this step
         constexpr int VD = SDPA_WIDE_VD;                   // V fragment prefetch depth
         // next step reads the next K buffer: advance the fragment addresses in place
@@ -876,11 +906,19 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
         // (q block, split) after the loop, and the launcher runs the general kernel right behind this
         // one over the flagged blocks, which rewrites their rows.
         int t = 0;
-        for (; t + 2 < T; t += 2) {
+        // Only the shard's LAST tile can be ragged, so only the step that scores it masks: the steady-state loop
+        // stops two tiles short of the end and the tail below runs the masking instantiation.  (Round 4: with the
+        // mask in every step hipcc turned its wave-uniform branch into ~45 selects per step, a third of the loop's
+        // VALU work, next to MFMAs that do not overlap with VALU issue -- profiles/r04/bf16_ragged_mask_hoist.log.)
+        for (; t + 3 < T; t += 2) {
             step(std::true_type(), std::false_type(), pA, pB, t);
             step(std::true_type(), std::false_type(), pB, pA, t + 1);
         }
-        if (T - t == 2) {
+        if (T - t == 3) {
+            step(std::true_type(), std::false_type(), pA, pB, t);
+            step(std::true_type(), std::true_type(), pB, pA, t + 1);
+            step(std::false_type(), std::true_type(), pA, pB, t + 2);
+        } else if (T - t == 2) {
             step(std::true_type(), std::true_type(), pA, pB, t);
             step(std::false_type(), std::true_type(), pB, pA, t + 1);
         } else {
@@ -1029,7 +1067,49 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_tandem_kernel(
                      : "v"(lane_part), "s"(lds_byte), "s"(swz), "s"(gbase)
                      : "memory" SDPA_M0_CLOBBER);
     };
+    // the same with the piece's place inside the tile as an IMMEDIATE (steady-state steps, DK = 512: a piece is one
+    // K row = 1 KiB, a wave's eight rows are consecutive; `gmid` points at the wave's FIFTH row, so pieces 0..7 sit at
+    // -4096 .. +3072, inside the instruction's signed 13-bit offset): ONE scalar address per tile instead of
+    // clamp + shift + 64-bit add per piece -- five scalar instructions per piece that a one-wave-per-SIMD
+    // kernel pays for in issue slots (profiles/r04/bf16_tandem_ablations.log)
+#define SDPA_K_PIECE_IMM(J, OFF)                                                                          \
+    case J:                                                                                               \
+        asm volatile("s_mov_b32 m0, %2\n\t"                                                               \
+                     "v_xor_b32 %0, %3, %1\n\t"                                                           \
+                     "global_load_lds_dwordx4 %0, %4 offset:" #OFF                                         \
+                     : "=&v"(off)                                                                         \
+                     : "v"(lane_part), "s"(lds_byte), "s"(swz), "s"(gmid)                                 \
+                     : "memory" SDPA_M0_CLOBBER);                                                         \
+        break;
+    auto dma_piece_xor_imm = [&](const char *gmid, int j, unsigned lane_part, unsigned swz, unsigned lds_byte) __attribute__((always_inline)) {
+        SDPA_BF16_AUDIT(a, gmid + (j - 4) * 1024 + (lane_part ^ swz));
+        unsigned off;
+        switch (j) {
+            SDPA_K_PIECE_IMM(0, -4096)
+            SDPA_K_PIECE_IMM(1, -3072)
+            SDPA_K_PIECE_IMM(2, -2048)
+            SDPA_K_PIECE_IMM(3, -1024)
+            SDPA_K_PIECE_IMM(4, 0)
+            SDPA_K_PIECE_IMM(5, 1024)
+            SDPA_K_PIECE_IMM(6, 2048)
+            default: SDPA_K_PIECE_IMM(7, 3072)
+        }
+    };
+#undef SDPA_K_PIECE_IMM
     const unsigned klane = (unsigned)((lane / KCH) * DK * 2 + (((lane % KCH) ^ ((lane / KCH) & SWZ)) << 4));
+    // a tile that is NOT the shard's last one is whole: no row clamp (the steady-state loop never loads the last tile)
+    auto dma_k_piece_whole = [&](int tile, int buf, int j) __attribute__((always_inline)) {
+        static_assert(true, "");
+        const int row0 = wave * KPW + j;
+        const unsigned swz = (unsigned)((row0 & SWZ) << 4);
+        // the instruction's immediate offset moves BOTH ends of an LDS-DMA -- the global address and the LDS
+        // address (M0 + offset + 16 * lane) -- so M0 names the wave's fifth row in the buffer as well, for every piece
+        // (-DSDPA_TANDEM_KIMM_LDS_PER_PIECE=1: M0 per piece, i.e. the offset taken as global-only -- call 9's bug, kept
+        // for the A/B that settled it)
+        const unsigned dst = lds_base + (unsigned)(buf * KTILE * 2 + (wave * KPW + (SDPA_TANDEM_KIMM_LDS_PER_PIECE ? j : 4)) * 1024);
+        const char *gmid = reinterpret_cast<const char *>(a.K + (size_t)(kv_begin + tile * kKvTile + wave * KPW + 4) * DK);
+        dma_piece_xor_imm(gmid, j, klane, swz, dst);
+    };
     auto dma_k_piece = [&](int tile, int buf, int j) __attribute__((always_inline)) {
         const int base = kv_begin + tile * kKvTile;
         const int last = kv_end - 1 - base;
@@ -1058,7 +1138,7 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_tandem_kernel(
     auto stage_fence = [&](auto keep) __attribute__((always_inline)) {
         constexpr int KEEP = decltype(keep)::value;
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
-        __syncthreads();
+        if constexpr (!(SDPA_TANDEM_ABL & 8)) __syncthreads();
     };
 
     // K fragment byte addresses inside a K buffer (chunk 2ks+hi of row li, un-swizzled); the buffer being
@@ -1068,6 +1148,7 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_tandem_kernel(
 #pragma unroll
     for (int u = 0; u < NKA; ++u) kaddr[u] = (unsigned)(li * DK * 2 + (((2 * u + hi) ^ (li & SWZ)) << 4));
     auto kfrag = [&](int ks) __attribute__((always_inline)) -> u32x4 {
+        if constexpr (SDPA_TANDEM_ABL & 2) return qf[(ks + 1) % NKS];
         return *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(Ks) +
                                                 kaddr[ks % NKA] + (ks / NKA) * 256);
     };
@@ -1079,16 +1160,23 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_tandem_kernel(
         vaddr[h] = (unsigned)(role * 8 * 2048 + li * 64 + (((2 * h + hi) ^ ((li >> 2) & 3)) << 4));
     auto vfrag = [&](int buf, int f) __attribute__((always_inline)) -> u32x4 {
         const int h = f / NTW, tt = f % NTW;
+        if constexpr (SDPA_TANDEM_ABL & 2) return qf[(f + 3) % NKS];
         return *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(Vs + buf * VTILE) +
                                                 vaddr[h] + tt * 2048);
     };
     // the P exchange: this wave's P tile of key half h in buffer b, lane-linear 16-byte entries
     const unsigned pmine = (unsigned)(wave * 2048 + lane * 16), ptheirs = (unsigned)((wave ^ 1) * 2048 + lane * 16);
     auto p_store = [&](int b, const u32x4 (&pv)[2]) __attribute__((always_inline)) {
+        if constexpr (SDPA_TANDEM_ABL & 16) return;
         *reinterpret_cast<u32x4 *>(Ps + b * 8192 + pmine) = pv[0];
         *reinterpret_cast<u32x4 *>(Ps + b * 8192 + pmine + 1024) = pv[1];
     };
     auto p_load = [&](int b, u32x4 (&pv)[2]) __attribute__((always_inline)) {
+        if constexpr (SDPA_TANDEM_ABL & 16) {
+            pv[0] = qf[1];
+            pv[1] = qf[2];
+            return;
+        }
         pv[0] = *reinterpret_cast<const u32x4 *>(Ps + b * 8192 + ptheirs);
         pv[1] = *reinterpret_cast<const u32x4 *>(Ps + b * 8192 + ptheirs + 1024);
     };
@@ -1114,6 +1202,10 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_tandem_kernel(
     //  fragment ring depths and MFMA grouping: profiles/r03/bf16_tandem_ab.log)
     f32x16 sx;
     auto p_elem = [&](int r, u32x4 (&pout)[2]) __attribute__((always_inline)) {
+        if constexpr (SDPA_TANDEM_ABL & 1) {
+            if (r < 8) pout[r / 4][r % 4] = __builtin_bit_cast(unsigned, sx[r]);      // (the score registers as they are)
+            return;
+        }
         asm volatile("v_exp_f32 %0, %0" : "+v"(sx[r]));
         if (r >= 1) {
             asm volatile("v_add_f32 %0, %0, %1" : "+v"(l_run) : "v"(sx[r - 1]));
@@ -1121,6 +1213,7 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_tandem_kernel(
         }
     };
     auto p_close = [&](u32x4 (&pout)[2]) __attribute__((always_inline)) {
+        if constexpr (SDPA_TANDEM_ABL & 1) return;
         asm volatile("v_add_f32 %0, %0, %1" : "+v"(l_run) : "v"(sx[15]));
         pout[1][3] = bpin_pack(sx[14], sx[15]);
     };
@@ -1131,6 +1224,7 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_tandem_kernel(
         constexpr bool FENCED = decltype(fenced)::value;
         constexpr int vbuf = decltype(parity)::value;
         const int tk = min(t + 2, T - 1);                  // past the end: a harmless reload into a free buffer
+        constexpr bool WHOLE = !FENCED && RPP == 1 && KPW == 8 && SDPA_TANDEM_KIMM;   // (steady state: t + 2 <= T - 2)
         if constexpr (HAS_NEXT) {
             // [A]
             constexpr int KD = NKS < SDPA_TANDEM_KD ? NKS : SDPA_TANDEM_KD;
@@ -1144,7 +1238,12 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_tandem_kernel(
                 if (ks == 0) mfma_bf16_vgpr_first(sx, kf, qf[0]);
                 else mfma_bf16_vgpr(sx, kf, qf[ks]);
                 if (ks + KD < NKS) kq[ks % KD] = kfrag(ks + KD);
-                if (ks % 4 == 0) dma_k_piece(tk, vbuf, ks / 4);      // K(t+2) into the buffer K(t) left (NKS / KPW == 4)
+                if constexpr (!(SDPA_TANDEM_ABL & 4)) {
+                    if (ks % 4 == 0) {                               // K(t+2) into the buffer K(t) left (NKS / KPW == 4)
+                        if constexpr (WHOLE) dma_k_piece_whole(t + 2, vbuf, ks / 4);
+                        else dma_k_piece(tk, vbuf, ks / 4);
+                    }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (FENCED) mfma_result_fence(sx);
@@ -1156,7 +1255,7 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_tandem_kernel(
         // [B]
         u32x4 pp[2];                                       // the partner's P(t)
         p_load(vbuf, pp);
-        if constexpr (HAS_NEXT) mask_ragged(sx, t + 1);
+        if constexpr (HAS_NEXT && (FENCED || SDPA_BF16_MASK_EVERY_STEP)) mask_ragged(sx, t + 1);    // (only a fenced step scores the last tile)
         constexpr int FRAGS = 2 * NTW;                     // Vt fragments of this step, two MFMAs each
         constexpr int VD = SDPA_TANDEM_VD;                 // fragment prefetch depth (>= GROUP)
         constexpr int GRP = SDPA_TANDEM_GROUP;             // MFMA order: GRP own, then the same GRP fragments for the partner
@@ -1183,7 +1282,8 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_tandem_kernel(
             // fragment f is dead behind its partner MFMA: refill its ring slot
             if (partner && f + VD < FRAGS) vq[f % VD] = vfrag(vbuf, f + VD);
             if constexpr (HAS_NEXT) {
-                if (slot % 4 == 1) dma_v_piece(t + 1, vbuf ^ 1, slot / 4);       // VPW == 8 pieces over 32 slots
+                if constexpr (!(SDPA_TANDEM_ABL & 4))
+                    if (slot % 4 == 1) dma_v_piece(t + 1, vbuf ^ 1, slot / 4);   // VPW == 8 pieces over 32 slots
                 // first read of the score tile: >= 11 issue slots behind the chain's last link
                 if (slot >= 12 && slot < 28) p_elem(slot - 12, pn);
                 if (slot == 28) p_close(pn);
@@ -1226,9 +1326,20 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_tandem_kernel(
         int t = 0;
         using even = std::integral_constant<int, 0>;
         using odd = std::integral_constant<int, 1>;
-        for (; t + 2 < T; t += 2) {
+        // Only the shard's LAST tile can be ragged, so only the step that scores it masks: the steady-state loop
+        // stops two tiles short of the end and the tail below runs the masking instantiation.  (Round 4: with the
+        // mask in every step hipcc turned its wave-uniform branch into ~45 selects per step, a third of the loop's
+        // VALU work, next to MFMAs that do not overlap with VALU issue -- profiles/r04/bf16_ragged_mask_hoist.log.)
+        // (... and three short of it, so that no steady-state step LOADS the last tile either -- K(t+2) goes out in
+        //  step t -- and the K pieces need no row clamp: dma_k_piece_whole)
+        for (; t + 4 < T; t += 2) {
             step(std::true_type(), std::false_type(), even(), pA, pB, t);
             step(std::true_type(), std::false_type(), odd(), pB, pA, t + 1);
+        }
+        if (T - t >= 3) {                                   // 3 or 4 steps left: two fenced ones, then the cases below
+            step(std::true_type(), std::true_type(), even(), pA, pB, t);
+            step(std::true_type(), std::true_type(), odd(), pB, pA, t + 1);
+            t += 2;
         }
         if (T - t == 2) {
             step(std::true_type(), std::true_type(), even(), pA, pB, t);
@@ -1564,9 +1675,10 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
     int kr = 1, kw = 0, vr = 0, vw = NVB - 1;
     // One step t.  scur: scores of tile t (its slices [NB_SL, 32) still to do), snxt: receives
     // S^T(t+1); pcur: P(t) (completed in [A]), pnxt: receives P(t+1) (slices [0, NB_SL) in [B]).
-    auto step = [&](auto has_next, f32x16 (&scur)[2], f32x16 (&snxt)[2], SliceState &stc, SliceState &stn,
+    auto step = [&](auto has_next, auto masked, f32x16 (&scur)[2], f32x16 (&snxt)[2], SliceState &stc, SliceState &stn,
                     u32x4 (&pcur)[2][2], u32x4 (&pnxt)[2][2], int t) __attribute__((always_inline)) {
         constexpr bool HAS_NEXT = decltype(has_next)::value;
+        constexpr bool MASKED = decltype(masked)::value;   // this step scores the shard's last (possibly ragged) tile
         DUO_PIN_O();
 #ifdef SDPA_DUO_PINQ
         pin_q();
@@ -1610,7 +1722,7 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
         DUO_PIN_O();
 
         // [B]
-        if constexpr (HAS_NEXT) mask_ragged(snxt, t + 1);
+        if constexpr (HAS_NEXT && (MASKED || SDPA_BF16_MASK_EVERY_STEP)) mask_ragged(snxt, t + 1);
         constexpr int SLOTS = 2 * NT;                      // Vt fragments of this step (2 MFMAs each)
         constexpr int VD = SDPA_DUO_VD;
         const int kr_next = kr == NKB - 1 ? 0 : kr + 1;
@@ -1686,27 +1798,37 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
         for (int u = 0; u < NKA; ++u) kaddr[u] += (unsigned)(KTILE * 2);   // step 0 reads K(1) in buffer 1
 
         int t = 0;
+        using yes = std::true_type;
+        using no = std::false_type;
         if constexpr (SETS == 2) {
-            for (; t + 2 < T; t += 2) {
-                step(std::true_type(), sA, sB, stA, stB, pA, pB, t);
-                step(std::true_type(), sB, sA, stB, stA, pB, pA, t + 1);
+            for (; t + 3 < T; t += 2) {             // (the last tile is scored by a masking step of the tail: see the pipe kernel)
+                step(yes(), no(), sA, sB, stA, stB, pA, pB, t);
+                step(yes(), no(), sB, sA, stB, stA, pB, pA, t + 1);
             }
-            if (T - t == 2) {
-                step(std::true_type(), sA, sB, stA, stB, pA, pB, t);
-                step(std::false_type(), sB, sA, stB, stA, pB, pA, t + 1);
+            if (T - t == 3) {
+                step(yes(), no(), sA, sB, stA, stB, pA, pB, t);
+                step(yes(), yes(), sB, sA, stB, stA, pB, pA, t + 1);
+                step(no(), no(), sA, sB, stA, stB, pA, pB, t + 2);
+            } else if (T - t == 2) {
+                step(yes(), yes(), sA, sB, stA, stB, pA, pB, t);
+                step(no(), no(), sB, sA, stB, stA, pB, pA, t + 1);
             } else {
-                step(std::false_type(), sA, sB, stA, stB, pA, pB, t);
+                step(no(), no(), sA, sB, stA, stB, pA, pB, t);
             }
         } else {            // one score set: it is dead once its slices ran under [B]
-            for (; t + 2 < T; t += 2) {
-                step(std::true_type(), sA, sA, stA, stA, pA, pB, t);
-                step(std::true_type(), sA, sA, stA, stA, pB, pA, t + 1);
+            for (; t + 3 < T; t += 2) {             // (the last tile is scored by a masking step of the tail: see the pipe kernel)
+                step(yes(), no(), sA, sA, stA, stA, pA, pB, t);
+                step(yes(), no(), sA, sA, stA, stA, pB, pA, t + 1);
             }
-            if (T - t == 2) {
-                step(std::true_type(), sA, sA, stA, stA, pA, pB, t);
-                step(std::false_type(), sA, sA, stA, stA, pB, pA, t + 1);
+            if (T - t == 3) {
+                step(yes(), no(), sA, sA, stA, stA, pA, pB, t);
+                step(yes(), yes(), sA, sA, stA, stA, pB, pA, t + 1);
+                step(no(), no(), sA, sA, stA, stA, pA, pB, t + 2);
+            } else if (T - t == 2) {
+                step(yes(), yes(), sA, sA, stA, stA, pA, pB, t);
+                step(no(), no(), sA, sA, stA, stA, pB, pA, t + 1);
             } else {
-                step(std::false_type(), sA, sA, stA, stA, pA, pB, t);
+                step(no(), no(), sA, sA, stA, stA, pA, pB, t);
             }
         }
         bool redo = false;

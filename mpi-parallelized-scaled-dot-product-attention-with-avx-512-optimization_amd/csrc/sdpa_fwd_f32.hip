@@ -1214,7 +1214,7 @@ static hipError_t launch_pipelined(const PartialArgs &a, hipStream_t s) {
     hipError_t e;
     // stream-K (sdpa_internal.h: F32Plan): the plan for THIS stream's compute units; taken when the caller gave
     // the launch at least the slabs it needs (callers size a.kv_splits with the same function)
-    const F32Plan plan = ABL || k.tickets ? F32Plan{1, 0, 0, 0} : plan_f32_launch(a.m, a.n_local, a.dk, a.dv, stream_cus(s));
+    const F32Plan plan = ABL || k.tickets ? F32Plan{1, 0, 0, 0} : plan_f32_launch(a.m, a.n_local, a.dk, a.dv, a.cus > 0 ? a.cus : stream_cus(s));
     bool launched = false;
     if constexpr (DK <= kMaxFastDim) {
         if (plan.streamk && plan.splits <= a.kv_splits && (a.kv_splits <= 1 || a.ws_contrib)) {

@@ -95,6 +95,8 @@ struct Rank {
     std::vector<hipEvent_t> ev_k;        // fused-kernel timing brackets (rank 0)
     hipEvent_t ev_t0 = nullptr, ev_kv_done = nullptr, ev_end = nullptr;
     hipEvent_t ev_tail[4] = {};          // rank 0, last batch's collective tail: start | merged | reduced | widened (comm stream)
+    std::vector<hipEvent_t> ev_w;        // host-side widening: piece i of this rank's fp32 result rows has reached the host
+    int ev_w_used = 0;
 };
 
 // One enqueue thread per rank (P > 1 only).  A job is a function of the rank index; run() hands it to
@@ -172,6 +174,7 @@ struct Engine {
     sdpa::HostConverter *hc = nullptr;   // $SDPA_HOST_CVT=1: fp64 -> operand images on host threads (sdpa_hostcvt.h)
     char *bounce = nullptr;              // 8 KiB page-locked: the partial first / last page of `result` travels through here
     int run_cus = 0;                     // compute units of a rank's compute stream (create_rank)
+    int chip_cus = 0;                    // compute units of rank 0's device
     bool rccl_hung = false;              // the last RCCL self-test did not finish (lazy_init does not fall back then)
     sdpa_timing last = {};
 };
@@ -194,14 +197,20 @@ int env_int(const char *name, int dflt) {
 }
 
 // Compute units a rank's compute stream leaves to the other streams ($SDPA_COMM_CUS; unset = the default:
-// 8 -- one per XCD -- when the call merges over several ranks, so that a batch's collectives and merge
+// 16 -- two per XCD -- when the call merges over several ranks, so that a batch's collectives and merge
 // kernels run UNDER the next batch's fused kernels the way the reference's MPI_Ireduce stays in flight
 // (attention-mpi.c:364-380); 0 with one rank, where nothing runs beside the fused kernel).  The fused
-// launches size their stream-K grids by what is left, so the reservation costs its share of the chip
-// (8 / 256 = 3 %) and no more (round 3: a CU-masked stream broke the exact fit of the grid: +55 %).
+// launches size their stream-K grids by what is left, so the reservation costs about its share of the chip
+// and no more (round 3: a CU-masked stream broke the exact fit of the grid: +55 %).  Why 16 and not 8
+// (measured, one rank with forced collectives at config 4, rocprofv3 kernel trace): with 8 CUs' worth of
+// slots free the merge kernel of batch b STARTS beside batch b+1's fused kernel but finishes with it
+// (6.9 ms: the dispatcher deals a kernel's workgroups to the shader engines in turn and stalls at the
+// first engine without a free slot); with 16 it takes 25-300 us
+// (profiles/r04/config4_one_rank_forced_collectives_overlap_reserve{8,16,32}.txt).  A call reserves
+// only when it has a NEXT batch to hide a tail under (make_plan: collectives and more than one Q batch).
 int comm_cus_reserved(int cus, int ranks) {
     const char *v = getenv("SDPA_COMM_CUS");
-    int want = (v && *v) ? atoi(v) : (ranks > 1 ? 8 : 0);
+    int want = (v && *v) ? atoi(v) : (ranks > 1 ? 16 : 0);
     if (want <= 0) return 0;
     const int xcds = cus >= 64 ? cus / 32 : 1;
     int r = (want + xcds - 1) / xcds * xcds;
@@ -209,24 +218,62 @@ int comm_cus_reserved(int cus, int ranks) {
     return r;
 }
 
+// Is this host address page-locked memory the runtime knows (hipHostMalloc / sdpa_host_alloc, or registered by the caller)?
+bool page_locked(const void *p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
+// $SDPA_HOST_REGISTER=1: page-lock the caller's pageable arrays for the duration of the call (hipHostRegister), the
+// default of rounds 1-3.  OFF by default since round 4: registering and unregistering heap ranges in a process whose
+// other code copies from the same addresses with plain (pageable) hipMemcpy -- PyTorch's .cuda() of a numpy array, any
+// host application's own copies -- makes the GPU fault on a host page within seconds (the HIP runtime keeps its own
+// transient pins of pageable sources by address; tools/gpu_register_stress.py: fault after 5-11 s in every mode that
+// registers, 0 faults in 25 000 copies / 6 700 calls when nothing is registered; profiles/r04/).  It was the rare
+// silent abort of rounds 2-3.  Pageable arrays now travel through the library's own page-locked staging instead
+// (host converts in, host widening out: want_host_cvt / want_host_widen).
+bool register_caller_arrays() {
+    const char *v = getenv("SDPA_HOST_REGISTER");
+    return v && *v && atoi(v) != 0;
+}
+
+bool pin_probe() {
+    static const bool on = [] { const char *v = getenv("SDPA_PIN_PROBE"); return !(v && *v == '0'); }();
+    return on;
+}
+
 // RAII page-locking of caller-owned host arrays (best effort: a range that cannot be registered,
 // e.g. because the caller already allocated it page-locked, is simply left as it is).
 struct HostPins {
     std::vector<void *> ptr;
     double us = 0.0;                                        // host time spent registering
-    // Only the WHOLE PAGES inside [p, p + bytes) are registered (round 4).  A registration maps its pages into the
-    // GPU's address space at their host addresses; two caller arrays that are neighbours in the heap share the page
-    // their boundary falls in, and a page that belongs to two mappings -- ours and ours, or ours and the transient one
-    // the HIP runtime makes for an unregistered (pageable) neighbour's copy -- is unmapped for BOTH when the first of
-    // them goes away.  The one GPU memory fault this library has ever produced was a read of exactly such an
-    // address (a page-aligned HOST heap address, profiles/r04/gpu_memory_fault_on_a_host_heap_page.log).  The
-    // partial pages at the two ends are copied as pageable slivers (copy_h2d_cuts / copy_d2h_cuts split there).
+    // ($SDPA_HOST_REGISTER=1 only -- see register_caller_arrays.)  Only the WHOLE PAGES inside [p, p + bytes) are
+    // registered: a registration maps its pages into the GPU's address space at their host addresses, and two caller
+    // arrays that are neighbours in the heap share the page their boundary falls in.  The partial pages at the two ends
+    // are copied as pageable slivers (copy_h2d_cuts / copy_d2h_cuts split there).  (This was round 4's first theory of
+    // the suite's rare GPU memory fault; it narrowed nothing -- the fault needs no shared page, only a registration that
+    // comes and goes over addresses the runtime has pinned for its own pageable copies:
+    // profiles/r04/gpu_memory_fault_root_cause_hipHostRegister.log.)
     static const char *page_up(const void *p) { return (const char *)(((uintptr_t)p + 4095) & ~(uintptr_t)4095); }
     static const char *page_down(const void *p) { return (const char *)((uintptr_t)p & ~(uintptr_t)4095); }
     void add(const void *p, size_t bytes) {
         const char *lo = page_up(p), *hi = page_down((const char *)p + bytes);
         if (hi <= lo || (size_t)(hi - lo) < (1u << 20)) return;   // small ranges: not worth the call
         const double t0 = now_us();
+        // Memory the runtime already knows (hipHostMalloc / sdpa_host_alloc arrays, an earlier registration of the
+        // caller's, managed memory) is left alone: registering it again is REFUSED by the runtime ("Failed creating
+        // memory ... Cannot create memory for size"), and both GPU memory faults of round 4 came 0.5 s and 3.3 s
+        // behind exactly two such refusals (tests' sdpa_host_alloc'ed K and V; profiles/r04/).  $SDPA_PIN_PROBE=0
+        // restores the blind attempt (tools/gpu_register_stress.py compares the two).
+        if (pin_probe()) {
+            hipPointerAttribute_t at;
+            if (hipPointerGetAttributes(&at, lo) != hipSuccess) (void)hipGetLastError();
+            else if (at.type != hipMemoryTypeUnregistered) { us += now_us() - t0; return; }
+        }
         if (hipHostRegister(const_cast<char *>(lo), (size_t)(hi - lo), hipHostRegisterDefault) == hipSuccess)
             ptr.push_back(const_cast<char *>(lo));
         else
@@ -383,7 +430,6 @@ bool want_bf16(int flags) {
 void make_plan(Plan &pl, int m, int n, int dk, int dv, int flags, int ranks = 0) {
     pl.m = m; pl.n = n; pl.dk = dk; pl.dv = dv;
     pl.P = ranks > 0 ? ranks : E.n;
-    pl.cus = (ranks > 0 || E.run_cus <= 0) ? sdpa::kChipCus - comm_cus_reserved(sdpa::kChipCus, pl.P) : E.run_cus;
     pl.bf16 = want_bf16(flags);
     pl.qrows = (flags & SDPA_F_PLAN_QROWS) != 0;
     if (const char *v = getenv("SDPA_PLAN")) pl.qrows = pl.qrows || strcmp(v, "qrows") == 0;
@@ -439,6 +485,13 @@ void make_plan(Plan &pl, int m, int n, int dk, int dv, int flags, int ranks = 0)
     pl.nb = (max_rows + B - 1) / B;
     if (pl.nb < 1) pl.nb = 1;
     if (no_pipe) pl.row_pieces = 1;
+    // the fused launches leave compute units to the comm streams only when this call has a collective tail AND a next
+    // batch whose kernels it can run under; a one-batch call (config 3 at the default batch) gets the whole chip
+    {
+        const int chip = (ranks > 0 || E.chip_cus <= 0) ? sdpa::kChipCus : E.chip_cus;
+        const int reserved = (ranks > 0 || E.run_cus <= 0) ? comm_cus_reserved(chip, pl.P) : chip - E.run_cus;
+        pl.cus = (pl.collectives && pl.nb > 1) ? chip - reserved : chip;
+    }
 
     for (int g = 0; g < pl.P; ++g) {
         RankPlan &rp = pl.r[g];
@@ -556,6 +609,7 @@ int launch_fused(const Plan &pl, Rank &rk, const RankPlan &rp, int s, int bs, in
         a.ldv = dummy ? 4 : pl.ldv;
         a.m = jr; a.n_local = keys > 0 ? keys : 0; a.dk = dummy ? 4 : pl.dk; a.dv = pl.dv;
         a.kv_splits = keys > 0 ? splits : 1;
+        a.cus = pl.cus;
         if (slot0 >= 0 && a.kv_splits == 1) {
             a.contrib = sl_c; a.ldo = pl.ldo; a.lmax = sl_m; a.lsum = sl_s;
         } else {
@@ -763,6 +817,13 @@ struct Call {
     struct Sliver { char *dst; const char *src; size_t bytes; };
     std::vector<Sliver> slivers;
     std::mutex sliver_mu;
+    // host-side widening ($SDPA_HOST_WIDEN): result rows come home as fp32 into page-locked staging `w_base` (row i of the
+    // result at w_base + i*dv floats) and host threads widen them into `result` (which is then never registered)
+    bool widen = false;
+    float *w_base = nullptr;
+    struct WidenPiece { hipEvent_t landed; size_t row0; int rows; };
+    std::vector<WidenPiece> w_pieces;             // in enqueue order (guarded by sliver_mu)
+    double widen_us = 0.0;                        // host time inside the widening calls
     Call() { for (auto &e : enq) e.store(0); }
     int fail(int code) {
         int none = 0;
@@ -799,6 +860,55 @@ int copy_result_rows(Call &c, double *dst_rows, const void *src, size_t bytes, h
     return SDPA_OK;
 }
 
+// Host-side widening (attention-mpi.c:373 / :396: the ROOT widens the reduced rows with cvt_f2d_avx512): rows
+// [row0, row0 + rows) of the result exist as fp32 on rank rk's device -- `src32`, `ld` floats a row, already normalised
+// when lsum == nullptr, else still to be divided by lsum (merge step 5, :358-362).  They are made dense in `dense32`
+// (device), cross PCIe as fp32 -- half the bytes of the fp64 rows -- into the page-locked staging, and the calling
+// thread hands them to the converter pool once `landed` has fired (widen_landed_pieces).
+int ship_rows_f32(Call &c, Rank &rk, size_t row0, int rows, const float *src32, int ld, const float *lsum,
+                  float *dense32, hipStream_t produced_on, hipEvent_t produced, hipStream_t st) {
+    if (rows <= 0) return SDPA_OK;
+    const int dv = c.dv;
+    const float *from = src32;
+    if (lsum || ld != dv) {
+        HIP_TRY(sdpa::launch_finish_f32(src32, ld, lsum, dense32, rows, dv, produced_on));
+        from = dense32;
+    }
+    HIP_TRY(hipEventRecord(produced, produced_on));
+    HIP_TRY(hipStreamWaitEvent(st, produced, 0));
+    HIP_TRY(hipMemcpyAsync(c.w_base + row0 * dv, from, (size_t)rows * dv * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (rk.ev_w_used == (int)rk.ev_w.size()) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        rk.ev_w.push_back(e);
+    }
+    hipEvent_t landed = rk.ev_w[rk.ev_w_used++];
+    HIP_TRY(hipEventRecord(landed, st));
+    std::lock_guard<std::mutex> lk(c.sliver_mu);
+    c.w_pieces.push_back({landed, row0, rows});
+    return SDPA_OK;
+}
+
+// the calling thread, behind the enqueue of the whole call: piece after piece, wait until the fp32 rows are in the
+// staging area (a spin on the event: the call blocks anyway, and the last piece's latency is the call's tail),
+// then widen them into `result` on the pool's threads and this one
+int widen_landed_pieces(Call &c) {
+    for (size_t i = 0; i < c.w_pieces.size(); ++i) {
+        const Call::WidenPiece &w = c.w_pieces[i];
+        for (;;) {
+            const hipError_t e = hipEventQuery(w.landed);
+            if (e == hipSuccess) break;
+            if (e != hipErrorNotReady) HIP_TRY(e);
+            (void)hipGetLastError();
+            cpu_relax();
+        }
+        const double t0 = now_us();
+        E.hc->widen(c.w_base + w.row0 * c.dv, c.result + w.row0 * c.dv, (size_t)w.rows * c.dv);
+        c.widen_us += now_us() - t0;
+    }
+    return SDPA_OK;
+}
+
 // Page-lock the caller's arrays for the duration of the call.  Copies from pages the driver has never
 // seen run at ~11 GB/s on this platform (tools/probes/h2d_probe.cpp); registered ones at ~57 GB/s and
 // truly asynchronously, which the enqueue-then-wait structure relies on for its overlap (it stays
@@ -811,21 +921,22 @@ int copy_result_rows(Call &c, double *dst_rows, const void *src, size_t bytes, h
 // in front of the copies that need it.  Nothing stays registered after the call.
 void pin_stage(Call &c, int stage) {
     if (c.do_pin) {
+        const size_t res_bytes = c.widen ? 0 : (size_t)c.m * c.dv * sizeof(double);   // widened by the host: no DMA into it
         if (c.hostcvt) {
-            if (stage == 3) c.pins.add(c.result, (size_t)c.m * c.dv * sizeof(double));
+            if (stage == 3) c.pins.add(c.result, res_bytes);
         } else if (!c.progressive) {
             if (stage == 0) {
                 c.pins.add(c.K, c.k_bytes);
                 c.pins.add(c.V, c.v_bytes);
                 c.pins.add(c.Q, (size_t)c.m * c.dk * sizeof(double));
-                c.pins.add(c.result, (size_t)c.m * c.dv * sizeof(double));
+                c.pins.add(c.result, res_bytes);
             }
         } else {
             switch (stage) {
                 case 0: for (auto &r : c.pin0) c.pins.add(r.first, r.second); break;
                 case 1: c.pins.add(c.Q, (size_t)c.m * c.dk * sizeof(double)); break;
                 case 2: for (auto &r : c.pin2) c.pins.add(r.first, r.second); break;
-                default: c.pins.add(c.result, (size_t)c.m * c.dv * sizeof(double)); break;
+                default: c.pins.add(c.result, res_bytes); break;
             }
         }
     }
@@ -973,6 +1084,10 @@ int rank_batch(Call &c, int g, int b) {
     // fp64 writeback (attention-mpi.c:358-362, :373), then they go home
     auto finish_rows = [&](int ev, int j0, int jr) -> int {
         need_pin(c, 3);                  // behind the enqueue of (nearly) all of the batch's kernels
+        if (c.widen)
+            return ship_rows_f32(c, rk, i0 + j0, jr, (const float *)rk.contrib[s].p + (size_t)j0 * pl.ldo, pl.ldo,
+                                 (const float *)rk.stat[s].p + bs + j0, (float *)rk.out64[s].p + (size_t)j0 * dv,
+                                 rk.s_run, rk.ev_sub[s][ev], rk.s_out);
         HIP_TRY(sdpa::launch_finish_f64((const float *)rk.contrib[s].p + (size_t)j0 * pl.ldo, pl.ldo,
                                         (const float *)rk.stat[s].p + bs + j0,
                                         (double *)rk.out64[s].p + (size_t)j0 * dv, jr, dv, rk.s_run));
@@ -1108,6 +1223,18 @@ int tail_batch(Call &c, int b) {
             Rank &rk = E.r[g];
             const int r0 = g * share, rows = std::min(share, bs - r0);
             HIP_TRY(hipSetDevice(rk.dev));
+            if (c.widen) {
+                // (the repack, if the rows are padded, runs on the comm stream; ev_comm[s] doubles as "produced")
+                if (g == 0 && mark) HIP_TRY(hipEventRecord(root.ev_tail[3], root.s_comm));
+                SDPA_TRY(ship_rows_f32(c, rk, i0 + r0, rows, (const float *)rk.red[s].p, pl.ldo, nullptr,
+                                       (float *)rk.out64[s].p, rk.s_comm, rk.ev_comm[s], rk.s_out));
+                if (rows <= 0) {
+                    HIP_TRY(hipEventRecord(rk.ev_comm[s], rk.s_comm));
+                    HIP_TRY(hipStreamWaitEvent(rk.s_out, rk.ev_comm[s], 0));
+                }
+                HIP_TRY(hipEventRecord(rk.ev_out[s], rk.s_out));
+                continue;
+            }
             if (rows > 0)
                 HIP_TRY(sdpa::launch_cvt_f2d((const float *)rk.red[s].p, pl.ldo, (double *)rk.out64[s].p, rows, dv,
                                              rk.s_comm));
@@ -1125,17 +1252,24 @@ int tail_batch(Call &c, int b) {
             return coll_fail();
         SDPA_TRY(mark_tail(2));
         HIP_TRY(hipSetDevice(root.dev));
-        HIP_TRY(sdpa::launch_cvt_f2d((const float *)root.red[s].p, pl.ldo, (double *)root.out64[s].p, bs, dv,
-                                     root.s_comm));
+        if (!c.widen)
+            HIP_TRY(sdpa::launch_cvt_f2d((const float *)root.red[s].p, pl.ldo, (double *)root.out64[s].p, bs, dv,
+                                         root.s_comm));
         SDPA_TRY(mark_tail(3));
         for (int g = 0; g < P; ++g) {
+            if (g == 0 && c.widen) continue;                                // (the root's are recorded by ship_rows_f32)
             HIP_TRY(hipSetDevice(E.r[g].dev));
             HIP_TRY(hipEventRecord(E.r[g].ev_comm[s], E.r[g].s_comm));
             HIP_TRY(hipEventRecord(E.r[g].ev_out[s], E.r[g].s_comm));      // (non-roots: nothing leaves)
         }
         HIP_TRY(hipSetDevice(root.dev));
-        HIP_TRY(hipStreamWaitEvent(root.s_out, root.ev_comm[s], 0));
-        SDPA_TRY(copy_result_rows(c, c.result + i0 * dv, root.out64[s].p, (size_t)bs * dv * sizeof(double), root.s_out));
+        if (c.widen) {
+            SDPA_TRY(ship_rows_f32(c, root, i0, bs, (const float *)root.red[s].p, pl.ldo, nullptr, (float *)root.out64[s].p,
+                                   root.s_comm, root.ev_comm[s], root.s_out));
+        } else {
+            HIP_TRY(hipStreamWaitEvent(root.s_out, root.ev_comm[s], 0));
+            SDPA_TRY(copy_result_rows(c, c.result + i0 * dv, root.out64[s].p, (size_t)bs * dv * sizeof(double), root.s_out));
+        }
         HIP_TRY(hipEventRecord(root.ev_out[s], root.s_out));
     }
     return SDPA_OK;
@@ -1175,12 +1309,17 @@ int host_convert_thread_count() {
     return env_int("SDPA_HOST_CVT_THREADS", dflt);
 }
 
-bool want_host_cvt(const Plan &pl) {
+// `pageable`: the caller's input arrays are neither page-locked already nor about to be registered -- the device converts
+// would pull fp64 from pageable memory through the runtime's staging copies (metric shape 11.8 ms, config 3 44.3 ms at
+// the boundary, against 9.7 / 37.0 with host converts and 9.8 / 34.5 registered: profiles/r04/host_register_ab.log)
+bool want_host_cvt(const Plan &pl, bool pageable) {
     const int mode = host_cvt_mode();
     if (mode != 2) return mode == 1;
-    if (pl.P != 1) return false;
     const double elems = (double)pl.m * pl.dk + (double)pl.n * pl.dk + (double)pl.n * pl.dv;
     if (elems < 1e6) return false;                                   // latency bound either way
+    if (pageable)
+        return (int)std::thread::hardware_concurrency() >= 16 && host_convert_thread_count() >= 8;
+    if (pl.P != 1) return false;
     const double t_link = elems * 8.0 / 55e9;                        // fp64 over PCIe Gen5 x16, as measured
     const double rate = pl.bf16 ? 1.0e15 : (pl.dk <= 256 ? 1.3e14 : 1.0e14);
     const double t_kernel = 2.0 * pl.m * (double)pl.n * (pl.dk + pl.dv) / rate;
@@ -1192,6 +1331,26 @@ bool want_host_cvt(const Plan &pl) {
     if ((int)std::thread::hardware_concurrency() < 16 || threads < 8) return false;
     const double t_host = elems * 8.0 / std::min(100e9, threads * 3.2e9);
     return t_link > 1.4 * t_kernel && t_host < t_link;
+}
+
+// ---- where the result is widened to fp64 ($SDPA_HOST_WIDEN) ---------------------------------------------
+// 0 = on the device (finish_f64 / cvt_f2d kernels, fp64 rows cross PCIe into the registered `result`); 1 = on host
+// threads: fp32 rows cross PCIe into page-locked staging and the converter pool widens them into `result`, the
+// reference's own placement (cvt_f2d_avx512 on the root, attention-mpi.c:373 / :396) -- half the D2H bytes, and
+// `result` is never registered (registering a never-touched array faults all its pages in on the calling thread);
+// unset / "auto": on the host when the host has the threads for it (>= 16 hardware threads, >= 8 in the pool) and
+// the result is big enough to be worth waking them (profiles/r04/host_widen_ab.log).
+int host_widen_mode() {
+    const char *v = getenv("SDPA_HOST_WIDEN");
+    if (!v || !*v || strcmp(v, "auto") == 0) return 2;
+    return atoi(v) > 0 ? 1 : 0;
+}
+
+bool want_host_widen(const Plan &pl) {
+    const int mode = host_widen_mode();
+    if (mode != 2) return mode == 1;
+    if ((int)std::thread::hardware_concurrency() < 16 || host_convert_thread_count() < 8) return false;
+    return (double)pl.m * pl.dv >= 256.0 * 1024.0;
 }
 
 // the converter pool is created on first use (32 threads, $SDPA_HOST_CVT_THREADS)
@@ -1267,6 +1426,7 @@ void destroy_rank(Rank &g) {
     for (hipEvent_t e : g.ev_qh) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : g.ev_qp) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : g.ev_k) (void)hipEventDestroy(e);
+    for (hipEvent_t e : g.ev_w) (void)hipEventDestroy(e);
     hipEvent_t evs[] = {g.ev_t0, g.ev_kv_done, g.ev_end, g.ev_tail[0], g.ev_tail[1], g.ev_tail[2], g.ev_tail[3]};
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     if (g.s_cp) (void)hipStreamDestroy(g.s_cp);
@@ -1354,7 +1514,10 @@ int init_impl(int n_gpus) {
             return SDPA_ENODEV;
         }
         SDPA_TRY(create_rank(E.r[i], dev, comm_cus_reserved(prop.multiProcessorCount, want)));
-        if (i == 0) E.run_cus = sdpa::stream_cus(E.r[0].s_run);
+        if (i == 0) {
+            E.run_cus = sdpa::stream_cus(E.r[0].s_run);
+            E.chip_cus = prop.multiProcessorCount;
+        }
     }
     const bool force = getenv("SDPA_FORCE_COLLECTIVES") && atoi(getenv("SDPA_FORCE_COLLECTIVES")) != 0;
     if (want > 1 || force) {
@@ -1402,6 +1565,7 @@ void sdpa_shutdown(void) {
     E.bounce = nullptr;
     E.n = 0;
     E.run_cus = 0;
+    E.chip_cus = 0;
     E.up = false;
     E.virtual_ranks = false;
 }
@@ -1492,7 +1656,8 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
     } join{c};
     struct ClearCuts { ~ClearCuts() { CUT = PinCuts(); } } clear_cuts;
     CUT = PinCuts();
-    c.do_pin = !getenv("SDPA_HOST_REGISTER") || atoi(getenv("SDPA_HOST_REGISTER")) != 0;
+    c.do_pin = register_caller_arrays();
+    const bool pageable_in = !c.do_pin && !(page_locked(K) && page_locked(V) && page_locked(Q));
     c.k_bytes = (size_t)n * dk * sizeof(double);
     c.v_bytes = (size_t)n * dv * sizeof(double);
     const bool want_progressive = !getenv("SDPA_PROGRESSIVE_PIN") || atoi(getenv("SDPA_PROGRESSIVE_PIN")) != 0;
@@ -1520,8 +1685,13 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
     // $SDPA_HOST_CVT=1: host threads write the operand images; submit every conversion now, in the order
     // the copies will ask for them (every rank's chunk 0, the first Q batch, the other chunks, the other
     // batches), and let the enqueue code wait for each piece right before it copies it
+    for (Rank &rk : E.r) rk.ev_w_used = 0;
+    if (want_host_widen(pl) && ensure_host_converter() == SDPA_OK) {
+        c.w_base = (float *)E.hc->staging(3, (size_t)m * dv * sizeof(float));
+        c.widen = c.w_base != nullptr;
+    }
     HI = HostImages();
-    if (!PF.active && want_host_cvt(pl) && ensure_host_converter() == SDPA_OK) {
+    if (!PF.active && want_host_cvt(pl, pageable_in) && ensure_host_converter() == SDPA_OK) {
         const size_t kel = pl.kv_elem, qel = pl.q_elem;
         const int ldv_h = pl.bf16 ? dv : pl.ldv;
         const size_t vel = pl.bf16 ? sizeof(unsigned short) : sizeof(float);
@@ -1619,6 +1789,20 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
     HIP_TRY(hipSetDevice(root.dev));
     HIP_TRY(hipStreamWaitEvent(root.s_out, root.ev_run[(pl.nb - 1) & 1], 0));
     HIP_TRY(hipEventRecord(root.ev_end, root.s_out));
+    double t_landed = 0.0;                             // host clock when the last fp32 piece was in the staging area
+    if (c.widen) {
+        if (!c.w_pieces.empty()) {
+            // (everything but the last piece: widened while the GPU is still producing the later ones)
+            const Call::WidenPiece last = c.w_pieces.back();
+            c.w_pieces.pop_back();
+            SDPA_TRY(widen_landed_pieces(c));
+            c.w_pieces.assign(1, last);
+            while (hipEventQuery(last.landed) == hipErrorNotReady) cpu_relax();
+            (void)hipGetLastError();
+            t_landed = now_us();
+            SDPA_TRY(widen_landed_pieces(c));
+        }
+    }
     for (int g = 0; g < P; ++g) {
         HIP_TRY(hipSetDevice(E.r[g].dev));
         HIP_TRY(hipStreamSynchronize(E.r[g].s_run));
@@ -1630,6 +1814,7 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
     for (const Call::Sliver &sv : c.slivers) memcpy(sv.dst, sv.src, sv.bytes);     // result's partial first / last page
     drain.armed = false;
     const double t_exit = now_us();
+    const double host_tail_us = c.widen && t_landed > 0.0 ? t_exit - t_landed : 0.0;   // the last piece's widening: exposed
 
     HIP_TRY(hipSetDevice(root.dev));
     const int n_brackets = c.n_brackets;
@@ -1655,7 +1840,7 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
         HIP_TRY(hipEventElapsedTime(&ms, root.ev_k[0], root.ev_end));
         T.pipeline_us = ms * 1e3;
         HIP_TRY(hipEventElapsedTime(&ms, root.ev_k[n_brackets - 1], root.ev_end));
-        T.tail_us = ms * 1e3;
+        T.tail_us = ms * 1e3 + host_tail_us;
     }
     T.n_gpus = P;
     T.q_batches = pl.nb;
@@ -1673,7 +1858,7 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
     T.compute_cus = pl.cus;
     T.stream_k = (!pl.bf16 && c.last_keys > 0 &&
                   sdpa::plan_f32_launch(c.last_rows, c.last_keys, dk, dv, pl.cus).streamk) ? 1 : 0;
-    T.host_widen = 0;
+    T.host_widen = c.widen ? 1 : 0;
     T.rccl_selftest = E.coll ? E.coll->selftested_ranks() : 0;
     if (c.tail_marked) {
         HIP_TRY(hipEventElapsedTime(&ms, root.ev_tail[0], root.ev_tail[1]));
@@ -1795,7 +1980,9 @@ int sdpa_prepare(int m, int n, int dk, int dv, int flags) {
     make_plan(pl, m, n, dk, dv, flags);
     SDPA_TRY(check_plan(pl));
     SDPA_TRY(ensure_buffers(pl));
-    if (want_host_cvt(pl)) {      // and the page-locked staging of the host converts (hundreds of MB: not inside a timed call)
+    // and the page-locked staging of the host converts (hundreds of MB: not inside a timed call) -- whenever the real
+    // call COULD take them: it will if its arrays turn out to be pageable (the default no longer registers them)
+    if (want_host_cvt(pl, !register_caller_arrays())) {
         SDPA_TRY(ensure_host_converter());
         const size_t vrow = pl.bf16 ? (size_t)dv * sizeof(unsigned short) : (size_t)pl.ldv * sizeof(float);
         if (!E.hc->staging(0, (size_t)n * pl.ldk * pl.kv_elem) || !E.hc->staging(1, (size_t)n * vrow) ||

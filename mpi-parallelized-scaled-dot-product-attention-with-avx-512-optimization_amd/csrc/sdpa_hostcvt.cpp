@@ -106,6 +106,49 @@ inline void rows_to_bf16(const double *src, unsigned short *dst, long rows, int 
     else rows_to_bf16_scalar(src, dst, rows, cols, ld, mult);
 }
 
+// fp32 -> fp64 of `n` contiguous values: the reference's cvt_f2d_avx512 (attention-mpi.c:68-101, called on the
+// root at :373 / :396), exact.  The AVX-512 form streams its stores past the cache once dst is 64-byte aligned:
+// the caller reads `result` later, from another core as likely as not, and a write-allocate would first READ
+// every line it is about to overwrite.
+void widen_scalar(const float *src, double *dst, size_t n) {
+    for (size_t i = 0; i < n; ++i) dst[i] = (double)src[i];
+}
+
+__attribute__((target("avx512f,avx512bw,avx512vl")))
+void widen_avx512(const float *src, double *dst, size_t n) {
+    size_t i = 0;
+    while (i < n && ((uintptr_t)(dst + i) & 63u)) {
+        dst[i] = (double)src[i];
+        ++i;
+    }
+    for (; i + 8 <= n; i += 8) _mm512_stream_pd(dst + i, _mm512_cvtps_pd(_mm256_loadu_ps(src + i)));
+    for (; i < n; ++i) dst[i] = (double)src[i];
+    _mm_sfence();
+}
+
+inline void widen_range(const float *src, double *dst, size_t n, bool force_scalar = false) {
+    if (!force_scalar && have_avx512()) widen_avx512(src, dst, n);
+    else widen_scalar(src, dst, n);
+}
+
+// one blocking widen() call: the calling thread and every worker that wakes up in time take items from it
+struct WidenJob {
+    const float *src = nullptr;
+    double *dst = nullptr;
+    size_t n = 0, per = 0, items = 0;
+    std::atomic<size_t> next{0};
+    std::atomic<size_t> left{0};
+    void work() {
+        for (;;) {
+            const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= items) return;
+            const size_t e0 = i * per, cnt = n - e0 < per ? n - e0 : per;
+            widen_range(src + e0, dst + e0, cnt);
+            left.fetch_sub(1, std::memory_order_release);
+        }
+    }
+};
+
 struct Task {
     const double *src;
     void *dst;
@@ -149,7 +192,7 @@ public:
     int threads() const override { return (int)th_.size(); }
 
     void *staging(int which, size_t bytes) override {
-        if (which < 0 || which > 2) return nullptr;
+        if (which < 0 || which > 3) return nullptr;
         Buf &b = buf_[which];
         if (b.cap >= bytes && b.p) return b.p;
         if (b.p && hipHostFree(b.p) != hipSuccess) (void)hipGetLastError();
@@ -185,6 +228,7 @@ public:
             std::lock_guard<std::mutex> lk(mu_);
             cur_ = mine_;               // complete: nothing is added to a batch after this
             ++gen_;
+            gen_pub_.store(gen_, std::memory_order_release);
         }
         cv_.notify_all();
     }
@@ -206,6 +250,32 @@ public:
         mine_.reset();
     }
 
+    // blocking: dst[i] = (double)src[i], i < n, spread over the pool; the caller works too, so a pool whose threads
+    // are slow to wake costs nothing but their share
+    void widen(const float *src, double *dst, size_t n) override {
+        if (n == 0) return;
+        const size_t per = 16384;                        // 64 KiB read, 128 KiB written per item
+        const size_t items = (n + per - 1) / per;
+        if (items < 3 || th_.empty()) {
+            widen_range(src, dst, n);
+            return;
+        }
+        auto j = std::make_shared<WidenJob>();
+        j->src = src; j->dst = dst; j->n = n; j->per = per; j->items = items;
+        j->left.store(items, std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            wjob_ = j;
+            ++gen_;
+            gen_pub_.store(gen_, std::memory_order_release);
+        }
+        cv_.notify_all();
+        j->work();
+        while (j->left.load(std::memory_order_acquire) > 0) relax();
+        std::lock_guard<std::mutex> lk(mu_);
+        if (wjob_ == j) wjob_.reset();
+    }
+
 private:
     struct Buf {
         void *p = nullptr;
@@ -213,15 +283,23 @@ private:
     };
     void loop() {
         unsigned long seen = 0;
+        bool hot = false;
         for (;;) {
             std::shared_ptr<Batch> b;
+            std::shared_ptr<WidenJob> w;
+            // the widen jobs of a call come in quick succession (one per piece of result rows): behind one, look
+            // for the next for a moment before going to sleep
+            for (int spin = hot ? 20000 : 0; spin > 0 && gen_pub_.load(std::memory_order_acquire) == seen; --spin) relax();
             {
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
                 if (stop_) return;
                 seen = gen_;
                 b = cur_;
+                w = wjob_;
             }
+            hot = (bool)w;
+            if (w) w->work();
             if (!b) continue;
             const long total = (long)b->items.size();
             for (;;) {
@@ -243,9 +321,11 @@ private:
     std::condition_variable cv_;
     bool stop_ = false;
     unsigned long gen_ = 0;
+    std::atomic<unsigned long> gen_pub_{0};   // gen_, readable without the lock (the workers' short spin)
+    std::shared_ptr<WidenJob> wjob_;   // the widen() call in flight, if any (guarded by mu_)
     std::shared_ptr<Batch> cur_;       // what the threads work on (guarded by mu_)
     std::shared_ptr<Batch> mine_;      // the calling thread's handle on the batch it is building / waiting for
-    Buf buf_[3];
+    Buf buf_[4];
 };
 
 }  // namespace
@@ -261,6 +341,8 @@ void host_convert_rows(const double *src, void *dst, long rows, int cols, int ld
         else rows_to_bf16(src, (unsigned short *)dst, rows, cols, ld, mult);
     }
 }
+
+void host_widen(const float *src, double *dst, size_t n, bool force_scalar) { widen_range(src, dst, n, force_scalar); }
 
 HostConverter *HostConverter::create(int threads) {
     if (threads < 1) threads = 1;

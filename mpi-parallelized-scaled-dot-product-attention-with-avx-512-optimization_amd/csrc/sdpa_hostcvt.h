@@ -21,12 +21,15 @@ enum CvtKind {
 void host_convert_rows(const double *src, void *dst, long rows, int cols, int ld, CvtKind kind, double mult,
                        bool force_scalar);
 
+// dst[i] = (double)src[i] on the calling thread (cvt_f2d_avx512, attention-mpi.c:68-101)
+void host_widen(const float *src, double *dst, size_t n, bool force_scalar);
+
 class HostConverter {
 public:
     static HostConverter *create(int threads);      // nullptr on failure
     virtual ~HostConverter() {}
     virtual int threads() const = 0;
-    // page-locked staging area `which` (0 = K image, 1 = V image, 2 = Q image), grown to `bytes`
+    // page-locked staging area `which` (0 = K image, 1 = V image, 2 = Q image, 3 = fp32 result rows), grown to `bytes`
     virtual void *staging(int which, size_t bytes) = 0;
     // one call: begin(), submit() every conversion in the order the copies will need them, kick();
     // wait(task) in front of the copy that reads the task's output; finish() before the caller's arrays
@@ -36,6 +39,9 @@ public:
     virtual void kick() = 0;
     virtual void wait(int task) = 0;
     virtual void finish() = 0;
+    // fp32 result rows -> the caller's fp64 array, on the pool's threads and the calling one; returns when done.
+    // Independent of begin()/finish(): may be called while a batch of input conversions is still being worked on.
+    virtual void widen(const float *src, double *dst, size_t n) = 0;
 };
 
 }  // namespace sdpa

@@ -89,6 +89,8 @@ struct PartialArgs {
                                    // upper 56 bits equal it, so nothing has to be cleared between launches
     int tune;                      // -DSDPA_ABLATIONS builds only ($SDPA_TUNE): 4 = register-staged kernel
                                    // instead of the pipelined one, 16/32/64 = timing-only ablations
+    int cus;                       // compute units this launch may fill (stream-K grid); 0 = what the stream was
+                                   // registered with (register_stream_cus), the whole chip otherwise
 };
 
 // bf16 variant: Q,K row-major bf16 (ld = dk padded to 64/128/256/512, pad columns zero),
@@ -227,5 +229,8 @@ hipError_t launch_merge_gathered(float *contrib, int ldo, const float *stats, in
                                  int m, int dv, hipStream_t s);
 hipError_t launch_finish_f64(const float *contrib, int ldo, const float *lsum, double *result,
                              int m, int dv, hipStream_t s);
+// the same rows left in fp32, dense (dv floats a row); lsum == nullptr: repack only
+hipError_t launch_finish_f32(const float *contrib, int ldo, const float *lsum, float *out, int m, int dv,
+                             hipStream_t s);
 
 }  // namespace sdpa

@@ -43,7 +43,7 @@ def engine(pkg, monkeypatch):
         for k in ("SDPA_VIRTUAL_GPUS", "SDPA_FORCE_COLLECTIVES", "SDPA_QBATCH", "SDPA_KV_CHUNK_MIN",
                   "SDPA_KV_CHUNK_MAX", "SDPA_ROW_PIECES", "SDPA_PIECE_MIN_ROWS", "SDPA_PLAN", "SDPA_MERGE", "SDPA_PRECISION",
                   "SDPA_EGRESS", "SDPA_ENQUEUE_THREADS", "SDPA_PROGRESSIVE_PIN", "SDPA_HOST_CVT", "SDPA_HOST_CVT_THREADS",
-                  "SDPA_COMM_CUS"):
+                  "SDPA_COMM_CUS", "SDPA_HOST_WIDEN", "SDPA_HOST_REGISTER"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, str(v))
@@ -272,7 +272,9 @@ def test_multi_rank_schedules_agree_bit_for_bit(P, m, n, d, batch, engine, orc, 
         t_old = pkg.last_timing()
         assert t_old["enqueue_threads"] == 1 and t_old["egress"] == 1 and t_old["n_gpus"] == P, t_old
         check(old, want, V, "round-2 schedule, %s" % merge)
-        for knobs in (dict(), dict(SDPA_EGRESS="root"), dict(SDPA_ENQUEUE_THREADS=0), dict(SDPA_PROGRESSIVE_PIN=0)):
+        # (the registered paths of rounds 1-3 -- opt-in since round 4 -- stay covered: progressive and one-go page-locking)
+        for knobs in (dict(), dict(SDPA_EGRESS="root"), dict(SDPA_ENQUEUE_THREADS=0), dict(SDPA_HOST_REGISTER=1),
+                      dict(SDPA_HOST_REGISTER=1, SDPA_PROGRESSIVE_PIN=0), dict(SDPA_HOST_CVT=0, SDPA_HOST_WIDEN=0)):
             pkg = engine(SDPA_MERGE=merge, **common, **knobs)
             for rep in range(3):
                 new = pkg.attention(Q, K, V)
@@ -353,22 +355,108 @@ def test_host_side_convert_gives_the_device_converts_result_bit_for_bit(m, n, dk
         assert t["host_convert_threads"] == threads and t["register_us"] >= 0, t
 
 
-def test_convert_placement_is_chosen_per_problem(engine, orc, O):
-    """$SDPA_HOST_CVT unset: per problem.  Host threads convert when the fp64 inputs would take clearly
-    longer over PCIe than the kernels take (one rank only); the device converts when the kernels cover
-    the transfer anyway, and always with several ranks (they would share the host's convert threads)."""
+# ------------------------------------------------- $SDPA_HOST_WIDEN: the root widens the rows (attention-mpi.c:373, :396) -----
+@pytest.mark.parametrize("m,n,dk,dv,prec,env", [
+    (1000, 9000, 128, 128, None, {}),                                  # one rank: the last chunk's rows leave in pieces
+    (300, 5000, 72, 40, None, {}),                                     # padded rows (ldo 64, dv 40): repacked on the device
+    (700, 3000, 64, 64, None, {"SDPA_QBATCH": 256}),                   # 3 Q batches: the dense32 buffers rotate
+    (260, 5000, 512, 512, "bf16", {}),                                 # bf16 wide kernel
+    (1500, 9000, 128, 128, None, {"SDPA_VIRTUAL_GPUS": 3, "SDPA_QBATCH": 512}),                            # reduce-scatter egress
+    (1500, 9000, 128, 128, None, {"SDPA_VIRTUAL_GPUS": 3, "SDPA_QBATCH": 512, "SDPA_EGRESS": "root"}),    # reduce to the root
+    (700, 6000, 72, 40, None, {"SDPA_VIRTUAL_GPUS": 2, "SDPA_MERGE": "allreduce"}),                       # padded rows through the collectives
+    (900, 7000, 64, 64, None, {"SDPA_VIRTUAL_GPUS": 2, "SDPA_PLAN": "qrows"}),                            # every rank finishes its own rows
+    (300, 5, 64, 64, None, {"SDPA_VIRTUAL_GPUS": 4}),                                                      # n < P: empty shards
+    (5, 700, 64, 64, None, {"SDPA_VIRTUAL_GPUS": 4}),                                                      # m < P: ranks with no row to send home
+])
+def test_host_side_widening_gives_the_device_result_bit_for_bit(m, n, dk, dv, prec, env, engine, orc, O):
+    """$SDPA_HOST_WIDEN=1: the normalised rows cross PCIe as fp32 into page-locked staging and host threads widen them
+    into `result` -- where the reference widens them (cvt_f2d_avx512 on the root, attention-mpi.c:373 / :396).  The
+    device's fp32 value is the same and fp32 -> fp64 is exact: the same result bit for bit, in every egress of the
+    pipeline, with `result` at any alignment (it is never registered in this mode)."""
+    Q, K, V = O.make_inputs(m, n, dk, dv, "D2", seed=m + dk)
+    common = dict(SDPA_KV_CHUNK_MIN=1024, SDPA_KV_CHUNK_MAX=2048, SDPA_PIECE_MIN_ROWS=128, **env)
+    pkg = engine(SDPA_HOST_WIDEN=0, **common)
+    want = pkg.attention(Q, K, V, precision=prec)
+    assert pkg.last_timing()["host_widen"] == 0
+    tol = 1e-2 * max(1.0, float(np.abs(V).max())) if prec == "bf16" else None
+    check(want, orc.attention_f64(Q, K, V), V, "device widening", tol)
+    for threads in (1, 3, 16):
+        pkg = engine(SDPA_HOST_WIDEN=1, SDPA_HOST_CVT_THREADS=threads, **common)
+        for rep in range(2):
+            got = pkg.attention(Q, K, V, precision=prec)
+            assert np.array_equal(got, want), "host widening (%d threads, call %d) differs from the device's" % (threads, rep)
+        t = pkg.last_timing()
+        assert t["host_widen"] == 1 and t["tail_us"] >= 0, t
+    # together with host-side input converts (one pool serves both)
+    pkg = engine(SDPA_HOST_WIDEN=1, SDPA_HOST_CVT=1, SDPA_HOST_CVT_THREADS=8, **common)
+    assert np.array_equal(pkg.attention(Q, K, V, precision=prec), want)
+
+
+def test_widening_placement_is_chosen_per_problem(engine, O):
+    """$SDPA_HOST_WIDEN unset: the host widens when it has the threads and the result is worth waking them for"""
+    import os
     pkg = engine()
+    rng = np.random.default_rng(2)
+    Q, K, V = (rng.uniform(-1, 1, s) for s in ((4096, 128), (2048, 128), (2048, 128)))
+    a = pkg.attention(Q, K, V)
+    big_host = (os.cpu_count() or 1) >= 16
+    assert pkg.last_timing()["host_widen"] == (1 if big_host else 0)
+    assert pkg.attention(Q[:64], K, V).shape == (64, 128)                  # tiny result: the device widens
+    assert pkg.last_timing()["host_widen"] == 0
+    pkg = engine(SDPA_HOST_WIDEN=0)
+    assert np.array_equal(pkg.attention(Q, K, V), a)
+
+
+def test_convert_placement_is_chosen_per_problem(engine, orc, O):
+    """$SDPA_HOST_CVT unset: per problem.  PAGEABLE caller arrays (numpy's) are never registered since round 4, so on a
+    host with the threads for it they always go through the library's page-locked staging (host converts).  Arrays
+    that ARE page-locked (sdpa_host_alloc, the CLI's reader) -- or registered on request, $SDPA_HOST_REGISTER=1 --
+    take the round-3 model: host threads convert when the fp64 inputs would take clearly longer over PCIe than the
+    kernels take (one rank only), the device converts when the kernels cover the transfer anyway."""
+    import ctypes
+    import os
+    big_host = (os.cpu_count() or 1) >= 16
+    pkg = engine()
+    lib = pkg.load()
     Q, K, V = O.make_inputs(260, 5000, 512, 512, "D1", seed=3)            # config 5's dims: copy bound
     got = pkg.attention(Q, K, V, precision="bf16")
-    assert pkg.last_timing()["host_convert_threads"] > 0
+    assert (pkg.last_timing()["host_convert_threads"] > 0) == big_host
+    assert pkg.last_timing()["register_us"] == 0                          # nothing is registered by default
     check(got, orc.attention_f64(Q, K, V), V, "auto -> host converts", 1e-2 * max(1.0, float(np.abs(V).max())))
     rng = np.random.default_rng(1)
     Q, K, V = (rng.uniform(-1, 1, s) for s in ((16384, 128), (16384, 128), (16384, 128)))   # kernel bound
-    pkg.attention(Q, K, V)
-    assert pkg.last_timing()["host_convert_threads"] == 0
+    want = pkg.attention(Q, K, V)
+    assert (pkg.last_timing()["host_convert_threads"] > 0) == big_host    # pageable: staged all the same
     assert pkg.attention(Q[:64], K[:512], V[:512]).shape == (64, 128)     # tiny: latency bound either way
     assert pkg.last_timing()["host_convert_threads"] == 0
-    pkg = engine(SDPA_VIRTUAL_GPUS=2)
+    # the same kernel-bound problem from page-locked caller arrays: the device converts
+    bufs = []
+    def pinned_copy(a):
+        p = lib.sdpa_host_alloc(a.nbytes)
+        assert p
+        bufs.append(p)
+        out = np.ctypeslib.as_array((ctypes.c_double * a.size).from_address(p)).reshape(a.shape)
+        out[...] = a
+        return out
+    try:
+        Qp, Kp, Vp = pinned_copy(Q), pinned_copy(K), pinned_copy(V)
+        got = pkg.attention(Qp, Kp, Vp)
+        assert pkg.last_timing()["host_convert_threads"] == 0 and pkg.last_timing()["register_us"] == 0
+        assert np.array_equal(got, want)
+        del Qp, Kp, Vp
+    finally:
+        for q in bufs:
+            lib.sdpa_host_free(q)
+    # registration on request (rounds 1-3's default): the round-3 model, same bits
+    pkg = engine(SDPA_HOST_REGISTER=1)
+    got = pkg.attention(Q, K, V)
+    assert pkg.last_timing()["host_convert_threads"] == 0 and pkg.last_timing()["register_us"] > 0
+    assert np.array_equal(got, want)
+    pkg = engine(SDPA_VIRTUAL_GPUS=2, SDPA_HOST_REGISTER=1)
     Q, K, V = O.make_inputs(260, 5000, 512, 512, "D1", seed=3)
     pkg.attention(Q, K, V, precision="bf16")
     assert pkg.last_timing()["host_convert_threads"] == 0 and pkg.last_timing()["n_gpus"] == 2
+    pkg = engine(SDPA_VIRTUAL_GPUS=2)                                      # pageable, two ranks: one pool serves both
+    got = pkg.attention(Q, K, V, precision="bf16")
+    assert (pkg.last_timing()["host_convert_threads"] > 0) == big_host
+    check(got, orc.attention_f64(Q, K, V), V, "two ranks, host converts", 1e-2 * max(1.0, float(np.abs(V).max())))

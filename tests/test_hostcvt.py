@@ -71,3 +71,31 @@ def test_argument_checks(pkg):
     assert lib.sdpa_host_cvt_rows(p, p, 1, 4, 4, 2, 1.0, 0) == pkg._lib.SDPA_EINVAL      # unknown kind
     assert lib.sdpa_host_cvt_rows(None, p, 1, 4, 4, 0, 1.0, 0) == pkg._lib.SDPA_EINVAL
     assert lib.sdpa_host_cvt_rows(None, None, 0, 4, 4, 0, 1.0, 0) == 0
+
+
+# ---- the host-side widening of result rows ($SDPA_HOST_WIDEN; cvt_f2d_avx512, attention-mpi.c:68-101) ----
+@pytest.mark.parametrize("n", [0, 1, 7, 8, 9, 1000, 16384 * 3 + 5, 16384 * 40 + 1])
+@pytest.mark.parametrize("threads", [1, 4])
+def test_host_widen_is_exact_for_every_length_alignment_and_thread_count(pkg, n, threads):
+    rng = np.random.default_rng(n + threads)
+    src = rng.standard_normal(n + 3).astype(np.float32)
+    if n > 4:
+        src[1:5] = [np.inf, -0.0, np.float32(1e-45), -np.inf]          # specials and a subnormal survive
+    for off in (0, 1, 3):                                             # dst 64-byte aligned or not
+        dst = np.full(n + 16, -7.0)
+        lib = pkg.load()
+        rc = lib.sdpa_host_widen(src[off:].ctypes.data, dst[off:].ctypes.data, n, threads, 0)
+        assert rc == 0
+        assert np.array_equal(dst[off:off + n], src[off:off + n].astype(np.float64))
+        assert (dst[:off] == -7.0).all() and (dst[off + n:] == -7.0).all(), "wrote outside its range"
+    dst2 = np.empty(n)
+    assert pkg.load().sdpa_host_widen(src.ctypes.data, dst2.ctypes.data, n, 1, 1) == 0      # the plain C loop
+    assert np.array_equal(dst2, src[:n].astype(np.float64))
+
+
+def test_host_widen_argument_errors(pkg):
+    lib = pkg.load()
+    a = np.zeros(4, np.float32)
+    assert lib.sdpa_host_widen(None, a.ctypes.data, 4, 1, 0) == pkg._lib.SDPA_EINVAL
+    assert lib.sdpa_host_widen(a.ctypes.data, None, 4, 1, 0) == pkg._lib.SDPA_EINVAL
+    assert lib.sdpa_host_widen(None, None, 0, 1, 0) == 0

@@ -64,6 +64,8 @@ def main_loop_span(k):
         #  cold ragged-tile DMA block of the stream-K instantiations behind its join block)
         if any((lo2, hi2) != (lo, hi) and lo <= lo2 and hi2 <= hi and mfmas(lo2, hi2) > 0 for lo2, hi2 in back):
             continue                                   # contains another loop
+        if any(l.startswith("\ts_endpgm") for l in k[lo:hi + 1]):
+            continue                                   # block layout again: a tail placed behind the epilogue jumps back
         c = mix(lo, hi)
         n = sum(v for name, v in c.items() if name.startswith("v_mfma"))
         # ties go to the FIRST loop in program order: the fp32 pipelined kernels carry their K/V walk
@@ -103,8 +105,9 @@ def test_wide_kernel_loop_is_spill_free(bf16_asm):
     c = main_loop_mix(kernel_lines(bf16_asm, "fused_bf16_wide_kernelILi512ELi0E"))
     assert c["v_mfma_f32_32x32x16_bf16"] == 128 and c["ds_read_b128"] == 128, c
     assert sum(v for k, v in c.items() if k.startswith("scratch_")) == 0, c
-    # one O tile crosses the back-edge through VGPRs (the accumulator file is completely full)
-    assert c["v_accvgpr_read_b32"] <= 16 and c["v_accvgpr_write_b32"] <= 16, c
+    # at most two O tiles cross the back-edge through VGPRs (the accumulator file is completely full; one tile before
+    # round 4 took the ragged-tile mask -- ~90 VALU instructions per loop trip -- out of the steady-state loop)
+    assert c["v_accvgpr_read_b32"] <= 32 and c["v_accvgpr_write_b32"] <= 32, c
 
 
 def test_tandem_kernel_loop_is_spill_free_and_reads_50_fragments_per_64_mfmas(bf16_asm):

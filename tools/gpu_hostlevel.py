@@ -18,6 +18,12 @@ pkg.init(1)
 # then with host converts (=1) at several thread counts, then the default (auto: chosen per problem); the
 # engine is re-created for each
 hostcvt = "--hostcvt" in sys.argv
+# --widen: A/B of where the result is widened to fp64 -- the device ($SDPA_HOST_WIDEN=0: fp64 rows cross PCIe) or host
+# threads (=1: fp32 rows cross, attention-mpi.c:373/:396), then the default; interleaved twice so that drift shows
+widen = "--widen" in sys.argv
+# --register: what the boundary costs WITHOUT page-locking the caller's arrays ($SDPA_HOST_REGISTER=0) -- fp64 from
+# pageable memory to the device converts, or through the library's own page-locked staging (host converts / host widening)
+register = "--register" in sys.argv
 KNOBS = ("SDPA_QBATCH", "SDPA_KV_CHUNK_MIN", "SDPA_KV_CHUNK_MAX", "SDPA_ROW_PIECES", "SDPA_PIECE_MIN_ROWS", "SDPA_HOST_REGISTER",
          "SDPA_PROGRESSIVE_PIN")
 SWEEP = [{},
@@ -55,12 +61,18 @@ for name in args or ["headline", "config2", "config1"]:
     R, pr = hostbuf(np.zeros((m, d)))
     flags = 2 if prec else 0
     CVT = ([{"SDPA_HOST_CVT": 0}] + [{"SDPA_HOST_CVT": 1, "SDPA_HOST_CVT_THREADS": t} for t in (8, 16, 32, 64)] + [{}]) if hostcvt else [{}]
-    for knobs in (SWEEP if sweep else CVT):
-        for k in KNOBS + ("SDPA_HOST_CVT", "SDPA_HOST_CVT_THREADS"):
+    WID = [{"SDPA_HOST_WIDEN": 0}, {"SDPA_HOST_WIDEN": 1}, {"SDPA_HOST_WIDEN": 0}, {"SDPA_HOST_WIDEN": 1}, {}]
+    REG = [{"SDPA_HOST_REGISTER": 1}, {"SDPA_HOST_REGISTER": 0},
+           {"SDPA_HOST_REGISTER": 0, "SDPA_HOST_CVT": 0, "SDPA_HOST_WIDEN": 0},
+           {"SDPA_HOST_REGISTER": 0, "SDPA_HOST_CVT": 1, "SDPA_HOST_WIDEN": 0},
+           {"SDPA_HOST_REGISTER": 0, "SDPA_HOST_CVT": 1, "SDPA_HOST_WIDEN": 1},
+           {"SDPA_HOST_REGISTER": 1}, {}]
+    for knobs in (SWEEP if sweep else WID if widen else REG if register else CVT):
+        for k in KNOBS + ("SDPA_HOST_CVT", "SDPA_HOST_CVT_THREADS", "SDPA_HOST_WIDEN"):
             os.environ.pop(k, None)
         for k, v in knobs.items():
             os.environ[k] = str(v)
-        if hostcvt:
+        if hostcvt or widen or register:
             pkg.shutdown()
             pkg.init(1)
             if lib.sdpa_prepare(m, n, d, d, flags) != 0:
@@ -76,7 +88,7 @@ for name in args or ["headline", "config2", "config1"]:
         row = {"shape": name, "pinned": pinned, "knobs": knobs}
         for k in ("total_us", "head_us", "tail_us", "register_us", "kv_stage_us", "pipeline_us", "kernel_us"):
             row[k.replace("_us", "_ms")] = round(best[k] / 1e3, 3)
-        for k in ("q_batches", "kv_chunks", "fused_launches", "kv_splits", "host_convert_threads"):
+        for k in ("q_batches", "kv_chunks", "fused_launches", "kv_splits", "host_convert_threads", "host_widen"):
             row[k] = best[k]
         row["kernel_tflops"] = round(4.0 * m * n * d / (best["kernel_us"] * 1e-6) / 1e12, 1)
         print(json.dumps(row), flush=True)

@@ -15,11 +15,18 @@ coll = [r for r in rows if any(k in r[0] for k in ("loop_reduce", "loop_gather",
                                                     "merge_normalise", "cvt_f2d"))]
 t0 = rows[0][1] if rows else 0
 print("%d dispatches, %d fused launches, %d collective kernels" % (len(rows), len(fused), len(coll)))
-n_over = 0
+n_over = n_hideable = n_slow = 0
 tail = coll[-12:] if len(coll) > 48 else coll
 for name, a, b, st in coll:
     over = [(fa, fb, fs) for _, fa, fb, fs in fused if fa < b and fb > a]
     n_over += 1 if over else 0
+    # a tail kernel CAN hide only if fused work of a later batch exists when it becomes ready: a fused launch that is
+    # running at its start or starts within 2 ms of it (the last batch of a call has none: nothing left to run under)
+    hideable = any(fa < a + 2_000_000 and fb > a for _, fa, fb, fs in fused)
+    n_hideable += 1 if hideable else 0
+    # ... and it has only really run UNDER the fused kernel if it did not simply wait for that kernel's end
+    if over and any(abs(b - fb) < 100_000 and (b - a) > 1_000_000 for fa, fb, fs in over):
+        n_slow += 1
     if (name, a, b, st) in tail:
         import re
         mm = re.search(r"(loop_\w+|ncclDevKernel\w*|merge_\w+|cvt_f2d\w*)", name)
@@ -28,3 +35,6 @@ for name, a, b, st in coll:
             short, st, (a - t0) / 1e3, (b - t0) / 1e3, (b - a) / 1e3,
             ", ".join("stream %s %.0f..%.0f us" % (fs, (fa - t0) / 1e3, (fb - t0) / 1e3) for fa, fb, fs in over) or "none"))
 print("collective kernels that ran while a fused kernel was running: %d of %d" % (n_over, len(coll)))
+print("  of the %d that had a later batch's fused kernel to run under: %d did (%.0f %%); %d of them took > 1 ms and ended "
+      "with the fused kernel (started beside it, waited for its slots)" % (
+          n_hideable, n_over, 100.0 * n_over / max(1, n_hideable), n_slow))
