@@ -236,7 +236,8 @@ def boundary_timing(pkg, m, n, d, precision):
     """the reference's own timed region -- entry to exit of attention() with
     fp64 HOST inputs and outputs (H2D, converts, kernels, D2H), engine already initialised.
     Timed twice: with the caller's arrays in page-locked memory from sdpa_host_alloc (what the CLI's
-    reader allocates) and with plain pageable arrays (page-locked inside the call).
+    reader allocates) and with plain pageable arrays (never registered since round 4: their rows go
+    through the library's page-locked staging on host threads).
     Reported next to the device-resident `value`, never as it."""
     import ctypes
     lib = pkg.load()
@@ -253,7 +254,8 @@ def boundary_timing(pkg, m, n, d, precision):
                 "head_ms": t["head_us"] / 1e3, "tail_ms": t["tail_us"] / 1e3,
                 "register_ms": t["register_us"] / 1e3, "kv_stage_ms": t["kv_stage_us"] / 1e3,
                 "pipeline_ms": t["pipeline_us"] / 1e3, "fused_kernel_ms": t["kernel_us"] / 1e3,
-                "fused_launches": t["fused_launches"], "q_batches": t["q_batches"], "kv_chunks": t["kv_chunks"]}
+                "fused_launches": t["fused_launches"], "q_batches": t["q_batches"], "kv_chunks": t["kv_chunks"],
+                "host_convert_threads": t.get("host_convert_threads"), "host_widen": t.get("host_widen")}
 
     def best_of(call, reps=5):
         best = None
@@ -267,7 +269,8 @@ def boundary_timing(pkg, m, n, d, precision):
     pageable = best_of(lambda: pkg.attention(Q, K, V, flags=flags))
     out = fields(pageable)
     out["what"] = ("sdpa_attention_f64: host fp64 in/out incl. PCIe, best of 5 warm calls, 1 GPU; caller arrays "
-                   "pageable (numpy), page-locked inside the call")
+                   "pageable (numpy), not registered: fp64 -> fp32 on host threads into page-locked staging, fp32 rows widened "
+                   "on host threads (host_convert_threads / host_widen say what this call did)")
     bufs = []
     try:
         def pinned(a):

@@ -6,8 +6,9 @@
   * the C host -- one process, `sdpa_attention_f64` on P ranks (here: loopback ranks, $SDPA_VIRTUAL_GPUS=P):
     the same stages from `tail_batch` (csrc/sdpa_host.hip).
 
-Same kernels, same split plan (both launch on a stream that reserves 8 CUs' worth of workgroup slots, so
-both take the same stream-K cuts), same merge algebra, sums in rank order on both sides (the C host's loopback
+Same kernels, same split plan (both launch on a stream that leaves the same number of workgroup slots free -- 16 CUs'
+worth when the call has a next batch to hide a collective tail under, none for a one-batch call -- so both take the
+same stream-K cuts), same merge algebra, sums in rank order on both sides (the C host's loopback
 collectives; the dev-mode gloo adapter of bench.py): the results must agree BIT FOR BIT, P in {2, 3, 8}, with
 ragged shards and several Q batches -- and both within the fp32 tolerance of the fp64 oracle.  (The C host
 streams its K/V shard in chunks under the first batch by default, which is a different -- equally exact --
@@ -27,7 +28,7 @@ RANK = r'''
 import ctypes, importlib, os, sys
 import numpy as np, torch, torch.distributed as dist
 ROOT, PKG, store, out_dir = sys.argv[1:5]
-rank, world, m, n, d, B, seed = (int(x) for x in sys.argv[5:12])
+rank, world, m, n, d, B, seed, reserve = (int(x) for x in sys.argv[5:13])
 for p in (ROOT, os.path.join(ROOT, "oracle")):
     sys.path.insert(0, p)
 import oracle as O
@@ -40,8 +41,8 @@ d_ = bench.HostStagedDist(dist)                 # collectives staged through hos
 try:
     Q, K, V = O.make_inputs(m, n, d, d, "D2", seed=seed)
     be = pkg.HipBackend(dev)
-    sp = ctypes.c_void_p()                      # the C host's compute stream for P > 1: 8 CUs' worth of slots reserved
-    pkg._lib.check(pkg.load().sdpa_dev_stream_create(8, ctypes.byref(sp)), "sdpa_dev_stream_create")
+    sp = ctypes.c_void_p()                      # the C host's compute stream for P > 1: `reserve` CUs' worth of slots stay free
+    pkg._lib.check(pkg.load().sdpa_dev_stream_create(reserve, ctypes.byref(sp)), "sdpa_dev_stream_create")
     with torch.cuda.stream(torch.cuda.ExternalStream(sp.value, device=dev)):
         sa = pkg.ShardedAttention(be, rank, world, d_, merge="gather", egress="scatter")
         c0, cn = pkg.owner_disp(n, world, rank), pkg.owner_count(n, world, rank)
@@ -62,7 +63,7 @@ C_HOST = r'''
 import importlib, os, sys
 import numpy as np
 ROOT, PKG, out = sys.argv[1:4]
-m, n, d, seed = (int(x) for x in sys.argv[4:8])
+m, n, d, seed, cus = (int(x) for x in sys.argv[4:9])
 for p in (ROOT, os.path.join(ROOT, "oracle")):
     sys.path.insert(0, p)
 import oracle as O
@@ -70,7 +71,7 @@ pkg = importlib.import_module(PKG)
 Q, K, V = O.make_inputs(m, n, d, d, "D2", seed=seed)
 res = pkg.attention(Q, K, V)
 t = pkg.last_timing()
-assert t["virtual_ranks"] == 1 and t["egress"] == 2 and t["merge"] == 1 and t["compute_cus"] == 248, t
+assert t["virtual_ranks"] == 1 and t["egress"] == 2 and t["merge"] == 1 and t["compute_cus"] == cus, t
 np.save(out, res)
 '''
 
@@ -86,7 +87,8 @@ def test_python_host_and_c_host_agree_bit_for_bit(world, m, n, B, tmp_path, O):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     procs = [subprocess.Popen([sys.executable, "-c", RANK, ROOT, PKG, store, out_dir] +
-                              [str(x) for x in (r, world, m, n, d, B, seed)], stderr=subprocess.PIPE, text=True, env=env)
+                              [str(x) for x in (r, world, m, n, d, B, seed, 16 if m > B else 0)], stderr=subprocess.PIPE,
+                             text=True, env=env)
              for r in range(world)]
     for p in procs:
         _, err = p.communicate(timeout=600)
@@ -103,7 +105,10 @@ def test_python_host_and_c_host_agree_bit_for_bit(world, m, n, B, tmp_path, O):
     c_out = str(tmp_path / "c_host.npy")
     cenv = dict(env, SDPA_VIRTUAL_GPUS=str(world), SDPA_QBATCH=str(B), SDPA_ROW_PIECES="1",
                 SDPA_KV_CHUNK_MIN=str(1 << 22), SDPA_KV_CHUNK_MAX=str(1 << 22), SDPA_HOST_CVT="0")
-    r = subprocess.run([sys.executable, "-c", C_HOST, ROOT, PKG, c_out] + [str(x) for x in (m, n, d, seed)],
+    # 16 compute units' worth of workgroup slots stay free for the comm streams when the call has a NEXT batch to hide a
+    # collective tail under (csrc/sdpa_host.hip: comm_cus_reserved, make_plan); a one-batch call gets the whole chip
+    cus = 240 if m > B else 256
+    r = subprocess.run([sys.executable, "-c", C_HOST, ROOT, PKG, c_out] + [str(x) for x in (m, n, d, seed, cus)],
                        capture_output=True, text=True, timeout=600, env=cenv)
     assert r.returncode == 0, r.stderr[-2500:]
     c = np.load(c_out)
