@@ -995,6 +995,8 @@ bool plan_progressive_pins(Call &c) {
 
 // Everything rank g enqueues for Q batch b: its inputs (K/V chunks with the first batch), the fused
 // launches, and -- when it finishes its rows itself (no merge collective) -- finish + D2H.
+constexpr int kStageAhead = 2;            // host converts: chunks staged ahead of the launch that is being enqueued
+
 int rank_batch(Call &c, int g, int b) {
     const Plan &pl = c.pl;
     Rank &rk = E.r[g];
@@ -1049,15 +1051,25 @@ int rank_batch(Call &c, int g, int b) {
     }
     // the chunks behind the first: enqueued AFTER chunk 0's launches (see below), so that a rank's first
     // kernel is issued before the host spends time on the K/V remainders' registration
+    // With HOST converts staging a chunk WAITS (on this thread) until the pool has written its rows: staging every
+    // chunk before chunk 1's launch held that launch back until the whole shard was converted -- the compute stream
+    // sat idle for 2.7 ms of config 3's call and 0.7 ms of the metric shape's (profiles/r04/boundary_timeline_*.txt).
+    // So they are staged a few chunks ahead of the launch that needs them (device converts: all at once, nothing waits).
     bool rest_staged = b != 0;
-    auto stage_rest = [&]() -> int {
+    int staged_hi = 0;
+    auto stage_upto = [&](int hi) -> int {
         if (rest_staged) return SDPA_OK;
-        rest_staged = true;
         need_pin(c, 2);
-        for (int ch = 1; ch < C; ++ch) SDPA_TRY(stage_chunk(pl, rk, rp, g, c.K, c.V, ch));
-        if (g == 0) HIP_TRY(hipEventRecord(rk.ev_kv_done, rk.s_in));
+        hi = std::min(hi, C - 1);
+        for (int ch = staged_hi + 1; ch <= hi; ++ch) SDPA_TRY(stage_chunk(pl, rk, rp, g, c.K, c.V, ch));
+        staged_hi = std::max(staged_hi, hi);
+        if (staged_hi >= C - 1) {
+            rest_staged = true;
+            if (g == 0) HIP_TRY(hipEventRecord(rk.ev_kv_done, rk.s_in));
+        }
         return SDPA_OK;
     };
+    auto stage_rest = [&]() -> int { return stage_upto(C - 1); };
 
     // compute stream.  contrib[s] / stat[s] / out64[s] were last used by batch b-2: by its finish + D2H
     // (ev_out[s]) when this rank finishes its rows itself, by its collective tail on the comm stream
@@ -1105,7 +1117,7 @@ int rank_batch(Call &c, int g, int b) {
         const int k0 = streamed ? rp.chunks[ch].k0 : 0;
         const int keys = streamed ? rp.chunks[ch].keys : rp.key_cnt;
         // a launch that needs chunks behind the first (a later chunk, or the whole shard at once)
-        if (!(streamed && first)) SDPA_TRY(stage_rest());
+        if (!(streamed && first)) SDPA_TRY(stage_upto((streamed && HI.cv) ? ch + kStageAhead : C - 1));
         if (b == 0 && C > 0) HIP_TRY(hipStreamWaitEvent(rk.s_run, rk.ev_kv[streamed ? ch : C - 1], 0));
         const int np = in_pieces ? pieces : 1;
         for (int j = 0; j < np; ++j) {
