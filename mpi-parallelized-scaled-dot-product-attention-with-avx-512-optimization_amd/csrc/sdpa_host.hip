@@ -459,7 +459,23 @@ void make_plan(Plan &pl, int m, int n, int dk, int dv, int flags, int ranks = 0)
     // 32768 rows = 256 query blocks: with 2 in-launch splits that is one full wave of 512
     // workgroups, the shape the fused kernel runs fastest at
     int B = env_int("SDPA_QBATCH", 32768);
-    int cmin = env_int("SDPA_KV_CHUNK_MIN", 4096), cmax = env_int("SDPA_KV_CHUNK_MAX", 16384);
+    // The largest K/V chunk of a streamed shard, when $SDPA_KV_CHUNK_MAX does not say: how long the inputs take to
+    // arrive (fp64 over the link, or through the host's convert pool: ~70 GB/s either way) against how long the kernels
+    // take.  Kernel bound (metric shape, configs 3 / 4): data is far ahead of the kernels, a launch costs ~25 us of
+    // ramp and tail, so chunks grow to 65536 keys (config 3: 18 -> 8 chunks, 33.3 -> 32.6 ms).  Feed bound (config 5 in
+    // bf16: 671 MB in for 4 ms of kernel): what counts is how little kernel is left when the last rows arrive: 8192
+    // (8.7 -> 7.8 ms).  profiles/r04/host_sweep_pageable_incremental.log
+    int cmax_dflt = 16384;
+    {
+        const int Pn = ranks > 0 ? ranks : std::max(1, E.n);
+        const double keys_r = (double)n / Pn;
+        const double t_feed = ((double)m * dk + keys_r * (dk + dv)) * 8.0 / 70e9;
+        const double rate = want_bf16(flags) ? 1.0e15 : (dk <= 256 ? 1.3e14 : 1.0e14);
+        const double t_kernel = 2.0 * m * keys_r * (dk + dv) / rate;
+        if (t_feed > t_kernel) cmax_dflt = 8192;
+        else if (t_feed < 0.5 * t_kernel) cmax_dflt = 65536;
+    }
+    int cmin = env_int("SDPA_KV_CHUNK_MIN", 4096), cmax = env_int("SDPA_KV_CHUNK_MAX", cmax_dflt);
     cmin = std::max(1024, cmin / 1024 * 1024);
     cmax = std::max(cmin, cmax / 1024 * 1024);
     pl.row_pieces = std::min(kMaxSub, env_int("SDPA_ROW_PIECES", 4));
@@ -995,7 +1011,10 @@ bool plan_progressive_pins(Call &c) {
 
 // Everything rank g enqueues for Q batch b: its inputs (K/V chunks with the first batch), the fused
 // launches, and -- when it finishes its rows itself (no merge collective) -- finish + D2H.
-constexpr int kStageAhead = 2;            // host converts: chunks staged ahead of the launch that is being enqueued
+// host converts: chunks staged ahead of the launch that is being enqueued.  One is enough -- chunk ch+1's copy then
+// runs under chunk ch's kernel, and the wait for chunk ch+2's conversion happens under it too -- and with chunk sizes
+// that double, every further chunk of look-ahead holds a launch back until twice as many rows are converted
+constexpr int kStageAhead = 1;
 
 int rank_batch(Call &c, int g, int b) {
     const Plan &pl = c.pl;

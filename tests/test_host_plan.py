@@ -79,10 +79,13 @@ def test_query_row_sharded_plan(m, n, dk, dv, ranks, pkg, orc):
 
 
 def test_metric_shape_schedule_is_the_documented_one(pkg):
-    """chunks of 4096, 4096, 8192, 16384, ... keys, 4 row pieces of 8192 rows"""
+    """chunks of 4096, 4096, 8192, 16384, ... keys, 4 row pieces of 8192 rows; the largest chunk by how the
+    feed time compares with the kernel time (round 4): 65536 keys when kernel bound, 8192 when feed bound"""
     pl = pkg.plan(32768, 65536, 128, 128)
     rp = pl["r"][0]
-    assert [c[1] for c in rp["chunks"]] == [4096, 4096, 8192, 16384, 16384, 16384]
+    assert [c[1] for c in rp["chunks"]] == [4096, 4096, 8192, 16384, 32768]
+    assert [c[1] for c in pkg.plan(32768, 262144, 128, 128)["r"][0]["chunks"]] == [4096, 4096, 8192, 16384, 32768, 65536, 65536, 65536]
+    assert [c[1] for c in pkg.plan(32768, 65536, 512, 512, SDPA_F_BF16)["r"][0]["chunks"]] == [4096, 4096] + [8192] * 7
     assert pl["row_pieces"] == 4 and rp["piece_rows"] == 8192 and pl["q_batches"] == 1
     # config 4: four Q batches over the same K/V schedule
     assert pkg.plan(131072, 65536, 128, 128)["q_batches"] == 4
