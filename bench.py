@@ -772,8 +772,10 @@ def main():
                     help="launch the fused kernels on a stream that leaves this many compute units (multiple of 8) to "
                          "other streams, so that RCCL's kernels of step k can run UNDER step k+1's fused kernel instead "
                          "of waiting for its last workgroup (a fused launch otherwise holds every wave slot of the chip). "
-                         "-1 = the C host's default: 8 when N > 1, 0 at N = 1.  The fused kernel sizes its stream-K grid "
-                         "by the stream's compute units, so this costs reserve/256 of its rate and no more")
+                         "-1 = the C host's default: 16 when N > 1 (with 8 a co-resident kernel starts beside the fused kernel but "
+                         "finishes with it: profiles/r04/config4_one_rank_forced_collectives_overlap_reserve*.txt), 0 at N = 1.  "
+                         "The fused kernel sizes its stream-K grid by the stream's compute units, so this costs about "
+                         "reserve/256 of its rate and no more")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
                     help="operand precision of the fused kernel (the headline metric is f32)")
     ap.add_argument("--min-gpu-seconds", type=float, default=2.0,
@@ -866,7 +868,7 @@ def main():
     prewarm_steps = job.prewarm_steps(args.prewarm_ms)
     import contextlib
     compute = contextlib.nullcontext()
-    reserve = args.reserve_cus if args.reserve_cus >= 0 else (8 if (dist is not None and not qrows and world > 1) else 0)
+    reserve = args.reserve_cus if args.reserve_cus >= 0 else (16 if (dist is not None and not qrows and world > 1) else 0)
     if reserve > 0:
         import ctypes
         sp = ctypes.c_void_p()
