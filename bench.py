@@ -772,8 +772,9 @@ def main():
                     help="launch the fused kernels on a stream that leaves this many compute units (multiple of 8) to "
                          "other streams, so that RCCL's kernels of step k can run UNDER step k+1's fused kernel instead "
                          "of waiting for its last workgroup (a fused launch otherwise holds every wave slot of the chip). "
-                         "-1 = the C host's default: 16 when N > 1 (with 8 a co-resident kernel starts beside the fused kernel but "
-                         "finishes with it: profiles/r04/config4_one_rank_forced_collectives_overlap_reserve*.txt), 0 at N = 1.  "
+                         "-1 = the C host's default: 16 when N > 1 and a rank's step holds less than ~3.3 ms of kernel (with 8 a "
+                         "co-resident kernel starts beside the fused kernel but finishes with it: "
+                         "profiles/r04/config4_one_rank_forced_collectives_overlap_reserve*.txt), else 0.  "
                          "The fused kernel sizes its stream-K grid by the stream's compute units, so this costs about "
                          "reserve/256 of its rate and no more")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
@@ -868,7 +869,11 @@ def main():
     prewarm_steps = job.prewarm_steps(args.prewarm_ms)
     import contextlib
     compute = contextlib.nullcontext()
-    reserve = args.reserve_cus if args.reserve_cus >= 0 else (16 if (dist is not None and not qrows and world > 1) else 0)
+    # (the C host's rule, make_plan: 16 compute units' worth of slots cost the fused kernel 7.6-7.9 % and hide a tail of
+    #  ~0.25 ms, which pays below ~3.3 ms of kernel per step and rank: N >= 3 at the metric shape)
+    t_rank = 4.0 * job.m * (job.n / max(world, 1)) * job.d / (1.0e15 if args.precision == "bf16" else 1.3e14)
+    reserve = args.reserve_cus if args.reserve_cus >= 0 else (
+        16 if (dist is not None and not qrows and world > 1 and t_rank < 3.3e-3) else 0)
     if reserve > 0:
         import ctypes
         sp = ctypes.c_void_p()

@@ -506,7 +506,15 @@ void make_plan(Plan &pl, int m, int n, int dk, int dv, int flags, int ranks = 0)
     {
         const int chip = (ranks > 0 || E.chip_cus <= 0) ? sdpa::kChipCus : E.chip_cus;
         const int reserved = (ranks > 0 || E.run_cus <= 0) ? comm_cus_reserved(chip, pl.P) : chip - E.run_cus;
-        pl.cus = (pl.collectives && pl.nb > 1) ? chip - reserved : chip;
+        // ... and only where it pays: leaving 16 of 256 compute units' worth of slots free costs a batch's kernels
+        // 7.6-7.9 % (a 1/2 share of the metric shape 3.93 -> 4.22 ms, a 1/8 share 1.03 -> 1.12:
+        // profiles/r04/rank_share_*.json) and hides a tail of ~0.25 ms, i.e. pays below ~3.3 ms of kernel per batch
+        // ($SDPA_COMM_CUS set: the caller decides)
+        const double rate = pl.bf16 ? 1.0e15 : (dk <= 256 ? 1.3e14 : 1.0e14);
+        const double t_batch = 2.0 * B * ((double)n / pl.P) * (dk + dv) / rate;
+        const char *forced = getenv("SDPA_COMM_CUS");
+        const bool pays = (forced && *forced) || t_batch < 3.3e-3;
+        pl.cus = (pl.collectives && pl.nb > 1 && pays) ? chip - reserved : chip;
     }
 
     for (int g = 0; g < pl.P; ++g) {
@@ -1976,12 +1984,13 @@ int sdpa_plan_describe(int m, int n, int dk, int dv, int flags, int ranks, char 
     Plan pl;
     make_plan(pl, m, n, dk, dv, flags, ranks);
     std::string o;
-    char t[256];
+    char t[320];
     snprintf(t, sizeof t, "{\"ranks\": %d, \"bf16\": %d, \"qrows\": %d, \"collectives\": %d, \"merge_allreduce\": %d, "
-             "\"egress\": \"%s\", \"q_batch\": %d, \"q_batches\": %d, \"row_pieces\": %d, \"piece_min_rows\": %d, \"r\": [",
+             "\"egress\": \"%s\", \"q_batch\": %d, \"q_batches\": %d, \"row_pieces\": %d, \"piece_min_rows\": %d, "
+             "\"compute_cus\": %d, \"r\": [",
              pl.P, pl.bf16 ? 1 : 0, pl.qrows ? 1 : 0, pl.collectives ? 1 : 0, pl.merge_allreduce ? 1 : 0,
              !pl.collectives ? "own rows" : pl.egress_scatter ? "reduce-scatter" : "root", pl.B, pl.nb,
-             pl.row_pieces, pl.piece_min_rows);
+             pl.row_pieces, pl.piece_min_rows, pl.cus);
     o += t;
     for (int g = 0; g < pl.P; ++g) {
         const RankPlan &rp = pl.r[g];

@@ -94,6 +94,23 @@ def test_metric_shape_schedule_is_the_documented_one(pkg):
     assert all([c[1] for c in r["chunks"]] == [4096, 4096, 8192, 16384] for r in p8["r"])
 
 
+def test_compute_units_are_left_to_the_comm_streams_only_where_it_pays(pkg, monkeypatch):
+    """16 of 256 compute units' worth of workgroup slots stay free for the comm streams when the call merges over several
+    ranks, has a next batch to hide a tail under, and a batch's kernels are short enough for the hidden tail (~0.25 ms)
+    to outweigh the 7.6-7.9 % they cost (make_plan; profiles/r04/rank_share_*.json)"""
+    monkeypatch.delenv("SDPA_COMM_CUS", raising=False)
+    assert pkg.plan(131072, 65536, 128, 128, 0, 8)["compute_cus"] == 240      # config 4 on 8 ranks: 4 batches of ~1 ms
+    assert pkg.plan(131072, 65536, 128, 128, 0, 4)["compute_cus"] == 240      # ~2.1 ms
+    assert pkg.plan(131072, 65536, 128, 128, 0, 2)["compute_cus"] == 256      # ~4.2 ms of kernel per batch: not worth 0.3 ms
+    assert pkg.plan(32768, 65536, 128, 128, 0, 8)["compute_cus"] == 256       # one batch: nothing to hide a tail under
+    assert pkg.plan(131072, 65536, 128, 128, 0, 1)["compute_cus"] == 256      # one rank: no collective
+    assert pkg.plan(131072, 65536, 128, 128, SDPA_F_PLAN_QROWS, 8)["compute_cus"] == 256
+    monkeypatch.setenv("SDPA_COMM_CUS", "32")
+    assert pkg.plan(131072, 65536, 128, 128, 0, 2)["compute_cus"] == 224      # the caller decides
+    monkeypatch.setenv("SDPA_COMM_CUS", "0")
+    assert pkg.plan(131072, 65536, 128, 128, 0, 8)["compute_cus"] == 256
+
+
 def test_knobs(pkg, monkeypatch):
     base = pkg.plan(100000, 100000, 128, 128)
     assert base["q_batch"] == 32768 and base["q_batches"] == 4
