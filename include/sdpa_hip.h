@@ -191,7 +191,9 @@ SDPA_API int sdpa_last_timing(struct sdpa_timing *out);
 SDPA_API int sdpa_prepare(int m, int n, int dk, int dv, int flags);
 
 /* The schedule sdpa_attention_f64 would run for this problem on `ranks` ranks (1..16), as one JSON
- * object in buf: Q batch size and count, row pieces, and per rank its K/V rows (owner_count /
+ * object in buf: Q batch size and count, row pieces, the compute units the fused launches may use
+ * ("compute_cus": the chip, or 16 fewer when the call leaves workgroup slots to the comm streams),
+ * and per rank its K/V rows (owner_count /
  * owner_disp, attention-mpi.c:19-27) or query rows (SDPA_F_PLAN_QROWS), the streamed K/V chunks
  * [first key, keys, in-launch splits, first slot] and the scratch it needs.  Reads the same
  * environment knobs as the call itself.  Pure host arithmetic: needs no GPU and no engine.
