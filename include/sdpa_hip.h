@@ -228,7 +228,8 @@ SDPA_API void  sdpa_host_free(void *p);
  * the device converters' roundings bit for bit.  kind 0: float rows of `ld` floats, pad columns zero
  * (cvt_d2f_avx512, attention-mpi.c:31-64: vcvtpd2ps, 8 doubles at a time, where the CPU has AVX-512);
  * kind 1: bf16 rows, bf16((float)(x * mult)), both roundings to nearest even.  flags bit 0: the plain C
- * rows instead of the AVX-512 ones.  This is what $SDPA_HOST_CVT=1 runs on a pool of host threads inside
+ * rows instead of the AVX-512 ones; bit 1 / bit 2: streaming (non-temporal) stores for line-aligned
+ * destination rows on / off (neither: the pool's default, $SDPA_HOST_CVT_NT) -- the same bytes either way.  This is what $SDPA_HOST_CVT=1 runs on a pool of host threads inside
  * sdpa_attention_f64 (the reference's own placement of the converts, :224-225, :303); it needs no GPU.  */
 SDPA_API int sdpa_host_cvt_rows(const double *src, void *dst, long rows, int cols, int ld, int kind,
                                 double mult, int flags);

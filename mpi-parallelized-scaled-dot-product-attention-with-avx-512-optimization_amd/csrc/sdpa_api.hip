@@ -235,7 +235,7 @@ int sdpa_host_cvt_rows(const double *src, void *dst, long rows, int cols, int ld
     if (rows == 0) return SDPA_OK;
     if (!src || !dst) return SDPA_EINVAL;
     sdpa::host_convert_rows(src, dst, rows, cols, ld, kind == 0 ? sdpa::kCvtF32 : sdpa::kCvtBf16, kind == 0 ? 1.0 : mult,
-                            (flags & 1) != 0);
+                            (flags & 1) != 0, (flags & 2) ? 1 : (flags & 4) ? 0 : -1);
     return SDPA_OK;
 }
 

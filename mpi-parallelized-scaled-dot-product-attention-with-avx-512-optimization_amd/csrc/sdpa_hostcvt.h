@@ -17,9 +17,16 @@ enum CvtKind {
     kCvtBf16 = 1,     // bf16 image, rows padded to ld, values bf16((float)(x * mult)) (cvt_d2bf_kernel)
 };
 
-// `rows` rows on the calling thread (AVX-512 where the CPU has it; force_scalar: the plain-C rows)
+// Streaming (non-temporal) stores in the AVX-512 rows: whole 64-byte lines written past the cache wherever a row's
+// destination is line-aligned (the staging images are).  $SDPA_HOST_CVT_NT overrides this default.
+#ifndef SDPA_HOST_CVT_NT_DEFAULT
+#define SDPA_HOST_CVT_NT_DEFAULT 1
+#endif
+
+// `rows` rows on the calling thread (AVX-512 where the CPU has it; force_scalar: the plain-C rows;
+// stream_stores: 1 / 0 = streaming stores on / off, -1 = the default)
 void host_convert_rows(const double *src, void *dst, long rows, int cols, int ld, CvtKind kind, double mult,
-                       bool force_scalar);
+                       bool force_scalar, int stream_stores = -1);
 
 // dst[i] = (double)src[i] on the calling thread (cvt_f2d_avx512, attention-mpi.c:68-101)
 void host_widen(const float *src, double *dst, size_t n, bool force_scalar);

@@ -63,6 +63,37 @@ def test_bf16_rows_are_the_device_converters_two_roundings(cols, ld, mult, pkg):
         assert not got[:, cols:].any()
 
 
+def _aligned(rows, ld, dtype, offset_bytes=0):
+    """a (rows, ld) array whose first byte sits `offset_bytes` behind a 64-byte boundary"""
+    item = np.dtype(dtype).itemsize
+    raw = np.full(rows * ld * item + 128, 0x7f, dtype=np.uint8)
+    start = (-raw.ctypes.data) % 64 + offset_bytes
+    return raw[start:start + rows * ld * item].view(dtype).reshape(rows, ld)
+
+
+@pytest.mark.parametrize("kind,cols,ld", [(0, 128, 128), (0, 512, 512), (0, 100, 128), (0, 72, 128), (0, 16, 16), (0, 300, 304), (0, 9, 12),
+                                          (1, 128, 128), (1, 512, 512), (1, 100, 128), (1, 250, 256), (1, 32, 32), (1, 13, 16)])
+@pytest.mark.parametrize("offset", [0, 16, 4])
+def test_streaming_store_rows_write_the_same_bytes(kind, cols, ld, offset, pkg):
+    """flags bit 1: streaming (non-temporal) stores for line-aligned destination rows -- whole 64-byte lines of a row,
+    ordinary stores for unaligned rows, row tails and pad columns: the SAME image as the ordinary rows, at any
+    destination alignment (rows of a 64-byte multiple stay aligned, others alternate)"""
+    lib = pkg.load()
+    x = np.ascontiguousarray(samples(41, cols, 7 * cols + kind))
+    mult = 1.0 if kind == 0 else 0.1275
+    dt = np.float32 if kind == 0 else np.uint16
+    if offset % np.dtype(dt).itemsize:
+        pytest.skip("not an element boundary")
+    outs = []
+    for flags in (4, 2, 1):                                   # ordinary stores, streaming stores, plain C
+        dst = _aligned(41, ld, dt, offset)
+        assert lib.sdpa_host_cvt_rows(x.ctypes.data, dst.ctypes.data, 41, cols, ld, kind, mult, flags) == 0
+        outs.append(dst.copy())
+    assert np.array_equal(outs[0].view(np.uint8), outs[1].view(np.uint8))
+    assert np.array_equal(outs[0].view(np.uint8), outs[2].view(np.uint8))
+    assert not outs[1][:, cols:].any()
+
+
 def test_argument_checks(pkg):
     lib = pkg.load()
     buf = (ctypes.c_double * 16)()
