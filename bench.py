@@ -169,7 +169,7 @@ def cpu_baseline(m, n, d, budget_rows=8192):
 
 
 # the translation units (and their shared headers) that define the fused kernels of one precision
-KERNEL_SOURCES = {"f32": ("sdpa_fwd_f32.hip", "sdpa_fwd_f32_dksplit.hip", "sdpa_f32_device.h", "sdpa_internal.h"),
+KERNEL_SOURCES = {"f32": ("sdpa_fwd_f32.hip", "sdpa_fwd_f32_pipelined.inc", "sdpa_fwd_f32_dksplit.hip", "sdpa_f32_device.h", "sdpa_internal.h"),
                   "bf16": ("sdpa_fwd_bf16.hip", "sdpa_internal.h")}
 
 
@@ -232,7 +232,7 @@ def parity_check(res_rows, rows, Q64, kv_shards, precision):
     return err, tol
 
 
-def boundary_timing(pkg, m, n, d, precision):
+def boundary_timing(pkg, m, n, d, precision, reps=5, warm=3, pinned_leg=True, inputs=None):
     """the reference's own timed region -- entry to exit of attention() with
     fp64 HOST inputs and outputs (H2D, converts, kernels, D2H), engine already initialised.
     Timed twice: with the caller's arrays in page-locked memory from sdpa_host_alloc (what the CLI's
@@ -241,8 +241,11 @@ def boundary_timing(pkg, m, n, d, precision):
     Reported next to the device-resident `value`, never as it."""
     import ctypes
     lib = pkg.load()
-    rng = np.random.default_rng(99)
-    Q, K, V = (rng.uniform(-1, 1, s) for s in ((m, d), (n, d), (n, d)))
+    if inputs is None:
+        rng = np.random.default_rng(99)
+        Q, K, V = (rng.uniform(-1, 1, s) for s in ((m, d), (n, d), (n, d)))
+    else:
+        Q, K, V = inputs
     pkg.init(1)
     flags = 2 if precision == "bf16" else 0
     check = lib.sdpa_prepare(m, n, d, d, flags)
@@ -255,9 +258,10 @@ def boundary_timing(pkg, m, n, d, precision):
                 "register_ms": t["register_us"] / 1e3, "kv_stage_ms": t["kv_stage_us"] / 1e3,
                 "pipeline_ms": t["pipeline_us"] / 1e3, "fused_kernel_ms": t["kernel_us"] / 1e3,
                 "fused_launches": t["fused_launches"], "q_batches": t["q_batches"], "kv_chunks": t["kv_chunks"],
-                "host_convert_threads": t.get("host_convert_threads"), "host_widen": t.get("host_widen")}
+                "host_convert_threads": t.get("host_convert_threads"), "host_widen": t.get("host_widen"),
+                "last_kernel": t.get("last_kernel"), "streamed": t.get("streamed")}
 
-    def best_of(call, reps=5):
+    def best_of(call, reps=reps):
         best = None
         for _ in range(reps):
             call()
@@ -271,10 +275,21 @@ def boundary_timing(pkg, m, n, d, precision):
     R = np.zeros((m, d))
     call_pageable = lambda: pkg._lib.check(lib.sdpa_attention_f64(Q.ctypes.data, K.ctypes.data, V.ctypes.data, R.ctypes.data,
                                                                    m, n, d, d, flags), "sdpa_attention_f64")
-    for _ in range(3):
+    for _ in range(warm):
         call_pageable()
     pageable = best_of(call_pageable)
     out = fields(pageable)
+    # the call certifies itself as well: 16 rows of the last call against the fp64 restatement
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    prow = np.sort(np.random.default_rng(5).choice(m, min(16, m), replace=False))
+    want = O.numpy_attention_f64(Q, K, V, prow)
+    out["parity_max_err"] = float(np.abs(R[prow] - want).max()) if np.isfinite(R).all() else float("inf")
+    out["parity_tol"] = (1e-2 if precision == "bf16" else 5e-5) * max(1.0, float(np.abs(V).max()))
+    if not pinned_leg:
+        out["what"] = ("sdpa_attention_f64: host fp64 in/out incl. PCIe, best of %d warm calls (%d untimed first), 1 GPU; caller "
+                       "arrays pageable (numpy), nothing registered" % (reps, warm))
+        return out
     out["what"] = ("sdpa_attention_f64: host fp64 in/out incl. PCIe, best of 5 warm calls (3 untimed first), 1 GPU; caller arrays "
                    "pageable (numpy), not registered: fp64 -> fp32 on host threads into page-locked staging, fp32 rows widened "
                    "on host threads (host_convert_threads / host_widen say what this call did)")
@@ -392,8 +407,22 @@ class HostStagedDist:
         self._d.destroy_process_group()
 
 
+def launched_kernel(pkg, d, precision):
+    """The dominant kernel as the LAUNCHER recorded it (sdpa_dev_last_launch: name as rocprofv3 prints it, grid, slabs,
+    stream-K or not) -- what ran on this thread's last fused launch, not a prediction.  A library
+    without the entry point (an older build loaded for an A/B): the round-4 guess, marked as such."""
+    try:
+        rec = pkg.last_launch()
+        if rec.get("kernel"):
+            rec["source"] = "sdpa_dev_last_launch (recorded by the launcher)"
+            return rec
+    except Exception:  # noqa: BLE001
+        pass
+    return {"kernel": kernel_name_of(d, precision), "source": "guessed from the shape (library without sdpa_dev_last_launch)"}
+
+
 def kernel_name_of(d, precision):
-    """the dominant kernel's name as rocprofv3 prints it (for the reader of the line and of profiles/)"""
+    """fallback for libraries without sdpa_dev_last_launch: the kernel the shape is EXPECTED to run"""
     if precision == "bf16":
         pad = 512 if d > 256 else 256 if d > 128 else 128 if d > 64 else 64
         tandem = os.environ.get("SDPA_BF16_TANDEM", "1") != "0"
@@ -401,7 +430,7 @@ def kernel_name_of(d, precision):
                 " (+ its redo pass)" if d > 256
                 else "sdpa::fused_bf16_duo_kernel<%d,%d> (+ its redo pass)" % (pad, pad))
     if d in (64, 128, 256):
-        return "sdpa::fused_pipelined_kernel<%d,%d,0>" % (d, d)
+        return "sdpa::fused_pipelined_kernel<%d,%d,0,0>" % (d, d)
     if 128 < d <= 512:
         dks = 128 if d > 384 else 96 if d > 256 else 64
         piped = os.environ.get("SDPA_DKSPLIT_PIPE", "1") != "0"
@@ -560,6 +589,27 @@ class Job:
             self.dist.all_reduce(tmax, op=self.dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
         return elapsed, res
+
+    def latency(self, steps=5):
+        """ONE call's worth: a step with nothing of its neighbours overlapped -- fence, step, flush, fence -- the figure that
+        compares with the reference's one-call timed region (attention-mpi.c:519-524) when the inputs are resident.  `timed`
+        pipelines the reduce(-scatter) of step k under step k+1 (a throughput figure at N > 1); this does not.
+        Returns (mean ms, min ms), max over ranks."""
+        ts = []
+        for _ in range(steps + 1):                     # the first pass warms this code path
+            self.fence()
+            t0 = time.perf_counter()
+            self.run_once(False)
+            if not self.qrows:
+                self.flush()
+            self.fence()
+            ts.append(time.perf_counter() - t0)
+        ts = ts[1:]
+        if self.dist is not None:
+            tt = torch.tensor(ts, device=self.dev, dtype=torch.float64)
+            self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+            ts = [float(x) for x in tt.tolist()]
+        return float(np.mean(ts)) * 1e3, float(np.min(ts)) * 1e3
 
     def kernel_stats(self):
         k_ms = [e0.elapsed_time(e1) for e0, e1, _ in self.kernel_events]
@@ -747,6 +797,69 @@ def c_host_probe_main(n_gpus, workload, precision):
     return 0
 
 
+def n1_reference():
+    """the committed N = 1 per-step figures (profiles/n1_reference.json): what an N > 1 line's speedup is stated against,
+    so that a reader of ONE line sees the scaling without a second file"""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "n1_reference.json"))).get("workloads", {})
+    except Exception:  # noqa: BLE001
+        return {}
+
+
+OTHER_CONFIGS = (("config2", "config2", "f32"), ("config4", "config4", "f32"),
+                 ("config5_bf16", "config5", "bf16"), ("config5_f32", "config5", "f32"))
+
+
+def other_configs(pkg, be, dev, args):
+    """N = 1: BASELINE configs 2, 4 and 5 (bf16 = the config as named; fp32 = its dims on the fp32 path) measured the way the
+    headline is -- the same step on resident fp64 inputs, HIP events around the fused launch, 16 rows against the fp64
+    restatement -- plus the boundary call (host fp64 in/out).  5 timed steps each; every record is fenced."""
+    import copy
+    out = {}
+    inputs = {}
+    for key, wl, prec in OTHER_CONFIGS:
+        w = WORKLOADS[wl]
+        m, n, d = w["m"], w["n"], w["d"]
+        rec = {"workload": "%s: m=%d n=%d dk=dv=%d, %s compute / fp64 in-out" % (wl, m, n, d, prec), "dtype": prec}
+        try:
+            a2 = copy.copy(args)
+            a2.precision, a2.plan, a2.emulate_ranks = prec, "kv", 0
+            j = Job(pkg, be, None, 1, 0, dev, m, n, d, a2, q_batch=0)
+            steps = 5
+            e, r = j.timed(steps, 1, j.prewarm_steps(min(args.prewarm_ms, 40.0)))
+            k_ms, k_flop, n_l = j.kernel_stats()
+            launch = launched_kernel(pkg, d, prec)
+            lat_mean, _ = j.latency(2)
+            err, tol, rows = j.parity(r, nrows=16)
+            j.release()
+            peak = BF16_MFMA_PEAK_TFLOPS if prec == "bf16" else F32_MFMA_PEAK_TFLOPS
+            rec.update({"steps": steps, "ms_per_step": e / steps * 1e3, "latency_ms": lat_mean, "q_rows_per_s": m / (e / steps),
+                        "tflops": 4.0 * m * n * d / (e / steps) / 1e12,
+                        "kernel": launch.get("kernel"), "kernel_launch": launch, "kernel_ms_avg": k_ms, "launches": n_l,
+                        "achieved_tflops": k_flop / (k_ms * 1e-3) / 1e12, "peak_tflops": peak,
+                        "frac": k_flop / (k_ms * 1e-3) / 1e12 / peak,
+                        "parity_max_err": err, "parity_tol": tol, "parity_rows": rows})
+            if not (err <= tol):
+                rec["error"] = "PARITY FAILURE"
+        except Exception as ex:  # noqa: BLE001
+            rec["error"] = "%s: %s" % (type(ex).__name__, ex)
+        if not args.no_boundary:
+            try:
+                if wl not in inputs:
+                    inputs.clear()                      # (config 5's arrays serve both precisions; nothing else is kept)
+                    rng = np.random.default_rng(99)
+                    inputs[wl] = tuple(rng.uniform(-1, 1, sh) for sh in ((m, d), (n, d), (n, d)))
+                b = boundary_timing(pkg, m, n, d, prec, reps=3, warm=2, pinned_leg=False, inputs=inputs[wl])
+                rec["boundary_ms"] = b["ms"]
+                rec["boundary"] = b
+                if not (b["parity_max_err"] <= b["parity_tol"]):
+                    rec["error"] = "BOUNDARY PARITY FAILURE"
+            except Exception as ex:  # noqa: BLE001
+                rec["boundary"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        out[key] = rec
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -792,6 +905,8 @@ def main():
                          "own per-step mean is reported as a cross-check")
     ap.add_argument("--no-scaling-record", action="store_true",
                     help="skip the config-3 (n = 262144) scaling record that follows the headline measurement")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="N = 1: skip the record of the other BASELINE configs (config 2, 4, 5 in bf16 and in fp32) that follows")
     ap.add_argument("--no-c-host", action="store_true", help="N > 1: skip the C-host probe (one process, SDPA_GPUS = N)")
     ap.add_argument("--host", default="py", choices=["py", "c"],
                     help="py = one process per GPU, torch.distributed over RCCL (the contract's launch); c = time the C "
@@ -893,6 +1008,8 @@ def main():
     with compute:
         elapsed, res = job.timed(args.steps, args.warmup, prewarm_steps)
         avg_ms, flop_per_launch, n_launches = job.kernel_stats()
+        launch_rec = launched_kernel(pkg, d, args.precision)          # this thread's last fused launch = the timed steps'
+        lat_mean_ms, lat_min_ms = job.latency(5 if not dry_run else 2)
         # ---- visibility: the timed region above is the measurement; these untimed steps only make the GPU phase long
         #      enough for an external sampler (the driver's gpu_busy) and cross-check the per-step mean
         if args.min_gpu_seconds > 0 and not dry_run:
@@ -925,11 +1042,15 @@ def main():
                 steps3 = max(2, min(args.steps, 5 if world == 1 else 10))
                 e3, r3 = j3.timed(steps3, 1, j3.prewarm_steps(min(args.prewarm_ms, 40.0)))
                 k3_ms, k3_flop, _ = j3.kernel_stats()
+                launch3 = launched_kernel(pkg, w3["d"], args.precision)
+                lat3_mean, lat3_min = j3.latency(3 if not dry_run else 1)
                 p3_err, p3_tol, p3_rows = j3.parity(r3, nrows=16)
                 ph3 = j3.phases(2) if world > 1 else None
             scaling3 = {"workload": "config3: m=%d n=%d dk=dv=%d" % (w3["m"], w3["n"], w3["d"]), "n_gpus": world,
                         "steps": steps3, "ms_per_step": e3 / steps3 * 1e3, "q_rows_per_s": w3["m"] / (e3 / steps3),
                         "tflops": 4.0 * w3["m"] * w3["n"] * w3["d"] / (e3 / steps3) / 1e12,
+                        "latency_ms": lat3_mean, "latency_ms_min": lat3_min,
+                        "kernel": launch3.get("kernel"), "kernel_launch": launch3,
                         "kernel_ms_avg": k3_ms, "kernel_frac_of_peak": k3_flop / (k3_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
                         "kv_rows_per_gpu": j3.cnt, "parity_max_err": p3_err, "parity_tol": p3_tol, "parity_rows": p3_rows,
                         "phases": ph3,
@@ -937,14 +1058,34 @@ def main():
             if rank == 0 and not (p3_err <= p3_tol):
                 scaling3["error"] = "PARITY FAILURE"
             j3.release()
+            if rank == 0:
+                n1 = n1_reference().get("config3")
+                if n1 and world > 1 and not dry_run:
+                    scaling3["speedup_vs_n1_profile"] = {"pipelined": n1["ms_per_step"] / scaling3["ms_per_step"],
+                                                         "latency": n1["latency_ms"] / lat3_mean, "n1": n1}
         except Exception as e:  # noqa: BLE001  (never lose the headline line to the extra record)
             scaling3 = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    # ---- the other BASELINE configs, on the driver's own box and command (N = 1 only): kernel time and
+    #      fraction of peak, the boundary (host fp64 in/out) and parity, each fenced into {"error": ...}
+    configs_rec = None
+    if (world == 1 and args.workload == "headline" and args.precision == "f32" and not qrows and not args.no_configs
+            and args.emulate_ranks <= 1 and not force_dist):
+        job.release()
+        configs_rec = other_configs(pkg, be, dev, args)
+        if not args.no_boundary and isinstance(scaling3, dict) and "error" not in scaling3:
+            try:
+                b3 = boundary_timing(pkg, w3["m"], w3["n"], w3["d"], "f32", reps=3, warm=2, pinned_leg=False)
+                scaling3["boundary_ms"] = b3["ms"]
+                scaling3["boundary"] = b3
+            except Exception as e:  # noqa: BLE001
+                scaling3["boundary"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     line = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         peak = BF16_MFMA_PEAK_TFLOPS if args.precision == "bf16" else F32_MFMA_PEAK_TFLOPS
-        kernel_name = kernel_name_of(d, args.precision)
+        kernel_name = launch_rec.get("kernel")
         total_flop = 4.0 * m * n * d
         pmc = pmc_stamp(args.workload, args.precision) if world == 1 else {"traffic": None, "hbm_gbps": None, "mfma_util": None,
                                                                            "provenance": None}
@@ -952,13 +1093,17 @@ def main():
             "metric": ("DRY RUN of 1 of %d ranks, not a result: " % args.emulate_ranks if args.emulate_ranks > 1 else "") +
                       ("DRY RUN (%s%s), not a result: " % ("gloo, host-staged collectives" if gloo else "rccl",
                                                           ", all ranks on cuda:0" if share_gpu else "") if dry_run else "") +
-                      "Q-rows/sec, fused online-softmax attention m=%d n=%d dk=dv=%d" % (m, n, d),
+                      "Q-rows/sec, fused online-softmax attention m=%d n=%d dk=dv=%d" % (m, n, d) +
+                      (" (value = K back-to-back steps, step k's reduce-scatter in flight under step k+1: a THROUGHPUT figure; "
+                       "latency_ms = one step alone, the figure that compares with the reference's one-call timed region)"
+                       if world > 1 and not qrows else ""),
             "value": m / (elapsed / args.steps),
             "unit": "Q-rows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "rccl": rccl_info,
             "clock_prewarm_steps": prewarm_steps,
             "ms_per_step": ms_per_step,
+            "latency_ms": lat_mean_ms, "latency_ms_min": lat_min_ms,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -985,13 +1130,19 @@ def main():
                          # build (null otherwise) -- see pmc_from_profile for where and when they were taken
                          "hbm_gbps": pmc["hbm_gbps"], "mfma_util": pmc["mfma_util"],
                          "pmc_from_profile": pmc["provenance"],
-                         "kernel": kernel_name,
+                         "kernel": kernel_name, "kernel_launch": launch_rec,
                          "kernel_ms_avg": avg_ms, "launches": n_launches,
                          "flop_per_launch": flop_per_launch},
             "gpu_busy_extra": extra,
             "phases": phases,
             "scaling_config3": scaling3,
+            "configs": configs_rec,
         }
+        n1 = n1_reference().get(args.workload if args.precision == "f32" else "%s_%s" % (args.workload, args.precision))
+        if n1 and world > 1 and not dry_run and not qrows:
+            line["speedup_vs_n1_profile"] = {"pipelined": n1["ms_per_step"] / ms_per_step, "latency": n1["latency_ms"] / lat_mean_ms,
+                                             "n1": n1, "what": "this run's per-step times against the committed N = 1 figures "
+                                                               "(profiles/n1_reference.json), same step definition"}
         # the boundary call BEFORE the CPU baseline: its default path converts on host threads, and a host that has just
         # run every core under the reference's MPI ranks for half a minute is not the host a caller's call meets
         # (round 4, same box: 10.1 ms behind the baseline, 9.1-9.5 ms otherwise)

@@ -108,6 +108,13 @@ struct sdpa_timing {
     double merge_us;      /* rank 0, last batch: all-gather/all-reduce + merge kernel (comm stream)  */
     double reduce_us;     /* rank 0, last batch: reduce / reduce-scatter of the contributions        */
     double egress_us;     /* rank 0, last batch: widen + D2H of its rows                             */
+    /* -- fields added in ABI 5 (appended) ---------------------------------------------------- */
+    char   last_kernel[96]; /* rank 0's last fused launch as rocprofv3 names it, e.g.                 */
+                          /* "sdpa::fused_pipelined_kernel<128,128,0,0>" (what LAUNCHED, recorded by  */
+                          /* the launcher -- not a prediction)                                        */
+    int    last_grid;     /* its workgroups                                                          */
+    int    streamed;      /* 1 = the first Q batch ran as ONE persistent launch that followed the K/V */
+                          /* chunks as they arrived (round 5), 0 = one launch per chunk               */
 };
 
 /* ---- lifecycle ---------------------------------------------------------- */
@@ -144,7 +151,7 @@ SDPA_API const char *sdpa_strerror(int code);
 SDPA_API const char *sdpa_version(void);
 /* Bumped whenever a struct of this header changes size or a documented behaviour changes; hosts compare it
  * with the SDPA_ABI_VERSION they were compiled against (the package's ctypes loader and both C hosts do). */
-#define SDPA_ABI_VERSION 4
+#define SDPA_ABI_VERSION 5
 SDPA_API int sdpa_abi_version(void);
 
 /* The launch paths read their environment knobs ($SDPA_STREAMK, $SDPA_SPLIT_MERGE, $SDPA_DKSPLIT_PIPE,
@@ -257,12 +264,18 @@ SDPA_API int sdpa_owner_disp(int n, int size, int rank);
  * otherwise holds every workgroup slot of every CU until its last workgroup ends, so a collective (RCCL) or merge
  * kernel that becomes ready while it runs cannot start -- whatever its stream or priority.  A host that wants
  * batch b's reduce to run UNDER batch b+1's fused kernel (attention-mpi.c:364-380) launches the fused kernels on
- * such a stream (the C host: $SDPA_COMM_CUS, default 8 when it drives several ranks; bench.py: --reserve-cus).
+ * such a stream (the C host: $SDPA_COMM_CUS, default 16 when it drives several ranks; bench.py: --reserve-cus).
  * The reservation is made by grid size: the stream is an ordinary non-blocking stream that this library remembers
  * as having (256 - reserve) CUs, and sdpa_dev_shard_partial_f32 sizes its stream-K grid by that -- 2 x reserve of
  * the 512 workgroup slots stay free on CUs that hold one fused workgroup.  It costs the fused kernel reserve/256
  * of its rate and no more.  (Head dims whose kernels have no stream-K form -- dk > 128, bf16 -- ignore it.)      */
 SDPA_API int sdpa_dev_stream_create(int reserve_cus, void **stream);
+/* The calling thread's LAST fused launch through sdpa_dev_shard_partial_f32 / _bf16, as one JSON object:
+ * {"kernel": "sdpa::fused_pipelined_kernel<128,128,0,0>", "grid": 512, "splits": 2, "stream_k": 0, "rows": m,
+ *  "keys": n_local} -- the kernel name is the one rocprofv3 prints, recorded by the launcher itself, so a bench
+ * line or a profile reader names what ran (a stream with a reservation launches the stream-K form
+ * fused_pipelined_sk_kernel<DK,DV>).  SDPA_EINVAL when buf is too small.                                       */
+SDPA_API int sdpa_dev_last_launch(char *buf, size_t len);
 SDPA_API int sdpa_dev_stream_destroy(void *stream);
 
 /* The leading dimension to give the fp32 images of a matrix with d columns (and the contrib rows

@@ -33,10 +33,12 @@ class SdpaTiming(ctypes.Structure):
                 ("egress", _c_int), ("enqueue_threads", _c_int), ("host_convert_threads", _c_int),
                 # ABI 4
                 ("compute_cus", _c_int), ("stream_k", _c_int), ("host_widen", _c_int), ("rccl_selftest", _c_int),
-                ("merge_us", ctypes.c_double), ("reduce_us", ctypes.c_double), ("egress_us", ctypes.c_double)]
+                ("merge_us", ctypes.c_double), ("reduce_us", ctypes.c_double), ("egress_us", ctypes.c_double),
+                # ABI 5
+                ("last_kernel", ctypes.c_char * 96), ("last_grid", _c_int), ("streamed", _c_int)]
 
 
-SDPA_ABI_VERSION = 4          # the SDPA_ABI_VERSION of include/sdpa_hip.h this binding was written against
+SDPA_ABI_VERSION = 5          # the SDPA_ABI_VERSION of include/sdpa_hip.h this binding was written against
 
 
 class SdpaError(RuntimeError):
@@ -69,6 +71,7 @@ _PROTOS = {
     "sdpa_owner_disp": (_c_int, [_c_int] * 3),
     "sdpa_dev_stream_create": (_c_int, [_c_int, ctypes.POINTER(_c_void_p)]),
     "sdpa_dev_stream_destroy": (_c_int, [_c_void_p]),
+    "sdpa_dev_last_launch": (_c_int, [ctypes.c_char_p, ctypes.c_size_t]),
     "sdpa_dev_dense_ld": (_c_int, [_c_int]),
     "sdpa_dev_cvt_d2f": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p]),
     "sdpa_dev_cvt_f2d": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_long, _c_int, _c_void_p]),

@@ -10,6 +10,7 @@
 #include "sdpa_internal.h"
 
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -93,6 +94,29 @@ const LaunchKnobs &launch_knobs() {
 
 void reload_launch_knobs() { knobs_now.store(read_knobs(), std::memory_order_release); }
 
+// ---- the calling thread's last fused launch ----------------------------------------------------------------
+namespace {
+thread_local LaunchNote tl_note = {};
+}
+void note_launch(const char *kernel, int ntarg, int t0, int t1, int t2, int t3, int t4, int grid, int splits, int streamk,
+                 int rows, int keys) {
+    LaunchNote &n = tl_note;
+    n.kernel = kernel;
+    n.ntarg = ntarg;
+    n.targ[0] = t0; n.targ[1] = t1; n.targ[2] = t2; n.targ[3] = t3; n.targ[4] = t4;
+    n.grid = grid; n.splits = splits; n.streamk = streamk; n.rows = rows; n.keys = keys;
+}
+const LaunchNote &last_launch_note() { return tl_note; }
+void set_launch_note(const LaunchNote &n) { tl_note = n; }
+int format_launch_kernel(const LaunchNote &n, char *buf, size_t len) {
+    if (!n.kernel) return snprintf(buf, len, "%s", "");
+    char args[64];
+    int at = 0;
+    for (int i = 0; i < n.ntarg && i < 5; ++i) at += snprintf(args + at, sizeof args - at, "%s%d", i ? "," : "", n.targ[i]);
+    args[at] = 0;
+    return snprintf(buf, len, "sdpa::%s<%s>", n.kernel, args);
+}
+
 }  // namespace sdpa
 
 namespace {
@@ -112,7 +136,7 @@ extern "C" {
 #ifndef SDPA_BUILD_STAMP
 #define SDPA_BUILD_STAMP "hipcc unknown; src unknown"
 #endif
-const char *sdpa_version(void) { return "sdpa-hip 0.4 abi 4 (gfx950, f32 + bf16 MFMA; " SDPA_BUILD_STAMP ")"; }
+const char *sdpa_version(void) { return "sdpa-hip 0.5 abi 5 (gfx950, f32 + bf16 MFMA; " SDPA_BUILD_STAMP ")"; }
 int sdpa_abi_version(void) { return SDPA_ABI_VERSION; }
 
 void sdpa_reload_env(void) { sdpa::reload_launch_knobs(); }
@@ -251,6 +275,16 @@ int sdpa_host_widen(const float *src, double *dst, size_t n, int threads, int fl
     pool->widen(src, dst, n);
     delete pool;
     return SDPA_OK;
+}
+
+int sdpa_dev_last_launch(char *buf, size_t len) {
+    if (!buf || len == 0) return SDPA_EINVAL;
+    const sdpa::LaunchNote &n = sdpa::last_launch_note();
+    char name[128];
+    sdpa::format_launch_kernel(n, name, sizeof name);
+    const int need = snprintf(buf, len, "{\"kernel\": \"%s\", \"grid\": %d, \"splits\": %d, \"stream_k\": %d, \"rows\": %d, "
+                              "\"keys\": %d}", name, n.grid, n.splits, n.streamk, n.rows, n.keys);
+    return (need < 0 || (size_t)need >= len) ? SDPA_EINVAL : SDPA_OK;
 }
 
 int sdpa_dev_stream_create(int reserve_cus, void **stream) {

@@ -3,6 +3,7 @@
 // Replaces (paths relative to the reference tree) the MPI collectives of the merge:
 //   MPI_Iallreduce(MAX) attention-mpi.c:342, MPI_Iallreduce(SUM) :354, MPI_Ireduce(SUM) :380.
 #include "sdpa_coll.h"
+#include "sdpa_rccl_abi.h"
 
 #include <dlfcn.h>
 #include <math.h>
@@ -20,22 +21,19 @@ namespace {
 // =============================================================================
 // RCCL over xGMI: P physical GPUs, one communicator each, one host thread
 // =============================================================================
-typedef struct ncclComm *ncclComm_t;
-enum { kNcclSuccess = 0 };
-enum { kNcclFloat = 7 };                 // ncclFloat32
-enum { kNcclSum = 0, kNcclMax = 2 };     // ncclRedOp_t
+using namespace rccl_abi;                // the hand-declared slice of RCCL's ABI, checked against <rccl/rccl.h> at build time
 
 struct RcclApi {
     void *handle = nullptr;
-    int (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
-    int (*CommDestroy)(ncclComm_t) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*Reduce)(const void *, void *, size_t, int, int, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*ReduceScatter)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
+    CommInitAll_t CommInitAll = nullptr;
+    CommDestroy_t CommDestroy = nullptr;
+    GroupStart_t GroupStart = nullptr;
+    GroupEnd_t GroupEnd = nullptr;
+    AllReduce_t AllReduce = nullptr;
+    AllGather_t AllGather = nullptr;
+    Reduce_t Reduce = nullptr;
+    ReduceScatter_t ReduceScatter = nullptr;
+    GetErrorString_t GetErrorString = nullptr;
 };
 
 template <class F>

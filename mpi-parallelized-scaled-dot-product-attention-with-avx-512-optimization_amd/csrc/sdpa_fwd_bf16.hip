@@ -2010,6 +2010,7 @@ static hipError_t launch_bf16_pipe(const Bf16Args &a, hipStream_t s) {
     const float scale = 1.0f;   // attention-mpi.c:208's 1/sqrt(dk) (and log2 e) live in the Q image
     hipLaunchKernelGGL((fused_bf16_pipe_kernel<DK, DVC, ABL>), dim3(nqb * chunks * a.kv_splits), dim3(256), lds,
                        s, a, kv_per_split, nqb, chunks, scale);
+    note_launch("fused_bf16_pipe_kernel", 3, DK, DVC, ABL, 0, 0, nqb * chunks * a.kv_splits, a.kv_splits, 0, a.m, a.n_local);
     return hipGetLastError();
 }
 
@@ -2033,6 +2034,7 @@ static hipError_t launch_bf16_wide(const Bf16Args &a, hipStream_t s) {
     const float scale = 1.0f;   // attention-mpi.c:208's 1/sqrt(dk) (and log2 e) live in the Q image
     hipLaunchKernelGGL((fused_bf16_wide_kernel<DK, ABL>), dim3(nqb * chunks * a.kv_splits), dim3(256), lds, s,
                        a, kv_per_split, nqb, chunks, scale);
+    note_launch("fused_bf16_wide_kernel", 2, DK, ABL, 0, 0, 0, nqb * chunks * a.kv_splits, a.kv_splits, 0, a.m, a.n_local);
     return hipGetLastError();
 }
 
@@ -2055,6 +2057,7 @@ static hipError_t launch_bf16_tandem(const Bf16Args &a, hipStream_t s) {
     }
     hipLaunchKernelGGL((fused_bf16_tandem_kernel<DK>), dim3(nqb * chunks * a.kv_splits), dim3(256), lds, s,
                        a, kv_per_split, nqb, chunks, 1.0f);
+    note_launch("fused_bf16_tandem_kernel", 1, DK, 0, 0, 0, 0, nqb * chunks * a.kv_splits, a.kv_splits, 0, a.m, a.n_local);
     return hipGetLastError();
 }
 
@@ -2084,6 +2087,7 @@ static hipError_t launch_bf16_duo(const Bf16Args &a, hipStream_t s) {
     const float scale = 1.0f;   // attention-mpi.c:208's 1/sqrt(dk) (and log2 e) live in the Q image
     hipLaunchKernelGGL((fused_bf16_duo_kernel<DK, DV>), dim3(nqb * a.kv_splits), dim3(256), lds, s, a,
                        kv_per_split, nqb, nqb128, scale);
+    note_launch("fused_bf16_duo_kernel", 2, DK, DV, 0, 0, 0, nqb * a.kv_splits, a.kv_splits, 0, a.m, a.n_local);
     return hipGetLastError();
 }
 
@@ -2095,6 +2099,8 @@ hipError_t launch_shard_partial_bf16(const Bf16Args &args, hipStream_t s) {
     const int kp = bf16_pad_dk(a.dk), vc = bf16_chunk_dv(a.dv);
     if (a.dk > 512 || a.ldq != kp || a.ldk != kp) return hipErrorInvalidValue;
     hipError_t e = hipErrorInvalidValue;
+    LaunchNote main_note = {};
+    bool have_main = false;
 #ifdef SDPA_ABLATIONS   // tools/ builds only: the shipped library never reads $SDPA_TUNE
     static const int tune = getenv("SDPA_TUNE") ? atoi(getenv("SDPA_TUNE")) : 0;
     if (kp == 512 && vc == 256 && ((tune >> 8) & 15)) {   // timing-only ablations, pipelined kernel
@@ -2142,6 +2148,8 @@ hipError_t launch_shard_partial_bf16(const Bf16Args &args, hipStream_t s) {
             }
         }
         if (e != hipSuccess) return e;
+        main_note = last_launch_note();
+        have_main = true;
         // general kernel (256-column chunks, in-loop rescale) over the blocks the wide one flagged
         switch (kp) {
             case 64: e = launch_bf16_pipe<64, 256>(a, s); break;
@@ -2159,6 +2167,8 @@ hipError_t launch_shard_partial_bf16(const Bf16Args &args, hipStream_t s) {
         SDPA_DCASE(256, 64) SDPA_DCASE(256, 128) SDPA_DCASE(256, 256)
 #undef SDPA_DCASE
         if (e != hipSuccess) return e;
+        main_note = last_launch_note();
+        have_main = true;
         // then the general kernel over the blocks the duo kernel flagged (in-loop rescale)
     }
 #define SDPA_BCASE(KP, VC) \
@@ -2169,6 +2179,7 @@ hipError_t launch_shard_partial_bf16(const Bf16Args &args, hipStream_t s) {
     SDPA_BCASE(512, 64) SDPA_BCASE(512, 128) SDPA_BCASE(512, 256)
 #undef SDPA_BCASE
     if (e != hipSuccess) return e;
+    if (have_main) set_launch_note(main_note);       // the launch's kernel is the main one, not its redo pass
     if (a.kv_splits > 1 && !a.defer_merge) {
         PartialArgs p = {};
         p.contrib = a.contrib; p.ldo = a.ldo; p.lmax = a.lmax; p.lsum = a.lsum;

@@ -344,573 +344,12 @@ __global__ __launch_bounds__(256, (DKP > 128) ? 1 : 2) void fused_partial_kernel
 // that the merge passes (split_merge_kernel, the hosts' slot merge) stay what they are.  When the cuts
 // coincide with the classic equal splits the pieces, their slabs and therefore the results are the same
 // bit for bit.
-template <int DK, int DV, int ABL = 0, int MERGE = 0, int SK = 0>
-__global__ __launch_bounds__(256, (DK + DV > 256) ? 1 : 2) void fused_pipelined_kernel(PartialArgs a, int kv_per_split,
-                                                                                       int n_qblocks, float scale) {
-    static_assert(!(SK && MERGE), "the in-kernel split merge counts equal splits");
-    constexpr int NU = DK / 8;                // 16-byte K reads per tile per lane
-    constexpr int PPU = NU <= 16 ? 16 / NU : 1;   // P values finished per 4-MFMA QK^T step ...
-    constexpr int PEV = NU <= 16 ? 1 : NU / 16;   // ... of every PEV-th step (dk = 256: every other one)
-    constexpr int NT = DV / 32;               // O^T tiles
-    // V columns of a lane: NV consecutive floats per vector read, NH reads 128 columns apart.  O^T tile
-    // tt, row i is V column (tt / NV) * 32 NV + NV i + tt % NV  (dv <= 128: NT i + tt)
-    constexpr int NV = NT < 4 ? NT : 4;
-    constexpr int NH = NT / NV;
-    // One wave per SIMD with the whole 512-register file (dk + dv > 256): O^T lives in the accumulator
-    // file and is touched by nothing but MFMAs and "+a" asm (any plain VALU use of it makes hipcc shuttle
-    // tiles between the files on the hot path, as in the bf16 wide kernel); the score chains are inline-asm
-    // MFMAs with VGPR C/D, because in this mode hipcc puts every builtin MFMA result in AGPRs and the
-    // softmax works on VGPRs.  hipcc sees no MFMA inside an asm statement: wait states are placed by hand.
-    constexpr bool WIDE = DK + DV > 256;
-    constexpr int KTILE = kKvTile * DK;       // floats
-    constexpr int VTILE = kKvTile * DV;
-    constexpr int KCH = DK / 4;               // 16-byte chunks per K row
-    constexpr int VCH = DV / 4;
-    constexpr int KPW = (kKvTile * KCH / 64) / 4;   // 1-KiB DMA pieces per wave per K tile
-    constexpr int VPW = (kKvTile * VCH / 64) / 4;
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *const Ks = smem;                   // [2][KTILE], swizzled chunks
-    float *const Vs = smem + 2 * KTILE;       // [2][VTILE]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31;
-    const int hi = lane >> 5;
-
-    const int work = xcd_remap(blockIdx.x, gridDim.x);
-    // the piece of work in hand: query block, K/V range, slab.  Classic: fixed for the launch.  SK: one per
-    // trip of the piece loop below (sk_pos .. sk_end = this workgroup's run of tile steps)
-    int split, qblock, qrow, kv_begin, kv_end, T;
-    int sk_pos = 0, sk_end = 0, sk_ntiles = 1;
-    if constexpr (SK) {
-        sk_ntiles = (a.n_local + kKvTile - 1) / kKvTile;
-        const int total = n_qblocks * sk_ntiles;              // < 2^31: the launcher checks
-        sk_pos = min(total, work * kv_per_split);             // kv_per_split = tile steps per workgroup here
-        sk_end = min(total, sk_pos + kv_per_split);
-        if (sk_pos >= sk_end) return;
-        split = 0; qblock = 0; qrow = 0; kv_begin = 0; kv_end = 0; T = 0;
-    } else {
-        split = work / n_qblocks;
-        qblock = work - split * n_qblocks;
-        qrow = qblock * kQRowsPerBlock + wave * 32 + li;
-        kv_begin = split * kv_per_split;
-        kv_end = min(a.n_local, kv_begin + kv_per_split);
-        T = kv_end > kv_begin ? (kv_end - kv_begin + kKvTile - 1) / kKvTile : 0;
-    }
-    const float c = scale * 1.44269504088896340736f;
-
-    // Q is pre-multiplied by scale*log2(e): the MFMA chain then yields scores directly in the
-    // exp2 domain, and with the accumulator initialised to -m_ref it yields (score - m_ref), so a
-    // P value costs ONE VALU instruction (v_exp_f32).  VALU cycles are MFMA cycles lost here: the
-    // f32-input MFMA runs at the f32 vector rate and does not overlap VALU issue.
-    float4 qf[NU];
-    auto load_q = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            qf[u] = qrow < a.m ? *reinterpret_cast<const float4 *>(a.Q + (size_t)qrow * DK + 8 * u + 4 * hi)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
-            qf[u].x *= c; qf[u].y *= c; qf[u].z *= c; qf[u].w *= c;
-        }
-    };
-    if constexpr (!SK) load_q();
-
-    f32x16 oacc[NT];
-    // Softmax state of this lane's query row, all in the exp2 domain:
-    //   m_ref   reference exponent the accumulators are relative to (the row max when it was
-    //           last moved; NOT moved for rises below `defer` -- fp32 has the headroom)
-    //   max_rel running (true row max - m_ref) >= 0, folded back in at the epilogue
-    //   l_run   this half-wave's share of sum exp2(score - m_ref)
-    // Deferring spends up to 2^kDeferLog2 of fp32's exponent range: weights reach 2^24 instead of 1,
-    // so for |V| * n_local beyond ~2^104 the un-normalised sums overflow where the reference's eager
-    // rescale (attention-mpi.c:179-182) stays finite.  The epilogue checks: a workgroup that finds a
-    // non-finite value in its triple runs its K/V range a second time with defer = 0 (every rise of a
-    // row max moves the reference, weights <= 1: the reference's own bound) -- pass 1 below.
-    constexpr float kDeferLog2 = 24.0f;
-    float defer = kDeferLog2;
-    float m_ref, max_rel, l_run;
-    auto pin_o = [&]() __attribute__((always_inline)) {
-        if constexpr (WIDE) {
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt) asm volatile("" : "+a"(oacc[tt]));
-        }
-    };
-    // one link of a score chain: sx += k * q over two contraction indices
-    auto score_link = [&](f32x16 &sx, float kv, float qv) __attribute__((always_inline)) {
-        if constexpr (WIDE) {
-            // s_nop 1: "VALU write -> MFMA read" needs 2 wait states and the allocator may set an operand up right in front
-            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(sx) : "v"(kv), "v"(qv));
-        } else {
-            sx = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, qv, sx, 0, 0, 0);
-        }
-    };
-    // a 16-pass MFMA's result may be read by the VALU 18 wait states after issue
-    auto score_fence = [&](f32x16 &sx) __attribute__((always_inline)) {
-        if constexpr (WIDE) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(sx));
-    };
-    // ---- LDS-DMA staging: per-lane source byte offsets inside a tile (loop invariant)
-    unsigned koff[KPW], voff[VPW];
-    {   // (loop invariant, shared by both passes: re-deriving them per pass costs the hot loop two scratch reloads)
-#pragma unroll
-        for (int j = 0; j < KPW; ++j) {
-            const int row = (wave * KPW + j) * (64 / KCH) + lane / KCH;
-            const int cpos = lane % KCH;
-            koff[j] = (unsigned)(row * DK * 4 + ((cpos ^ (row & 15)) << 4));
-        }
-#pragma unroll
-        for (int j = 0; j < VPW; ++j) {
-            const int row = (wave * VPW + j) * (64 / VCH) + lane / VCH;
-            voff[j] = (unsigned)(row * DV * 4 + ((lane % VCH) << 4));
-        }
-    }
-    // The DMA is issued from inline asm on purpose: hipcc treats the builtin as a pending LDS
-    // write and drains vmcnt(0) before the next ds_read, which would serialise the stream.
-    // Hidden in asm, the loads stay in flight under the MFMAs; they are drained by the explicit
-    // s_waitcnt vmcnt(0) in front of the end-of-step barrier (stage_fence).
-    const unsigned lds_base = __builtin_amdgcn_readfirstlane(
-        (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)smem);
-#ifdef SDPA_DMA_ASSERT
-    int audit_bad = 0;
-#endif
-    auto dma_piece = [&](const char *gbase, unsigned lane_off, unsigned lds_byte) __attribute__((always_inline)) {
-        if constexpr (ABL & 1) return;
-#ifdef SDPA_DMA_ASSERT
-        // audit build (tools/build_variant.sh ... -DSDPA_DMA_ASSERT, never shipped): every 16-byte DMA source must lie
-        // inside the K or the V image of this launch (the LDS destinations are compile-time offsets of a tile buffer).
-        // A violation poisons the row sum (NaN), which every parity test sees -- no branch near the asm.
-        {
-            const char *src = gbase + lane_off;
-            const char *k0 = reinterpret_cast<const char *>(a.K), *k1 = k0 + (size_t)a.n_local * DK * 4;
-            const char *v0 = reinterpret_cast<const char *>(a.V), *v1 = v0 + (size_t)a.n_local * DV * 4;
-            const bool in_k = src >= k0 && src + 16 <= k1, in_v = src >= v0 && src + 16 <= v1;
-            audit_bad |= (!(in_k || in_v) || (lane_off & 15u) != 0) ? 1 : 0;
-        }
-#endif
-        // M0 is written without save/restore: hipcc treats it as reserved and re-initialises it next
-        // to each of its own uses (the same choice as in the bf16 wide kernel)
-        asm volatile("s_mov_b32 m0, %1\n\t"
-                     "s_nop 0\n\t"
-                     "global_load_lds_dwordx4 %0, %2"
-                     :
-                     : "v"(lane_off), "s"(lds_byte), "s"(gbase)
-                     : "memory" SDPA_M0_CLOBBER);
-    };
-    auto stage_fence = [&]() __attribute__((always_inline)) {
-        if constexpr (ABL & 1) return;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    };
-    // Full tiles (all but possibly the last of a split) take the branch-free path: no per-lane
-    // address arithmetic at all in the steady state (VALU cycles are MFMA cycles lost here).
-    auto dma_k = [&](int tile, int buf) __attribute__((always_inline)) {
-        const int base = kv_begin + tile * kKvTile;
-        const int last = kv_end - 1 - base;
-        const char *kb = reinterpret_cast<const char *>(a.K + (size_t)base * DK);
-        if (last >= kKvTile - 1) {
-#pragma unroll
-            for (int j = 0; j < KPW; ++j)
-                dma_piece(kb, koff[j], lds_base + (unsigned)(buf * KTILE + (wave * KPW + j) * 256) * 4u);
-        } else {                               // ragged tile: clamp the source row, keep the chunk
-#pragma unroll
-            for (int j = 0; j < KPW; ++j) {
-                const unsigned row = min((int)(koff[j] / (DK * 4)), last);
-                dma_piece(kb, row * (DK * 4) + (koff[j] % (DK * 4)),
-                          lds_base + (unsigned)(buf * KTILE + (wave * KPW + j) * 256) * 4u);
-            }
-        }
-    };
-    auto dma_v = [&](int tile, int buf) __attribute__((always_inline)) {
-        const int base = kv_begin + tile * kKvTile;
-        const int last = kv_end - 1 - base;
-        const char *vb = reinterpret_cast<const char *>(a.V + (size_t)base * DV);
-        if (last >= kKvTile - 1) {
-#pragma unroll
-            for (int j = 0; j < VPW; ++j)
-                dma_piece(vb, voff[j], lds_base + (unsigned)((2 * KTILE + buf * VTILE) + (wave * VPW + j) * 256) * 4u);
-        } else {
-#pragma unroll
-            for (int j = 0; j < VPW; ++j) {
-                const unsigned row = min((int)(voff[j] / (DV * 4)), last);
-                dma_piece(vb, row * (DV * 4) + (voff[j] % (DV * 4)),
-                          lds_base + (unsigned)((2 * KTILE + buf * VTILE) + (wave * VPW + j) * 256) * 4u);
-            }
-        }
-    };
-
-    // K fragment byte addresses inside a K buffer: chunk (2u+hi) of row li, un-swizzled
-    // (the XOR only touches the low 4 chunk bits: chunks 16..31 of a 128-wide row are the
-    //  same 8 addresses + 256 bytes)
-    unsigned kaddr[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) kaddr[u] = (unsigned)(li * DK * 4 + (((2 * u + hi) ^ (li & 15)) << 4));
-
-    auto kfrag = [&](int buf, int u) __attribute__((always_inline)) -> float4 {
-        if constexpr (ABL & 2) return qf[(u + 1) % NU];
-        return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Ks + buf * KTILE) +
-                                                 kaddr[u & 7] + (u >> 3) * 256);
-    };
-
-    auto mask_ragged = [&](f32x16 &sx, int tile) __attribute__((always_inline)) {
-        const int valid = kv_end - (kv_begin + tile * kKvTile);
-        if (valid < kKvTile) {
-            score_fence(sx);
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (crow(r, hi) >= valid) sx[r] = -INFINITY;
-        }
-    };
-    // Row max of a finished score tile (relative to m_ref).  Only a rise of more than
-    // 2^defer moves m_ref: O, l and the pending scores `sx` are then all brought to the
-    // new reference exactly once.  (Rare: after the first tile it needs a key whose score beats
-    // everything seen so far by > 16.6 in natural-log units.)
-    auto absorb_rel = [&](float tmax, f32x16 &sx) __attribute__((always_inline)) {
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        if (__any(tmax > defer)) {
-            const float jump = fmaxf(tmax, 0.f);
-            const float alpha = fast_exp2(-jump);
-            if constexpr (WIDE) {           // O stays in the accumulator file: read - scale - write back inside asm
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float tmp;
-                        asm volatile("v_accvgpr_read_b32 %1, %0\n\ts_nop 0\n\tv_mul_f32 %1, %1, %2\n\ts_nop 0\n\tv_accvgpr_write_b32 %0, %1"
-                                     : "+a"(oacc[tt][r]), "=&v"(tmp) : "v"(alpha));
-                    }
-            } else {
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) oacc[tt][r] *= alpha;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sx[r] -= jump;
-            l_run *= alpha;
-            m_ref += jump;
-            max_rel -= jump;
-            tmax -= jump;
-        }
-        max_rel = fmaxf(max_rel, tmax);
-    };
-
-    // one pipelined tile step: consumes S(t) in `su`, produces S(t+1) in `sm`
-    auto step = [&](auto has_next, f32x16 &su, f32x16 &sm, int t) __attribute__((always_inline)) {
-        constexpr bool HAS_NEXT = decltype(has_next)::value;
-        const int vbuf = t & 1, kbuf = (t + 1) & 1;
-        pin_o();
-        if (t + 2 < T) dma_k(t + 2, t & 1);
-        if (t + 1 < T) dma_v(t + 1, (t + 1) & 1);
-        if constexpr (HAS_NEXT) {
-            // [A] S^T(t+1) on the matrix pipe  ||  P(t) on the VALU.  Per 4 MFMAs: the K
-            // fragment for the step after next is read, and PPU score(s) become P values.  The
-            // exp2 is a volatile asm so that it stays inside its sched_barrier-fenced slot.
-            float4 kf = kfrag(kbuf, 0);
-            float4 kn = kfrag(kbuf, 1);
-            {   // accumulator = -m_ref in 8 packed moves instead of 16 (every VALU op beside an
-                // f32 MFMA costs matrix-pipe time)
-                const f32x2 negm = {-m_ref, -m_ref};
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    f32x2 t2;
-                    asm volatile("v_pk_mov_b32 %0, %1, %1" : "=v"(t2) : "v"(negm));
-                    sm[r] = t2.x;
-                    sm[r + 1] = t2.y;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                float4 kn2 = kn;
-                if (u + 2 < NU) kn2 = kfrag(kbuf, u + 2);
-                __builtin_amdgcn_sched_barrier(0);
-                score_link(sm, kf.x, qf[u].x);
-                score_link(sm, kf.y, qf[u].y);
-                score_link(sm, kf.z, qf[u].z);
-                score_link(sm, kf.w, qf[u].w);
-#pragma unroll
-                for (int r = (u / PEV) * PPU; r < (u % PEV == 0 ? (u / PEV + 1) * PPU : 0); ++r) {
-                    if constexpr (ABL & 4) {
-                        asm volatile("" : "+v"(su[r]));
-                    } else {
-                        // exp2 of element r, then the row-sum add of element r-1: the transcendental's
-                        // result is never read by the next instruction, so it needs no wait state
-                        asm volatile("v_exp_f32 %0, %0" : "+v"(su[r]));
-                        if (r > 0) asm volatile("v_add_f32 %0, %0, %1" : "+v"(l_run) : "v"(su[r - 1]));
-                    }
-                }
-                kf = kn;
-                kn = kn2;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!(ABL & 4)) l_run += su[15];
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                su[r] = fast_exp2(su[r]);
-                l_run += su[r];
-            }
-        }
-
-        // [B] O^T += V(t)^T.P(t)^T on the matrix pipe  ||  row max of S^T(t+1) on the VALU
-        if constexpr (HAS_NEXT) mask_ragged(sm, t + 1);
-        const float *vt = Vs + vbuf * VTILE + NV * li + 4 * hi * DV;
-        float tmax = -INFINITY;
-        auto vload = [&](int r) __attribute__((always_inline)) -> VFrag<NT> {
-            if constexpr (ABL & 2) {
-                VFrag<NT> f;
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt) f.v[tt] = qf[r % NU].x;
-                return f;
-            } else {
-                return VFrag<NT>::load(vt + crow(r, 0) * DV);
-            }
-        };
-        static_assert(NH == 1 || NT == 8, "VFrag<8> reads two float4 128 columns apart");
-        VFrag<NT> vf = vload(0);
-        VFrag<NT> vn = vload(1);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            VFrag<NT> vn2 = vn;
-            if (r + 2 < 16) vn2 = vload(r + 2);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt)
-                oacc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.v[tt], su[r], oacc[tt], 0, 0, 0);
-            // row max of S(t+1): starts one step late so that the QK^T chain has drained
-            if constexpr (HAS_NEXT && !(ABL & 4)) {
-                if (r == 2) tmax = pinned_max(sm[0], sm[1]);
-                if (r >= 4 && (r & 1) == 0) tmax = pinned_max3(tmax, sm[r - 2], sm[r - 1]);
-                if (r == 15) tmax = pinned_max3(tmax, sm[14], sm[15]);
-            }
-            vf = vn;
-            vn = vn2;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        pin_o();
-        if constexpr (HAS_NEXT && !(ABL & 4)) absorb_rel(tmax, sm);
-        stage_fence();                        // drain this wave's DMAs, then barrier
-    };
-
-    float l_tot = 0.f;
-    // one walk over the split's K/V range; instantiated twice (straight-line, no loop around the hot
-    // loop: its register allocation stays what it was), the second copy only runs after a failed range check
-    auto run_pass = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
-    pin_o();
-    m_ref = 0.f; max_rel = 0.f; l_run = 0.f;
-    f32x16 sA, sB;
-    if (T > 0) {
-        dma_k(0, 0);
-        dma_v(0, 0);
-        if (T > 1) dma_k(1, 1);
-        stage_fence();
-        // prologue: S^T(0), its mask and max
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sA[r] = 0.f;
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const float4 kf = kfrag(0, u);
-            score_link(sA, kf.x, qf[u].x);
-            score_link(sA, kf.y, qf[u].y);
-            score_link(sA, kf.z, qf[u].z);
-            score_link(sA, kf.w, qf[u].w);
-        }
-        score_fence(sA);
-        mask_ragged(sA, 0);
-        float tmax = sA[0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sA[r]);
-        m_ref = fmaxf(tmax, __shfl_xor(tmax, 32));      // finite: every tile has a valid key row
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sA[r] -= m_ref;
-        __syncthreads();                      // everyone is done with K(0) before K(2) lands on it
-
-        int t = 0;
-        for (; t + 2 < T; t += 2) {
-            step(std::true_type(), sA, sB, t);
-            step(std::true_type(), sB, sA, t + 1);
-        }
-        if (T - t == 2) {
-            step(std::true_type(), sA, sB, t);
-            step(std::false_type(), sB, sA, t + 1);
-        } else {
-            step(std::false_type(), sA, sB, t);
-        }
-    }
-
-    // ---- epilogue: express the triple relative to the TRUE row max (m_ref + max_rel), in the
-    //      reference's units (lmax is a natural-log score: exp2-domain value * ln 2)
-    const float fold = fast_exp2(-max_rel);
-#pragma unroll
-    for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[tt][r] *= fold;
-    l_tot = (l_run + __shfl_xor(l_run, 32)) * fold;
-#ifdef SDPA_DMA_ASSERT
-    if (__any(audit_bad)) l_tot = __builtin_nanf("");
-#endif
-    };  // run_pass
-
-    auto store_rows = [&](float *out, int ldo, float *omax, float *osum, const f32x16 (&o)[NT], float vmax,
-                          float vsum) __attribute__((always_inline)) {
-        if (qrow < a.m) {
-            float *orow = out + (size_t)qrow * ldo;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int col0 = NV * crow(r, hi);
-                if constexpr (NV == 4) {
-#pragma unroll
-                    for (int h = 0; h < NH; ++h)
-                        *reinterpret_cast<float4 *>(orow + 128 * h + col0) =
-                            make_float4(o[4 * h][r], o[4 * h + 1][r], o[4 * h + 2][r], o[4 * h + 3][r]);
-                } else {
-                    *reinterpret_cast<float2 *>(orow + col0) = make_float2(o[0][r], o[1][r]);
-                }
-            }
-            if (hi == 0) {
-                omax[qrow] = vmax;
-                osum[qrow] = vsum;
-            }
-        }
-    };
-    // this workgroup's triple: the rows of the result, or its slab of the split scratch
-    auto store_mine = [&]() __attribute__((always_inline)) {
-        const float my_max = T > 0 ? (m_ref + max_rel) * 0.69314718055994530942f : -INFINITY;
-        if (a.kv_splits <= 1)
-            store_rows(a.contrib, a.ldo, a.lmax, a.lsum, oacc, my_max, l_tot);
-        else
-            store_rows(a.ws_contrib + (size_t)split * a.ws_rows * a.ws_ld, a.ws_ld, a.ws_lmax + (size_t)split * a.ws_rows,
-                       a.ws_lsum + (size_t)split * a.ws_rows, oacc, my_max, l_tot);
-    };
-
-    // (Q, the DMA offsets and the check-then-store order below are arranged so that the FIRST pass's hot
-    //  loop is instruction for instruction the loop of the kernel without a second pass -- hipcc's
-    //  allocation of these full-register-file kernels shifts with any liveness change around the loop;
-    //  tests/test_kernel_isa.py holds it in place)
-    do {                                      // SK: one trip per piece of this workgroup's run; otherwise one trip
-    if constexpr (SK) {
-        // (integer division runs on the VALU: readfirstlane tells hipcc the quotients are wave-uniform -- the
-        //  DMA's base address must sit in SGPRs, and a "divergent" one costs a waterfall loop per piece)
-        qblock = __builtin_amdgcn_readfirstlane(sk_pos / sk_ntiles);
-        const int t0 = sk_pos - qblock * sk_ntiles;
-        const int t1 = min(sk_ntiles, t0 + (sk_end - sk_pos));
-        split = work - __builtin_amdgcn_readfirstlane((qblock * sk_ntiles) / kv_per_split);   // pieces of this query block before this one
-        qrow = qblock * kQRowsPerBlock + wave * 32 + li;
-        kv_begin = t0 * kKvTile;
-        kv_end = min(a.n_local, t1 * kKvTile);
-        T = t1 - t0;
-        load_q();
-    }
-    run_pass();
-#if SDPA_RANGE_REDO
-    {   // range check of the deferred-rescale pass (see `defer` above).  The LDS tiles are dead here:
-        // every wave has passed the last step's barrier behind its last fragment read.
-        bool bad = !__builtin_isfinite(l_tot);
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) bad |= !__builtin_isfinite(oacc[tt][r]);
-        int *vote = reinterpret_cast<int *>(smem);
-        const int wave_bad = __any(bad) ? 1 : 0;
-        if (lane == 0) vote[wave] = wave_bad;
-        __syncthreads();
-        const int redo = __builtin_amdgcn_readfirstlane(vote[0] | vote[1] | vote[2] | vote[3]);
-        if (redo) {
-            __syncthreads();                  // the votes are read before the second pass's first DMA lands on them
-            defer = 0.f;
-            run_pass();
-        }
-    }
-#endif
-    store_mine();
-    if constexpr (SK) {
-        if (kv_begin + T * kKvTile >= sk_ntiles * kKvTile) {
-            // the last piece of its query block: the slabs this block does not use get the empty triple
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[tt][r] = 0.f;
-            for (int sp = split + 1; sp < a.kv_splits; ++sp)
-                store_rows(a.ws_contrib + (size_t)sp * a.ws_rows * a.ws_ld, a.ws_ld, a.ws_lmax + (size_t)sp * a.ws_rows,
-                           a.ws_lsum + (size_t)sp * a.ws_rows, oacc, -INFINITY, 0.f);
-        }
-        sk_pos += T;
-        if (sk_pos < sk_end) __syncthreads();  // the range-check votes are read before the next piece's first DMA lands on them
-    }
-    } while (SK && sk_pos < sk_end);
-    if (SK || a.kv_splits <= 1) return;
-    if constexpr (!MERGE) {
-        return;                               // the slots are merged by a later pass (split_merge_kernel)
-    } else {
-
-    // ---- in-kernel split merge: the LAST workgroup of this query block to arrive merges the block's
-    // kv_splits partial triples (attention-mpi.c:340-351 applied inside one GPU).  Placement-independent
-    // hand-off (the splits of a block run on different XCDs, whose L2s are not coherent): plain slab
-    // stores, every wave drains them, one lane releases at agent scope and takes a ticket; the last
-    // arriver acquires at agent scope and reads every slab -- its own included, in split order, so that
-    // the sums do not depend on who arrived last (bitwise the separate merge pass's result).
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int *last_flag = reinterpret_cast<int *>(smem) + 8;
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // restates the wait behind buffer_wbl2 where hipcc cannot drop it
-        unsigned long long *word = a.tickets + qblock;
-        unsigned long long seen = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned arrived;
-        for (;;) {       // a word of another generation (or never written) counts as zero arrivals
-            arrived = (seen >> 8) == a.ticket_tag ? (unsigned)(seen & 255u) : 0u;
-            const unsigned long long next = (a.ticket_tag << 8) | (unsigned long long)(arrived + 1u);
-            if (__hip_atomic_compare_exchange_strong(word, &seen, next, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT))
-                break;
-        }
-        const int last = arrived + 1u == (unsigned)a.kv_splits;
-        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        *last_flag = last;
-    }
-    __syncthreads();
-    if (!__builtin_amdgcn_readfirstlane(*last_flag)) return;
-
-    f32x16 macc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) macc[t][r] = 0.f;
-    float gm = -INFINITY, tot = 0.f;
-    if (qrow < a.m) {
-        for (int sp = 0; sp < a.kv_splits; ++sp) gm = fmaxf(gm, a.ws_lmax[(size_t)sp * a.ws_rows + qrow]);
-        for (int sp = 0; sp < a.kv_splits; ++sp) {
-            const float lm = a.ws_lmax[(size_t)sp * a.ws_rows + qrow];
-            const float w = (lm == -INFINITY) ? 0.f : expf(lm - gm);
-            tot = fmaf(w, a.ws_lsum[(size_t)sp * a.ws_rows + qrow], tot);
-            const float *srow = a.ws_contrib + ((size_t)sp * a.ws_rows + qrow) * a.ws_ld;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int col0 = NV * crow(r, hi);
-                if constexpr (NV == 4) {
-#pragma unroll
-                    for (int h = 0; h < NH; ++h) {
-                        const float4 o = *reinterpret_cast<const float4 *>(srow + 128 * h + col0);
-                        macc[4 * h][r] = fmaf(w, o.x, macc[4 * h][r]);
-                        macc[4 * h + 1][r] = fmaf(w, o.y, macc[4 * h + 1][r]);
-                        macc[4 * h + 2][r] = fmaf(w, o.z, macc[4 * h + 2][r]);
-                        macc[4 * h + 3][r] = fmaf(w, o.w, macc[4 * h + 3][r]);
-                    }
-                } else {
-                    const float2 o = *reinterpret_cast<const float2 *>(srow + col0);
-                    macc[0][r] = fmaf(w, o.x, macc[0][r]);
-                    macc[1][r] = fmaf(w, o.y, macc[1][r]);
-                }
-            }
-        }
-    }
-    store_rows(a.contrib, a.ldo, a.lmax, a.lsum, macc, gm, tot);
-    }   // MERGE
-}
+#define SDPA_PK_SK 0
+#include "sdpa_fwd_f32_pipelined.inc"
+#undef SDPA_PK_SK
+#define SDPA_PK_SK 1
+#include "sdpa_fwd_f32_pipelined.inc"
+#undef SDPA_PK_SK
 
 // ---------------------------------------------------------------------------
 // In-GPU split merge: the reference's shard merge (attention-mpi.c:340-362 minus
@@ -1172,6 +611,7 @@ static hipError_t launch_fast(const PartialArgs &a, hipStream_t s) {
     const float scale = 1.0f / sqrtf((float)a.dk);   // attention-mpi.c:208
     hipLaunchKernelGGL((fused_partial_kernel<DKP, DVP>), dim3(nqb * chunks * a.kv_splits), dim3(256), lds,
                        s, a, kv_per_split, nqb, chunks, scale);
+    note_launch("fused_partial_kernel", 2, DKP, DVP, 0, 0, 0, nqb * chunks * a.kv_splits, a.kv_splits, 0, a.m, a.n_local);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (a.kv_splits > 1 && !a.defer_merge) e = launch_split_merge(a, s);
@@ -1219,9 +659,10 @@ static hipError_t launch_pipelined(const PartialArgs &a, hipStream_t s) {
     if constexpr (DK <= kMaxFastDim) {
         if (plan.streamk && plan.splits <= a.kv_splits && (a.kv_splits <= 1 || a.ws_contrib)) {
             static AttrOnce attr;
-            if ((e = attr.ensure(&fused_pipelined_kernel<DK, DV, 0, 0, 1>, dev, lds)) != hipSuccess) return e;
-            hipLaunchKernelGGL((fused_pipelined_kernel<DK, DV, 0, 0, 1>), dim3(plan.workers), dim3(256), lds, s, k,
+            if ((e = attr.ensure(&fused_pipelined_sk_kernel<DK, DV>, dev, lds)) != hipSuccess) return e;
+            hipLaunchKernelGGL((fused_pipelined_sk_kernel<DK, DV>), dim3(plan.workers), dim3(256), lds, s, k,
                                plan.run, nqb, scale);
+            note_launch("fused_pipelined_sk_kernel", 2, DK, DV, 0, 0, 0, plan.workers, plan.splits, 1, a.m, a.n_local);
             launched = true;
         }
     }
@@ -1232,11 +673,13 @@ static hipError_t launch_pipelined(const PartialArgs &a, hipStream_t s) {
         if ((e = attr.ensure(&fused_pipelined_kernel<DK, DV, ABL, 1>, dev, lds)) != hipSuccess) return e;
         hipLaunchKernelGGL((fused_pipelined_kernel<DK, DV, ABL, 1>), dim3(nqb * k.kv_splits), dim3(256), lds, s,
                            k, kv_per_split, nqb, scale);
+        note_launch("fused_pipelined_kernel", 4, DK, DV, ABL, 1, 0, nqb * k.kv_splits, k.kv_splits, 0, a.m, a.n_local);
     } else {
         static AttrOnce attr;
         if ((e = attr.ensure(&fused_pipelined_kernel<DK, DV, ABL, 0>, dev, lds)) != hipSuccess) return e;
         hipLaunchKernelGGL((fused_pipelined_kernel<DK, DV, ABL, 0>), dim3(nqb * k.kv_splits), dim3(256), lds, s,
                            k, kv_per_split, nqb, scale);
+        note_launch("fused_pipelined_kernel", 4, DK, DV, ABL, 0, 0, nqb * k.kv_splits, k.kv_splits, 0, a.m, a.n_local);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -1281,6 +724,7 @@ hipError_t launch_shard_partial(const PartialArgs &a_in, hipStream_t s) {
             ac.contrib = a.contrib + c0;
             ac.dv = std::min(64 * kGenericMaxCols, a.dv - c0);
             hipLaunchKernelGGL(generic_partial_kernel, dim3((a.m + 3) / 4), dim3(256), lds, s, ac, scale);
+            note_launch("generic_partial_kernel", 0, 0, 0, 0, 0, 0, (a.m + 3) / 4, 1, 0, a.m, a.n_local);
             const hipError_t e = hipGetLastError();
             if (e != hipSuccess) return e;
         }

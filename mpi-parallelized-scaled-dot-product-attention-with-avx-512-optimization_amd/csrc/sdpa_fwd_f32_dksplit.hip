@@ -697,6 +697,8 @@ static hipError_t launch_one(const PartialArgs &a, hipStream_t s) {
     else
         hipLaunchKernelGGL((fused_dksplit_kernel<DKS, DVS, QB>), dim3(nqb * chunks * a.kv_splits), dim3(256), lds, s,
                            a, kv_per_split, nqb, chunks, scale);
+    note_launch(dksplit_pipelined() ? "fused_dksplit_pipe_kernel" : "fused_dksplit_kernel", 3, DKS, DVS, QB, 0, 0,
+                nqb * chunks * a.kv_splits, a.kv_splits, 0, a.m, a.n_local);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (a.kv_splits > 1 && !a.defer_merge) e = launch_split_merge(a, s);

@@ -218,14 +218,41 @@ int comm_cus_reserved(int cus, int ranks) {
     return r;
 }
 
-// Is this host address page-locked memory the runtime knows (hipHostMalloc / sdpa_host_alloc, or registered by the caller)?
+// Is this host address page-locked memory?  Known without asking the runtime: the ranges sdpa_host_alloc() handed out
+// (what both CLI hosts read the file into).  Any OTHER pointer is taken for pageable and travels through the
+// library's page-locked staging -- as fast at every BASELINE shape (profiles/r04/hostlevel_all_configs.log) -- because
+// ASKING costs the host application log noise: hipPointerGetAttributes on a plain malloc / numpy array makes ROCm 7
+// print "Cannot get amd_mem_obj for ptr" at error level, 3-4 lines per attention() under AMD_LOG_LEVEL >= 1
+// (16 KB of the driver's pytest tail was this).  $SDPA_HOST_PROBE=1 asks after all (a caller that
+// page-locks its arrays itself and wants them used in place); the verdict is remembered per base pointer.
+struct HostRanges {
+    std::mutex mu;
+    std::vector<std::pair<const char *, size_t>> r;       // sdpa_host_alloc()ed, not yet freed
+    std::vector<std::pair<const void *, bool>> probed;    // $SDPA_HOST_PROBE=1: base pointer -> page-locked?
+};
+HostRanges &HR = *new HostRanges;
+
 bool page_locked(const void *p) {
-    hipPointerAttribute_t at;
-    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
-        (void)hipGetLastError();
-        return false;
+    {
+        std::lock_guard<std::mutex> lk(HR.mu);
+        for (auto &e : HR.r)
+            if ((const char *)p >= e.first && (const char *)p < e.first + e.second) return true;
     }
-    return at.type == hipMemoryTypeHost;
+    static const bool probe = [] { const char *v = getenv("SDPA_HOST_PROBE"); return v && *v && atoi(v) != 0; }();
+    if (!probe) return false;
+    {
+        std::lock_guard<std::mutex> lk(HR.mu);
+        for (auto &e : HR.probed)
+            if (e.first == p) return e.second;
+    }
+    hipPointerAttribute_t at;
+    bool locked = false;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) (void)hipGetLastError();
+    else locked = at.type == hipMemoryTypeHost;
+    std::lock_guard<std::mutex> lk(HR.mu);
+    if (HR.probed.size() >= 64) HR.probed.erase(HR.probed.begin());
+    HR.probed.push_back({p, locked});
+    return locked;
 }
 
 // $SDPA_HOST_REGISTER=1: page-lock the caller's pageable arrays for the duration of the call (hipHostRegister), the
@@ -836,6 +863,7 @@ struct Call {
     double first_kernel_us[sdpa::kMaxRanks] = {};  // entry -> rank g's first fused launch enqueued (host clock)
     int n_brackets = 0, last_splits = 1;           // rank 0's enqueue thread only
     int last_rows = 0, last_keys = 0;              // shape of rank 0's last fused launch
+    sdpa::LaunchNote last_note = {};               // ... and what it was (recorded by the launcher on that thread)
     bool tail_marked = false;                      // the last batch's collective tail recorded root.ev_tail[0..3]
     // bytes of `result` that lie in its partial first / last page: copied into E.bounce by the device, into place after the wait
     struct Sliver { char *dst; const char *src; size_t bytes; };
@@ -1168,6 +1196,7 @@ int rank_batch(Call &c, int g, int b) {
                 c.last_splits = sp;
                 c.last_rows = jr;
                 c.last_keys = keys;
+                c.last_note = sdpa::last_launch_note();
             }
             if (last) {
                 if (streamed) SDPA_TRY(merge_slots(pl, rk, rp, s, bs, j0, jr));
@@ -1385,11 +1414,17 @@ int host_widen_mode() {
     return atoi(v) > 0 ? 1 : 0;
 }
 
-bool want_host_widen(const Plan &pl) {
+// `pageable_result`: the caller's result array is neither page-locked nor about to be registered.  A device-to-host
+// copy straight into it would BLOCK the enqueuing thread until the rows exist (the runtime stages pageable
+// destinations synchronously), serialising batch b+1's enqueue behind batch b's kernels: such a result
+// comes home through the page-locked staging whatever the host's thread count -- a small host widens with the few
+// threads it has, on the calling thread if need be.
+bool want_host_widen(const Plan &pl, bool pageable_result = true) {
     const int mode = host_widen_mode();
     if (mode != 2) return mode == 1;
-    if ((int)std::thread::hardware_concurrency() < 16 || host_convert_thread_count() < 8) return false;
-    return (double)pl.m * pl.dv >= 256.0 * 1024.0;
+    if ((double)pl.m * pl.dv < 256.0 * 1024.0) return false;
+    if (pageable_result) return true;
+    return (int)std::thread::hardware_concurrency() >= 16 && host_convert_thread_count() >= 8;
 }
 
 // the converter pool is created on first use (32 threads, $SDPA_HOST_CVT_THREADS)
@@ -1725,7 +1760,7 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
     // the copies will ask for them (every rank's chunk 0, the first Q batch, the other chunks, the other
     // batches), and let the enqueue code wait for each piece right before it copies it
     for (Rank &rk : E.r) rk.ev_w_used = 0;
-    if (want_host_widen(pl) && ensure_host_converter() == SDPA_OK) {
+    if (want_host_widen(pl, !c.do_pin && !page_locked(result)) && ensure_host_converter() == SDPA_OK) {
         c.w_base = (float *)E.hc->staging(3, (size_t)m * dv * sizeof(float));
         c.widen = c.w_base != nullptr;
     }
@@ -1895,8 +1930,9 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
     T.enqueue_threads = c.threaded ? P : 1;
     T.host_convert_threads = c.hostcvt ? E.hc->threads() : 0;
     T.compute_cus = pl.cus;
-    T.stream_k = (!pl.bf16 && c.last_keys > 0 &&
-                  sdpa::plan_f32_launch(c.last_rows, c.last_keys, dk, dv, pl.cus).streamk) ? 1 : 0;
+    T.stream_k = c.last_note.streamk;
+    sdpa::format_launch_kernel(c.last_note, T.last_kernel, sizeof T.last_kernel);
+    T.last_grid = c.last_note.grid;
     T.host_widen = c.widen ? 1 : 0;
     T.rccl_selftest = E.coll ? E.coll->selftested_ranks() : 0;
     if (c.tail_marked) {
@@ -1968,11 +2004,20 @@ void *sdpa_host_alloc(size_t bytes) {
         (void)hipGetLastError();
         return nullptr;
     }
+    std::lock_guard<std::mutex> lk(HR.mu);
+    HR.r.push_back({(const char *)p, bytes});
     return p;
 }
 
 void sdpa_host_free(void *p) {
-    if (p && hipHostFree(p) != hipSuccess) (void)hipGetLastError();
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(HR.mu);
+        for (size_t i = 0; i < HR.r.size(); ++i)
+            if (HR.r[i].first == (const char *)p) { HR.r[i] = HR.r.back(); HR.r.pop_back(); break; }
+        HR.probed.clear();
+    }
+    if (hipHostFree(p) != hipSuccess) (void)hipGetLastError();
 }
 
 // The schedule sdpa_attention_f64 would run for this problem on `ranks` ranks, as one JSON object.
@@ -2028,6 +2073,23 @@ int sdpa_prepare(int m, int n, int dk, int dv, int flags) {
         if (!E.hc->staging(0, (size_t)n * pl.ldk * pl.kv_elem) || !E.hc->staging(1, (size_t)n * vrow) ||
             !E.hc->staging(2, (size_t)m * pl.ldq * pl.q_elem))
             return SDPA_ENOMEM;
+    }
+    // ... and of the host-side widening: the warm-up call below is too small to take it, so without this the ONE timed
+    // call of a CLI host paid a hipHostMalloc of m x dv floats and the creation of its "rows have landed" events
+    // inside the timer
+    if (want_host_widen(pl, !register_caller_arrays())) {
+        SDPA_TRY(ensure_host_converter());
+        if (!E.hc->staging(3, (size_t)m * dv * sizeof(float))) return SDPA_ENOMEM;
+        const int need_ev = pl.nb * (kMaxSub + 1) + 2;
+        for (int g = 0; g < pl.P; ++g) {
+            Rank &rk = E.r[g];
+            HIP_TRY(hipSetDevice(rk.dev));
+            while ((int)rk.ev_w.size() < need_ev) {
+                hipEvent_t e;
+                HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                rk.ev_w.push_back(e);
+            }
+        }
     }
     // 2. one small call through the same code path: loads the code objects, sets the kernel
     //    attributes, creates the timing events (the kernel variants depend on dk, dv only)

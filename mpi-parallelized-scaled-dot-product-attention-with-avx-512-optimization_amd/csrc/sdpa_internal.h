@@ -195,6 +195,26 @@ int  stream_cus(hipStream_t s);
 void register_stream_cus(hipStream_t s, int cus);
 void forget_stream_cus(hipStream_t s);
 
+// What the calling thread's LAST fused launch was: the kernel as rocprofv3 prints it (name + template arguments), its
+// grid and its work distribution.  Written by every fused launcher (a handful of stores), read by
+// sdpa_dev_last_launch() and the host pipeline (sdpa_timing.last_kernel): bench.py's roofline.kernel is what
+// LAUNCHED, not what a heuristic in the bench expects to launch.
+struct LaunchNote {
+    const char *kernel;   // e.g. "fused_pipelined_kernel" (a string literal), nullptr = none yet
+    int targ[5];          // template arguments in declaration order
+    int ntarg;
+    int grid;             // workgroups
+    int splits;           // slabs of split scratch (classic: equal K/V splits; stream-K: most pieces per query block)
+    int streamk;          // 1 = stream-K distribution
+    int rows, keys;       // launch shape
+};
+void note_launch(const char *kernel, int ntarg, int t0, int t1, int t2, int t3, int t4, int grid, int splits, int streamk,
+                 int rows, int keys);
+const LaunchNote &last_launch_note();
+void set_launch_note(const LaunchNote &n);   // (the bf16 launchers put the main kernel back behind its redo pass)
+// "sdpa::name<a,b,...>" into buf (always terminated); returns the length it would need
+int format_launch_kernel(const LaunchNote &n, char *buf, size_t len);
+
 // Launch-path knobs.  The launchers run on the hosts' enqueue threads, and glibc's environment is not safe to
 // read while another thread may setenv(): the knobs are read ONCE (first use) into an immutable snapshot;
 // sdpa_reload_env() (and every host-level entry point, on the calling thread, before any worker thread

@@ -107,10 +107,20 @@ def plan(m, n, dk, dv, flags=0, ranks=1):
     return json.loads(buf.value.decode())
 
 
+def last_launch():
+    """sdpa_dev_last_launch(): the calling thread's last fused launch through the device-level API -- kernel name as
+    rocprofv3 prints it, grid, slabs, stream-K or not."""
+    import json
+    buf = ctypes.create_string_buffer(512)
+    check(_lib.load().sdpa_dev_last_launch(buf, len(buf)), "sdpa_dev_last_launch")
+    return json.loads(buf.value.decode())
+
+
 def last_timing():
     t = SdpaTiming()
     check(_lib.load().sdpa_last_timing_sized(ctypes.byref(t), ctypes.sizeof(t)), "sdpa_last_timing_sized")
     out = {k: getattr(t, k) for k, _ in SdpaTiming._fields_}
+    out["last_kernel"] = out["last_kernel"].decode("ascii", "replace")
     out["enqueue_first_kernel_us"] = list(out["enqueue_first_kernel_us"])[:max(1, out["n_gpus"])]
     return out
 

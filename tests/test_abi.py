@@ -171,6 +171,33 @@ def test_no_gpu_fails_loudly_never_falls_back(pkg):
                                           None, 0, None) == pkg._lib.SDPA_ENODEV
 
 
+def test_hand_declared_rccl_abi_matches_the_installed_header(tmp_path):
+    """sdpa_coll.hip binds RCCL with dlsym() through function-pointer types declared by hand (csrc/sdpa_rccl_abi.h: the
+    library does not link against librccl).  csrc/sdpa_rccl_abi_check.cpp static_asserts the three enum values it uses and
+    the calling-convention class of every argument of the nine entry points against <rccl/rccl.h>; `make` compiles it
+    (-fsyntax-only) with every build.  Here: the check passes on the shipped declarations, and FAILS on a drifted copy
+    (a wrong signature would be undefined behaviour before the run-time self-test ever saw it)."""
+    hipcc, rccl_h = "/opt/rocm/bin/hipcc", "/opt/rocm/include/rccl/rccl.h"
+    if not (os.path.exists(hipcc) and os.path.exists(rccl_h)):
+        pytest.skip("needs hipcc and the RCCL header")
+    csrc = os.path.join(ROOT, PKG, "csrc")
+    cmd = [hipcc, "-x", "hip", "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-I/opt/rocm/include"]
+    r = subprocess.run(cmd + ["-I" + csrc, os.path.join(csrc, "sdpa_rccl_abi_check.cpp")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    # a drifted declaration: ncclReduce without its `root` argument, ncclMax = 3
+    hdr = open(os.path.join(csrc, "sdpa_rccl_abi.h")).read()
+    bad = hdr.replace("(const void *, void *, size_t, int, int, int, ncclComm_t, hipStream_t)",
+                      "(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t)").replace("kNcclMax = 2", "kNcclMax = 3")
+    assert bad != hdr
+    (tmp_path / "sdpa_rccl_abi.h").write_text(bad)
+    (tmp_path / "sdpa_rccl_abi_check.cpp").write_text(open(os.path.join(csrc, "sdpa_rccl_abi_check.cpp")).read())
+    r = subprocess.run(cmd + ["-I" + str(tmp_path), str(tmp_path / "sdpa_rccl_abi_check.cpp")], capture_output=True, text=True)
+    assert r.returncode != 0 and "ncclReduce does not match" in r.stderr and "ncclRedOp_t values" in r.stderr, r.stderr[-2000:]
+    # and sdpa_coll.hip uses exactly those declarations (no second copy to drift)
+    coll = open(os.path.join(csrc, "sdpa_coll.hip")).read()
+    assert '#include "sdpa_rccl_abi.h"' in coll and "typedef struct ncclComm" not in coll
+
+
 def test_product_never_touches_the_oracle():
     """the product tree must not import, link or execute anything under oracle/"""
     pdir = os.path.join(ROOT, PKG)

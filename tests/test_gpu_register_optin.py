@@ -66,10 +66,19 @@ def test_registered_caller_arrays_give_the_default_paths_result_bit_for_bit():
     env = dict(os.environ)
     for k in ("SDPA_HOST_REGISTER", "SDPA_PROGRESSIVE_PIN", "SDPA_VIRTUAL_GPUS", "SDPA_QBATCH", "SDPA_EGRESS"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, "-c", CHILD, ROOT, PKG], capture_output=True, text=True, timeout=900, env=env)
+    def child():
+        return subprocess.run([sys.executable, "-c", CHILD, ROOT, PKG], capture_output=True, text=True, timeout=900, env=env)
+    r = child()
     if r.returncode != 0 and "Memory access fault" in r.stderr:
-        # the documented hazard of the opt-in itself: not seen in this child so far (it makes no pageable
-        # copy of its own), but if the runtime ever faults here it is the path's known risk, not a parity failure
-        pytest.xfail("GPU memory fault inside the SDPA_HOST_REGISTER=1 child: the hazard the default avoids")
+        # The documented hazard of the opt-in itself: not seen in this child so far (it makes no pageable
+        # copy of its own).  ONE such fault is the path's known risk and is reported loudly, not silently: the test is
+        # repeated in a fresh process, and a second fault FAILS it (an xfail here must not be able to mask a
+        # regression in the registered paths).
+        sys.stderr.write("\n*** test_gpu_register_optin: GPU memory fault inside the SDPA_HOST_REGISTER=1 child; retrying once ***\n"
+                         + r.stderr[-1500:] + "\n")
+        r2 = child()
+        assert r2.returncode == 0 and "15 configurations" in r2.stdout, (
+            "the SDPA_HOST_REGISTER=1 child failed twice in a row", r.stderr[-800:], r2.stdout[-300:], r2.stderr[-1500:])
+        pytest.xfail("one GPU memory fault inside the SDPA_HOST_REGISTER=1 child (the hazard the default avoids); the retry passed")
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2500:])
     assert "15 configurations" in r.stdout, r.stdout[-500:]
