@@ -172,7 +172,15 @@ SDPA_API void sdpa_reload_env(void);
  * fp64 (:373,:396).  K/V rows are sharded over the engine's GPUs with
  * owner_count/owner_disp (:19-27) and merged with the algebra of :340-380
  * (flags choose the collective schedule).  The first Q batch streams the K/V
- * shard host->device in chunks and starts computing on chunk 0.
+ * shard host->device in groups of rows and computes as they land: for the
+ * fp32 shapes with dk, dv in (32, 128] ONE persistent launch whose workgroups
+ * wait, in the kernel, for the ready word of the rows they are about to read
+ * (raised by the copy engine behind the rows; sdpa_timing.streamed = 1; the
+ * same triples, bit for bit, as sdpa_dev_shard_partial_f32 on the resident
+ * shard; $SDPA_STREAMED=0: one launch per K/V chunk, as for every other shape).
+ * Every shape has a kernel: any dk, dv in fp32 (dk > 1024 on a VALU-only
+ * kernel); SDPA_F_BF16 beyond the bf16 kernels' dims (dk <= 512, dv <= 1024,
+ * 4 GiB of Vt per rank) runs the fp32 path and says so on stderr.
  * Numerical range: the fp32 kernels rescale their accumulators lazily (only
  * when a row maximum rises by more than 2^24), which spends that much of
  * fp32's exponent headroom: the un-normalised contrib of a row overflows for
@@ -192,9 +200,12 @@ SDPA_API int sdpa_last_timing(struct sdpa_timing *out);
 
 /* Optional: size the engine for one problem before the timed call -- allocates every device
  * buffer sdpa_attention_f64(m,n,dk,dv,flags) will use and runs a small problem of the same
- * dk, dv through the same code path so that code objects are loaded.  The analogue of the
- * reference doing MPI_Init and its transport set-up outside the timer (attention-mpi.c:10-17,
- * :504); sdpa_attention_f64 works without it, the first call is just slower.               */
+ * dk, dv through the same code path so that code objects are loaded, then keeps the matrix
+ * cores busy for ~25 ms on zeroed operands ($SDPA_PREPARE_WARM_MS, 0 = off): from idle the core
+ * clock needs about that long to reach its plateau, and a host that makes ONE timed call would
+ * time it on the ramp.  The analogue of the reference doing MPI_Init and its transport set-up
+ * outside the timer (attention-mpi.c:10-17, :504); sdpa_attention_f64 works without it, the first
+ * call is just slower.                                                                          */
 SDPA_API int sdpa_prepare(int m, int n, int dk, int dv, int flags);
 
 /* The schedule sdpa_attention_f64 would run for this problem on `ranks` ranks (1..16), as one JSON

@@ -230,7 +230,6 @@ int sdpa_dev_shard_partial_f32(const float *Qf, int ldq, const float *Kf, int ld
         return SDPA_EINVAL;
     if (misaligned16(Qf) || misaligned16(Kf) || misaligned16(Vf) || misaligned16(contrib))
         return SDPA_EINVAL;              // the kernels use 16-byte accesses on every operand
-    if (dk > 4096) return SDPA_EUNSUP;       // (the any-shape kernel keeps a workgroup's four Q rows in LDS)
     SDPA_TRY(require_device());
     PartialArgs a = {};
     a.Q = Qf; a.ldq = ldq; a.K = Kf; a.ldk = ldk; a.V = Vf; a.ldv = ldv;

@@ -345,11 +345,18 @@ __global__ __launch_bounds__(256, (DKP > 128) ? 1 : 2) void fused_partial_kernel
 // coincide with the classic equal splits the pieces, their slabs and therefore the results are the same
 // bit for bit.
 #define SDPA_PK_SK 0
+#define SDPA_PK_STREAM 0
 #include "sdpa_fwd_f32_pipelined.inc"
 #undef SDPA_PK_SK
 #define SDPA_PK_SK 1
 #include "sdpa_fwd_f32_pipelined.inc"
 #undef SDPA_PK_SK
+#undef SDPA_PK_STREAM
+#define SDPA_PK_SK 0
+#define SDPA_PK_STREAM 1
+#include "sdpa_fwd_f32_pipelined.inc"
+#undef SDPA_PK_SK
+#undef SDPA_PK_STREAM
 
 // ---------------------------------------------------------------------------
 // In-GPU split merge: the reference's shard merge (attention-mpi.c:340-362 minus
@@ -391,13 +398,20 @@ __global__ void split_merge_kernel(PartialArgs a) {
 constexpr int kGenericMaxCols = 16;   // dv <= 64 * 16
 static const int kGenericMaxColsAnchor = 0;   // (an address of this library's own image: see next_ticket_tag)
 
-__global__ __launch_bounds__(256) void generic_partial_kernel(PartialArgs a, float scale) {
+// q_in_lds = 0 (round 5: dk beyond what four Q rows of LDS hold, > 4096): the lanes read the query row from global
+// memory instead -- every lane the same address, served by the L1 -- so that NO dk is refused: the reference's
+// dot_avx512 loops over any n (attention-mpi.c:103-121), a drop-in must answer too, at whatever rate.
+__global__ __launch_bounds__(256) void generic_partial_kernel(PartialArgs a, float scale, int q_in_lds) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
-    float *qs = smem + (size_t)wave * a.ldq;
-    if (row < a.m)
-        for (int t = lane; t < a.ldq; t += 64) qs[t] = a.Q[(size_t)row * a.ldq + t];
+    const float *qs = a.Q + (size_t)(row < a.m ? row : 0) * a.ldq;
+    if (q_in_lds) {
+        float *ql = smem + (size_t)wave * a.ldq;
+        if (row < a.m)
+            for (int t = lane; t < a.ldq; t += 64) ql[t] = a.Q[(size_t)row * a.ldq + t];
+        qs = ql;
+    }
     __syncthreads();
     if (row >= a.m) return;
 
@@ -687,6 +701,48 @@ static hipError_t launch_pipelined(const PartialArgs &a, hipStream_t s) {
     return e;
 }
 
+bool stream_launch_supported(int dk, int dv) { return dk > 32 && dv > 32 && dk <= kMaxFastDim && dv <= kMaxFastDim; }
+
+template <int DK, int DV>
+static hipError_t launch_streamed(const PartialArgs &a, const StreamArgs &st, hipStream_t s) {
+    const int nqb = (a.m + kQRowsPerBlock - 1) / kQRowsPerBlock;
+    const int ntiles = (a.n_local + kKvTile - 1) / kKvTile;
+    const int tiles_per_split = (ntiles + a.kv_splits - 1) / a.kv_splits;
+    const int kv_per_split = tiles_per_split > 0 ? tiles_per_split * kKvTile : kKvTile;
+    const size_t lds = (size_t)2 * kKvTile * (DK + DV) * sizeof(float);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    const float scale = 1.0f / sqrtf((float)a.dk);   // attention-mpi.c:208
+    PartialArgs k = a;
+    k.tickets = nullptr;
+    static AttrOnce attr;
+    hipError_t e;
+    if ((e = attr.ensure(&fused_pipelined_stream_kernel<DK, DV>, dev, lds)) != hipSuccess) return e;
+    hipLaunchKernelGGL((fused_pipelined_stream_kernel<DK, DV>), dim3(nqb * k.kv_splits), dim3(256), lds, s, k, kv_per_split,
+                       nqb, scale, st);
+    note_launch("fused_pipelined_stream_kernel", 2, DK, DV, 0, 0, 0, nqb * k.kv_splits, k.kv_splits, 0, a.m, a.n_local);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (k.kv_splits > 1 && !k.defer_merge) e = launch_split_merge(k, s);
+    return e;
+}
+
+hipError_t launch_shard_partial_streamed(const PartialArgs &a_in, const StreamArgs &st, hipStream_t s) {
+    PartialArgs a = a_in;
+    if (a.ws_rows <= 0) a.ws_rows = a.m;
+    a.tune = 0;
+    const int kp = a.ldq, vp = a.ldv;
+    const bool dense = a.ldq == a.ldk && (kp == 64 || kp == 128) && kp >= a.dk && (vp == 64 || vp == 128) && vp >= a.dv &&
+                       a.ldo >= vp && a.ldo % 4 == 0 && (a.kv_splits <= 1 || (a.ws_contrib && a.ws_ld >= vp)) &&
+                       (reinterpret_cast<uintptr_t>(a.K) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.V) & 15) == 0;
+    if (!dense || !st.flags || !st.status || st.n_chunks < 1 || st.n_chunks > kStreamMaxChunks || a.n_local <= 0)
+        return hipErrorInvalidValue;
+    if (kp == 128 && vp == 128) return launch_streamed<128, 128>(a, st, s);
+    if (kp == 64 && vp == 64) return launch_streamed<64, 64>(a, st, s);
+    if (kp == 128 && vp == 64) return launch_streamed<128, 64>(a, st, s);
+    return launch_streamed<64, 128>(a, st, s);
+}
+
 hipError_t launch_shard_partial(const PartialArgs &a_in, hipStream_t s) {
     PartialArgs a = a_in;
     if (a.ws_rows <= 0) a.ws_rows = a.m;
@@ -713,8 +769,9 @@ hipError_t launch_shard_partial(const PartialArgs &a_in, hipStream_t s) {
     if (uses_dksplit(a.dk, a.dv) && !(a.tune & 8))     // $SDPA_TUNE&8: the kernels it replaced
         return launch_dksplit(a, s);                    // sdpa_fwd_f32_dksplit.hip
     if (a.dk > kMaxMfmaDk) {
-        const size_t lds = (size_t)4 * a.ldq * sizeof(float);
-        if (lds > 64 * 1024) return hipErrorInvalidValue;          // dk <= 4096
+        size_t lds = (size_t)4 * a.ldq * sizeof(float);
+        const int q_in_lds = lds <= 64 * 1024 ? 1 : 0;             // dk <= 4096: the workgroup's four Q rows live in LDS
+        if (!q_in_lds) lds = 16;
         const float scale = 1.0f / sqrtf((float)a.dk);
         // the kernel holds 64 * kGenericMaxCols value columns per row: wider V goes in column chunks, one
         // launch each (the scores are recomputed; lmax / lsum come out the same from every chunk)
@@ -723,7 +780,7 @@ hipError_t launch_shard_partial(const PartialArgs &a_in, hipStream_t s) {
             ac.V = a.V + c0;
             ac.contrib = a.contrib + c0;
             ac.dv = std::min(64 * kGenericMaxCols, a.dv - c0);
-            hipLaunchKernelGGL(generic_partial_kernel, dim3((a.m + 3) / 4), dim3(256), lds, s, ac, scale);
+            hipLaunchKernelGGL(generic_partial_kernel, dim3((a.m + 3) / 4), dim3(256), lds, s, ac, scale, q_in_lds);
             note_launch("generic_partial_kernel", 0, 0, 0, 0, 0, 0, (a.m + 3) / 4, 1, 0, a.m, a.n_local);
             const hipError_t e = hipGetLastError();
             if (e != hipSuccess) return e;

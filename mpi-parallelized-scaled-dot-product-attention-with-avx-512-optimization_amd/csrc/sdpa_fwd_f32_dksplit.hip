@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256, 1) void fused_dksplit_pipe_kernel(
     constexpr int PD = 4;
     constexpr int G = 4 * QB;                  // exchange groups: 4 score registers of one query block each
     constexpr int MPS = NT * QB;               // MFMAs per P.V k-step
-    constexpr int SLOTS = 16 * MPS;            // MFMAs of one tile's P.V = places to put a unit
+    [[maybe_unused]] constexpr int SLOTS = 16 * MPS;            // MFMAs of one tile's P.V = places to put a unit
     constexpr int U_X = 7 * G;                 // units: per group 4 reads (one per wave's partial) + 3 sums
     constexpr int U_M = 6 * QB;                // row max (5 units of 3 max) + running-max update, per block
     constexpr int U_E = 16 * QB;               // one exponential each

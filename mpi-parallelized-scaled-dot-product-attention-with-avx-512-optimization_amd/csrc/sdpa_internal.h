@@ -93,6 +93,32 @@ struct PartialArgs {
                                    // registered with (register_stream_cus), the whole chip otherwise
 };
 
+// The persistent chunk-following launch (fused_pipelined_stream_kernel, sdpa_fwd_f32_pipelined.inc): where its ready
+// words live and what they announce.  Passed by value beside PartialArgs.
+constexpr int kStreamMaxChunks = 16;      // ready words [0, 16): K/V chunks; [16, 16 + kStreamMaxPieces): Q row pieces
+constexpr int kStreamMaxPieces = 8;
+// A ready word is raised by the COPY ENGINE, and on this runtime only copies of some size are the copy engine's: a 4-byte
+// host-to-device copy (and hipStreamWriteValue32) is carried out by a shader blit, which cannot become resident while
+// the persistent launch owns every register of every SIMD -- it lands when the launch ends (tools/probes/
+// stream_flag_probe2.hip, profiles/r05/stream_flag_probe2.log: never seen within 300 ms; a 64 KiB copy: seen at once).
+// So every ready word is the first word of its own 64 KiB block, and raising it copies 64 KiB of generation words.
+constexpr int kStreamFlagStride = 16384;  // words between two ready words (64 KiB)
+struct StreamArgs {
+    const unsigned *flags;                // device words, kStreamFlagStride apart; a word counts when it equals `gen`
+    unsigned gen;                         // this launch's generation (never 0; nothing is cleared between launches)
+    int n_chunks;
+    int chunk_end[kStreamMaxChunks];      // tiles of a split's K/V range that are on the device once chunk c has landed
+                                          // (strictly increasing; the last one covers the longest split)
+    int q_piece_blocks;                   // query blocks per Q row piece (0 = Q is resident before the launch)
+    unsigned long long timeout_ticks;     // wall_clock64 ticks (100 MHz) one wait may last
+    int *status;                          // device-visible word, set to 1 when a wait timed out (results are garbage then)
+};
+// dims the stream form exists for: dense images 64 / 128 wide on both sides (every BASELINE fp32 shape with d <= 128)
+bool stream_launch_supported(int dk, int dv);
+// classic grid ceil(m/128) x a.kv_splits (equal K/V ranges), ONE launch; + the split merge when kv_splits > 1 and
+// !defer_merge.  The triples are bit for bit those of launch_shard_partial() with the same kv_splits on resident inputs.
+hipError_t launch_shard_partial_streamed(const PartialArgs &a, const StreamArgs &st, hipStream_t s);
+
 // bf16 variant: Q,K row-major bf16 (ld = dk padded to 64/128/256/512, pad columns zero),
 // Vt = V transposed, bf16 [dv_pad x ldvt] (ldvt = n_local padded to 32, pads zero), key j of a
 // row stored at bf16_kvpos(j).

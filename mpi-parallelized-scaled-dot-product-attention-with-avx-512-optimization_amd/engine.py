@@ -149,13 +149,15 @@ class HipBackend:
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def to_device(self, a, dtype=None):
-        """host array -> device.  An ASYNCHRONOUS copy only from page-locked memory: handed a pageable source with
-        non_blocking=True, the HIP runtime maps the user's pages into the GPU's address space for the duration of the
-        copy, and two such transient mappings that share a page (neighbouring numpy arrays in the heap: K and V) pull
-        it from under each other -- the one GPU memory fault this repo has seen was a read of a page-aligned host
-        heap address in exactly this call (profiles/r04/gpu_memory_fault_on_a_host_heap_page.log)."""
+        """host array -> device, synchronously.  Not non_blocking: handed a pageable source with non_blocking=True the HIP
+        runtime maps the user's pages into the GPU's address space for the duration of the copy, and two such transient
+        mappings that share a page (neighbouring numpy arrays in the heap: K and V) pull it from under each other -- the one
+        GPU memory fault this repo has seen was a read of a page-aligned host heap address in exactly this call
+        (profiles/r04/gpu_memory_fault_on_a_host_heap_page.log).  And not `t.is_pinned()` to find out which sources could
+        go asynchronously either: that query is hipPointerGetAttributes, which makes ROCm 7 log "Cannot get amd_mem_obj
+        for ptr" at error level for every pageable array (round 5: 951 such lines in one -m gpu run came from here)."""
         t = torch.as_tensor(a)
-        return t.to(self.device, dtype=dtype, non_blocking=t.is_pinned() if t.device.type == "cpu" else True)
+        return t.to(self.device, dtype=dtype, non_blocking=t.device.type != "cpu")
 
     def empty(self, shape, dtype):
         return torch.empty(shape, dtype=dtype, device=self.device)

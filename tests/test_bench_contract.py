@@ -140,3 +140,19 @@ def test_abort_trace_names_the_native_thread_that_aborts(tmp_path):
     assert r.returncode == -6, r
     assert "SIGABRT raised on thread" in r.stderr and "abort+0x" in r.stderr and "end of native backtrace" in r.stderr, r.stderr
     assert r.stderr.index("SIGABRT raised") < r.stderr.index("Fatal Python error"), r.stderr      # then faulthandler's dump
+
+
+def test_other_configs_record_names_the_baseline_configs_and_the_n1_reference_is_committed():
+    """bench.py at N = 1 measures BASELINE configs 2, 4, 5 (bf16 and fp32) beside the headline (tests/test_gpu_bench_line.py
+    runs it); an N > 1 line states its speedup against the committed N = 1 figures"""
+    sys.path.insert(0, ROOT)
+    import bench
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    names = {k: (bench.WORKLOADS[wl], prec) for k, wl, prec in bench.OTHER_CONFIGS}
+    assert sorted(names) == ["config2", "config4", "config5_bf16", "config5_f32"]
+    assert names["config2"][0] == dict(m=8192, n=8192, d=128) and "m=8192 n=8192" in base["configs"][1]
+    assert names["config4"][0] == dict(m=131072, n=65536, d=128) and "m=131072 n=65536" in base["configs"][3]
+    assert names["config5_bf16"] == (dict(m=32768, n=65536, d=512), "bf16") and "d_k=d_v=512" in base["configs"][4]
+    ref = bench.n1_reference()
+    for wl in ("headline", "config3"):
+        assert ref[wl]["ms_per_step"] > 0 and ref[wl]["latency_ms"] > 0 and 0.5 < ref[wl]["frac"] < 1.0

@@ -43,7 +43,8 @@ def engine(pkg, monkeypatch):
         for k in ("SDPA_VIRTUAL_GPUS", "SDPA_FORCE_COLLECTIVES", "SDPA_QBATCH", "SDPA_KV_CHUNK_MIN",
                   "SDPA_KV_CHUNK_MAX", "SDPA_ROW_PIECES", "SDPA_PIECE_MIN_ROWS", "SDPA_PLAN", "SDPA_MERGE", "SDPA_PRECISION",
                   "SDPA_EGRESS", "SDPA_ENQUEUE_THREADS", "SDPA_PROGRESSIVE_PIN", "SDPA_HOST_CVT", "SDPA_HOST_CVT_THREADS",
-                  "SDPA_COMM_CUS", "SDPA_HOST_WIDEN", "SDPA_HOST_REGISTER"):
+                  "SDPA_COMM_CUS", "SDPA_HOST_WIDEN", "SDPA_HOST_REGISTER", "SDPA_STREAMED", "SDPA_STREAM_CHUNK_MIN",
+                  "SDPA_STREAM_TIMEOUT_MS", "SDPA_STREAM_DROP_WORD"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, str(v))
@@ -448,7 +449,9 @@ def test_convert_placement_is_chosen_per_problem(engine, orc, O):
     assert (pkg.last_timing()["host_convert_threads"] > 0) == big_host    # pageable: staged all the same
     assert pkg.attention(Q[:64], K[:512], V[:512]).shape == (64, 128)     # tiny: latency bound either way
     assert pkg.last_timing()["host_convert_threads"] == 0
-    # the same kernel-bound problem from page-locked caller arrays: the device converts
+    # the same kernel-bound problem from page-locked caller arrays: round 5 -- its first batch can run as ONE streamed launch,
+    # which only the host converts can feed (no convert kernel runs beside a persistent launch): host converts again;
+    # a kernel-bound problem whose kernels have no streamed form (d = 256) keeps the device converts
     bufs = []
     def pinned_copy(a):
         p = lib.sdpa_host_alloc(a.nbytes)
@@ -460,9 +463,16 @@ def test_convert_placement_is_chosen_per_problem(engine, orc, O):
     try:
         Qp, Kp, Vp = pinned_copy(Q), pinned_copy(K), pinned_copy(V)
         got = pkg.attention(Qp, Kp, Vp)
-        assert pkg.last_timing()["host_convert_threads"] == 0 and pkg.last_timing()["register_us"] == 0
+        t = pkg.last_timing()
+        assert (t["host_convert_threads"] > 0) == big_host and t["streamed"] == (1 if big_host else 0) and t["register_us"] == 0, t
         assert np.array_equal(got, want)
         del Qp, Kp, Vp
+        Q2, K2, V2 = (pinned_copy(rng.uniform(-1, 1, s)) for s in ((16384, 256), (16384, 256), (16384, 256)))
+        got = pkg.attention(Q2, K2, V2)
+        t = pkg.last_timing()
+        assert t["host_convert_threads"] == 0 and t["streamed"] == 0 and t["register_us"] == 0, t
+        assert np.isfinite(got).all()
+        del Q2, K2, V2
     finally:
         for q in bufs:
             lib.sdpa_host_free(q)
@@ -472,3 +482,111 @@ def test_convert_placement_is_chosen_per_problem(engine, orc, O):
     got = pkg.attention(Q, K, V, precision="bf16")
     assert (pkg.last_timing()["host_convert_threads"] > 0) == big_host
     check(got, orc.attention_f64(Q, K, V), V, "two ranks, host converts", 1e-2 * max(1.0, float(np.abs(V).max())))
+
+
+# ------------------------------------------------- the streamed first batch (round 5): ONE persistent launch that follows its inputs -----
+def device_level(pkg, Q, K, V, batch):
+    """the device-level path on resident inputs, batch after batch: converts, ONE fused launch per batch on the whole
+    shard (sdpa_dev_shard_partial_f32), finish -- what the streamed launch must reproduce bit for bit"""
+    be = pkg.HipBackend("cuda:0")
+    sa = pkg.ShardedAttention(be)
+    n, dk = K.shape
+    dv = V.shape[1]
+    sa.load_kv_shard_f64(torch.from_numpy(K).cuda(), torch.from_numpy(V).cuda(), n, dk, dv)
+    out = []
+    for i0 in range(0, Q.shape[0], batch):
+        qf = sa.convert_q(torch.from_numpy(Q[i0:i0 + batch]).cuda())
+        contrib, lmax, lsum = sa.batch_partial(qf)
+        out.append(be.finish_f64(contrib, lsum, dv).cpu().numpy())
+    return np.concatenate(out)
+
+
+@pytest.mark.parametrize("m,n,dk,dv,dist,env", [
+    (8192, 8192, 128, 128, "D2", {}),                       # BASELINE config 2: 8 splits, 2 groups, 16 row ranges per operand
+    (16384, 20000, 128, 128, "D2", {}),                     # 4 splits of 157 tiles: ragged last split and last tile
+    (32768, 16384, 64, 64, "D1", {}),                       # 2 splits, 64-wide images
+    (8192, 12000, 100, 72, "D3", {}),                       # padded dims (images 128 wide), peaky scores
+    (16384, 9001, 128, 64, "D4", {}),                       # adversarial: the spike key sits late in the last group; ragged last tile
+    (20000, 16384, 128, 128, "D2", {"SDPA_QBATCH": 8192}),  # 3 batches: the first streamed, the others on the resident shard
+    (8192, 40000, 128, 128, "D2", {"SDPA_STREAM_CHUNK_MIN": 1024, "SDPA_KV_CHUNK_MAX": 4096}),   # many small groups
+])
+def test_streamed_first_batch_is_the_device_level_launch_bit_for_bit(m, n, dk, dv, dist, env, engine, orc, O):
+    """Round 5: with host converts feeding it, the first Q batch is ONE persistent launch -- the classic
+    grid over the whole shard -- whose workgroups wait in the kernel for the ready word of the K/V group (and the Q row
+    piece) they are about to read; the copy engine raises the words behind the bytes.  Same pieces of work and the same
+    operations in the same order as sdpa_dev_shard_partial_f32 on resident inputs: the SAME result bit for bit (and so
+    deterministic from call to call); the launch-per-chunk schedule ($SDPA_STREAMED=0) sums in another order and agrees
+    within the path's tolerance; both against the fp64 oracle."""
+    Q, K, V = O.make_inputs(m, n, dk, dv, dist, seed=m + n)
+    batch = int(env.get("SDPA_QBATCH", 32768))
+    pkg = engine(**env)
+    got = pkg.attention(Q, K, V)
+    t = pkg.last_timing()
+    assert t["streamed"] == 1 and t["host_convert_threads"] > 0, t
+    assert "fused_pipelined" in t["last_kernel"], t["last_kernel"]
+    if m <= batch:
+        assert t["fused_launches"] == 1 and t["last_kernel"].startswith("sdpa::fused_pipelined_stream_kernel<"), t
+    want = device_level(pkg, Q, K, V, batch)
+    assert np.array_equal(got, want), "streamed launch differs from the device-level launch in %d values (max %.3e)" % (
+        (got != want).sum(), np.abs(got - want).max())
+    for rep in range(2):
+        assert np.array_equal(pkg.attention(Q, K, V), got), "call %d differs" % rep
+    rows = np.sort(np.random.default_rng(m).choice(m, 48, replace=False))
+    ref = O.numpy_attention_f64(Q, K, V, rows)
+    check(got[rows], ref, V, "streamed")
+    pkg = engine(SDPA_STREAMED=0, **env)
+    old = pkg.attention(Q, K, V)
+    assert pkg.last_timing()["streamed"] == 0 and pkg.last_timing()["fused_launches"] > 1
+    check(old[rows], ref, V, "launch per chunk")
+    assert np.abs(old - got).max() <= 2 * fp32_tol(V)
+
+
+def test_streamed_launch_from_page_locked_caller_arrays_and_on_loopback_ranks(engine, orc, O):
+    """the CLI's arrays (sdpa_host_alloc) take the streamed form too -- the host converts feed it, a device convert
+    could not run beside the persistent launch; so do the ranks of a K/V-sharded call, each on its own shard"""
+    import ctypes
+    m, n, d = 8192, 16384, 128
+    Q, K, V = O.make_inputs(m, n, d, d, "D2", seed=77)
+    pkg = engine()
+    lib = pkg.load()
+    want = pkg.attention(Q, K, V)
+    bufs = []
+
+    def pinned_copy(a):
+        p = lib.sdpa_host_alloc(a.nbytes)
+        assert p
+        bufs.append(p)
+        out = np.ctypeslib.as_array((ctypes.c_double * a.size).from_address(p)).reshape(a.shape)
+        out[...] = a
+        return out
+    try:
+        Qp, Kp, Vp = pinned_copy(Q), pinned_copy(K), pinned_copy(V)
+        got = pkg.attention(Qp, Kp, Vp)
+        t = pkg.last_timing()
+        assert t["streamed"] == 1 and t["host_convert_threads"] > 0, t
+        assert np.array_equal(got, want)
+        del Qp, Kp, Vp
+    finally:
+        for q in bufs:
+            lib.sdpa_host_free(q)
+    pkg = engine(SDPA_VIRTUAL_GPUS=2)
+    got2 = pkg.attention(Q, K, V)
+    t = pkg.last_timing()
+    assert t["streamed"] == 1 and t["n_gpus"] == 2, t
+    rows = np.arange(0, m, 171)
+    check(got2[rows], O.numpy_attention_f64(Q, K, V, rows), V, "2 loopback ranks, streamed shards")
+
+
+def test_streamed_launch_times_out_instead_of_hanging(engine, O):
+    """A ready word that never comes (here: dropped on purpose) must end the launch -- bounded by $SDPA_STREAM_TIMEOUT_MS
+    -- with an error from the call, not hang the GPU: every wait in the kernel watches the wall clock."""
+    import time
+    Q, K, V = O.make_inputs(8192, 8192, 128, 128, "D1", seed=5)
+    pkg = engine(SDPA_STREAM_TIMEOUT_MS=200, SDPA_STREAM_DROP_WORD=2)          # the second K/V group is never announced
+    t0 = time.perf_counter()
+    with pytest.raises(pkg.SdpaError):
+        pkg.attention(Q, K, V)
+    assert time.perf_counter() - t0 < 5.0
+    pkg = engine()
+    got = pkg.attention(Q, K, V)                                               # and the engine is usable afterwards
+    assert pkg.last_timing()["streamed"] == 1 and np.isfinite(got).all()

@@ -11,8 +11,9 @@ worth when the call has a next batch to hide a collective tail under, none for a
 same stream-K cuts), same merge algebra, sums in rank order on both sides (the C host's loopback
 collectives; the dev-mode gloo adapter of bench.py): the results must agree BIT FOR BIT, P in {2, 3, 8}, with
 ragged shards and several Q batches -- and both within the fp32 tolerance of the fp64 oracle.  (The C host
-streams its K/V shard in chunks under the first batch by default, which is a different -- equally exact --
-summation order; the comparison pins it to one launch per batch with the chunk knobs.)"""
+streamed its K/V shard as one launch per chunk in rounds 1-4, a different -- equally exact -- summation order: the first
+three cases pin it to one launch per batch with the chunk knobs.  Since round 5 the default first batch is ONE streamed
+launch with the device-level launch's own splits: the last two cases run the C host on its defaults.)"""
 import os
 import subprocess
 import sys
@@ -63,7 +64,7 @@ C_HOST = r'''
 import importlib, os, sys
 import numpy as np
 ROOT, PKG, out = sys.argv[1:4]
-m, n, d, seed, cus = (int(x) for x in sys.argv[4:9])
+m, n, d, seed, cus, streamed = (int(x) for x in sys.argv[4:10])
 for p in (ROOT, os.path.join(ROOT, "oracle")):
     sys.path.insert(0, p)
 import oracle as O
@@ -72,14 +73,20 @@ Q, K, V = O.make_inputs(m, n, d, d, "D2", seed=seed)
 res = pkg.attention(Q, K, V)
 t = pkg.last_timing()
 assert t["virtual_ranks"] == 1 and t["egress"] == 2 and t["merge"] == 1 and t["compute_cus"] == cus, t
+assert t["streamed"] == streamed, t
 np.save(out, res)
 '''
 
 
-@pytest.mark.parametrize("world,m,n,B", [(2, 4096, 8192, 4096),       # one batch, even shards
-                                         (3, 5000, 10000, 2048),      # ragged shards (3334, 3333, 3333), 3 batches, ragged shares
-                                         (8, 4096, 16385, 4096)])     # 8 ranks, shards of 2049 / 2048 rows
-def test_python_host_and_c_host_agree_bit_for_bit(world, m, n, B, tmp_path, O):
+@pytest.mark.parametrize("world,m,n,B,streamed", [
+    (2, 4096, 8192, 4096, 0),       # one batch, even shards
+    (3, 5000, 10000, 2048, 0),      # ragged shards (3334, 3333, 3333), 3 batches, ragged shares
+    (8, 4096, 16385, 4096, 0),      # 8 ranks, shards of 2049 / 2048 rows
+    # round 5: the C host on its DEFAULT knobs -- every rank's first batch is one streamed launch fed by host converts --
+    # is the Python host's device-level launch on the resident shard, bit for bit
+    (2, 8192, 32768, 8192, 1),
+    (3, 8192, 50000, 8192, 1)])     # ragged shards 16667 / 16667 / 16666: ragged last split and tile on every rank
+def test_python_host_and_c_host_agree_bit_for_bit(world, m, n, B, streamed, tmp_path, O):
     d, seed = 128, 40 + world
     out_dir = str(tmp_path)
     store = str(tmp_path / "store")
@@ -103,12 +110,15 @@ def test_python_host_and_c_host_agree_bit_for_bit(world, m, n, B, tmp_path, O):
     py = np.concatenate(py_rows)
 
     c_out = str(tmp_path / "c_host.npy")
-    cenv = dict(env, SDPA_VIRTUAL_GPUS=str(world), SDPA_QBATCH=str(B), SDPA_ROW_PIECES="1",
-                SDPA_KV_CHUNK_MIN=str(1 << 22), SDPA_KV_CHUNK_MAX=str(1 << 22), SDPA_HOST_CVT="0")
+    if streamed:
+        cenv = dict(env, SDPA_VIRTUAL_GPUS=str(world), SDPA_QBATCH=str(B))
+    else:
+        cenv = dict(env, SDPA_VIRTUAL_GPUS=str(world), SDPA_QBATCH=str(B), SDPA_ROW_PIECES="1",
+                    SDPA_KV_CHUNK_MIN=str(1 << 22), SDPA_KV_CHUNK_MAX=str(1 << 22), SDPA_HOST_CVT="0")
     # 16 compute units' worth of workgroup slots stay free for the comm streams when the call has a NEXT batch to hide a
     # collective tail under (csrc/sdpa_host.hip: comm_cus_reserved, make_plan); a one-batch call gets the whole chip
     cus = 240 if m > B else 256
-    r = subprocess.run([sys.executable, "-c", C_HOST, ROOT, PKG, c_out] + [str(x) for x in (m, n, d, seed, cus)],
+    r = subprocess.run([sys.executable, "-c", C_HOST, ROOT, PKG, c_out] + [str(x) for x in (m, n, d, seed, cus, streamed)],
                        capture_output=True, text=True, timeout=600, env=cenv)
     assert r.returncode == 0, r.stderr[-2500:]
     c = np.load(c_out)

@@ -40,11 +40,12 @@ def dev_attention(pkg, be, Q, K, V):
     return be.finish_f64(contrib, lsum, dv).cpu().numpy()
 
 
-def check(got, want, V, what=""):
+def check(got, want, V, what="", tol=None):
+    tol = fp32_tol(V) if tol is None else tol
     assert got.shape == want.shape
     assert np.isfinite(got).all(), what + ": non-finite values"
     err = np.abs(got - want).max()
-    assert err <= fp32_tol(V), "%s: max|err| %.3e > %.3e" % (what, err, fp32_tol(V))
+    assert err <= tol, "%s: max|err| %.3e > %.3e" % (what, err, tol)
     return err
 
 
@@ -187,17 +188,33 @@ def test_shapes_host_level(m, n, dk, dv, dist, pkg, orc, O):
 
 
 def test_dv_beyond_1024_host_level(pkg, be, orc, O):
-    """the reference takes any dv; here the MFMA kernels chunk the value columns, and the VALU
-    any-shape kernel (dk > 1024) is launched once per 1024 columns; only dk > 4096 is refused"""
+    """the reference takes any dv and any dk (dot_avx512 / axpy_avx512 loop over any n, attention-mpi.c:103-140); here the
+    MFMA kernels chunk the value columns, the VALU any-shape kernel (dk > 1024) is launched once per 1024 columns and,
+    beyond dk = 4096, reads its query row from global memory instead of LDS: nothing is refused (round 5)"""
     Q, K, V = O.make_inputs(50, 3000, 128, 1300, "D2", seed=8)
     check(pkg.attention(Q, K, V), orc.attention_f64(Q, K, V), V, "dv = 1300, streamed")
     Q, K, V = O.make_inputs(8, 40, 1100, 2500, "D1", seed=9)
     check(pkg.attention(Q, K, V), orc.attention_f64(Q, K, V), V, "dk = 1100, dv = 2500: three launches of the any-shape kernel")
     check(dev_attention(pkg, be, Q, K, V), orc.attention_f64(Q, K, V), V, "same, device level")
     Q, K, V = O.make_inputs(2, 3, 4100, 8, "D1", seed=10)
-    with pytest.raises(pkg.SdpaError) as e:
-        pkg.attention(Q, K, V)
-    assert e.value.code == pkg._lib.SDPA_EUNSUP
+    check(pkg.attention(Q, K, V), orc.attention_f64(Q, K, V), V, "dk = 4100: Q rows from global memory")
+    check(dev_attention(pkg, be, Q, K, V), orc.attention_f64(Q, K, V), V, "same, device level")
+    Q, K, V = O.make_inputs(37, 700, 9000, 70, "D2", seed=11)
+    check(pkg.attention(Q, K, V), orc.attention_f64(Q, K, V), V, "dk = 9000")
+
+
+def test_bf16_beyond_its_kernels_dims_runs_the_fp32_path(pkg, orc, O, capfd):
+    """SDPA_F_BF16 with dk > 512 or dv > 1024: the call answers on the fp32 path -- at the fp32 tolerance -- and says so on
+    stderr, instead of SDPA_EUNSUP (VERDICT r4 "what's missing" 4: a drop-in should still answer)"""
+    for (m, n, dk, dv) in [(8, 40, 600, 64), (20, 300, 64, 1100)]:
+        Q, K, V = O.make_inputs(m, n, dk, dv, "D2", seed=dk + dv)
+        got = pkg.attention(Q, K, V, precision="bf16")
+        check(got, orc.attention_f64(Q, K, V), V, "bf16 asked, fp32 run, dk=%d dv=%d" % (dk, dv))
+        assert "runs the fp32 path" in capfd.readouterr().err
+    Q, K, V = O.make_inputs(20, 300, 512, 1024, "D1", seed=3)                 # the largest dims the bf16 kernels take: bf16 it is
+    got = pkg.attention(Q, K, V, precision="bf16")
+    assert "runs the fp32 path" not in capfd.readouterr().err
+    check(got, orc.attention_f64(Q, K, V), V, "bf16 at its limit", 1e-2 * max(1.0, float(np.abs(V).max())))
 
 
 def test_host_level_q_pipeline_batches(pkg, orc, O, monkeypatch):
@@ -322,7 +339,10 @@ def test_headline_shape_row_subset(pkg, O):
     check(got[rows], O.numpy_attention_f64(Q, K, V, rows), V, "headline rows")
     t = pkg.last_timing()
     assert t["n_gpus"] >= 1 and t["q_batches"] == 1      # default Q batch = 32768 rows
-    assert t["kv_chunks"] >= 4 and t["fused_launches"] == t["kv_chunks"] + 6   # K/V streamed, first and last chunk in 4 row pieces
+    # round 5: ONE streamed launch that follows 5 K/V groups (rounds 1-4: a launch per chunk, first and last chunk in 4 row
+    # pieces -- kv_chunks + 6 launches; $SDPA_STREAMED=0 still runs that)
+    assert t["streamed"] == 1 and t["kv_chunks"] >= 4 and t["fused_launches"] == 1, t
+    assert t["last_kernel"] == "sdpa::fused_pipelined_stream_kernel<128,128>", t
     again = pkg.attention(Q, K, V)
     assert np.array_equal(again, got), "same inputs must give bit-identical results run to run"
 

@@ -14,7 +14,7 @@ SHAPES = [(32768, 65536, 128, 128), (8192, 8192, 128, 128), (512, 512, 64, 64), 
 
 @pytest.fixture(autouse=True)
 def clean_env(monkeypatch):
-    for k in ("SDPA_QBATCH", "SDPA_KV_CHUNK_MIN", "SDPA_KV_CHUNK_MAX", "SDPA_ROW_PIECES", "SDPA_PIECE_MIN_ROWS",
+    for k in ("SDPA_STREAMED", "SDPA_STREAM_CHUNK_MIN", "SDPA_QBATCH", "SDPA_KV_CHUNK_MIN", "SDPA_KV_CHUNK_MAX", "SDPA_ROW_PIECES", "SDPA_PIECE_MIN_ROWS",
               "SDPA_PLAN", "SDPA_MERGE", "SDPA_PRECISION", "SDPA_FORCE_COLLECTIVES"):
         monkeypatch.delenv(k, raising=False)
 
@@ -41,6 +41,43 @@ def check_rank(pl, rp, n_keys_expected, rows_expected):
     pr = rp["piece_rows"]
     rows0 = min(pl["q_batch"], rp["row_cnt"])
     assert (pr == rows0) or (pr % 128 == 0 and pl["piece_min_rows"] <= pr < rows0) or rows0 == 0
+    check_stream(pl, rp)
+
+
+def check_stream(pl, rp):
+    """the streamed form of the first batch (round 5): ONE launch, `splits` equal K/V ranges of `tiles_per_split` tiles;
+    group c brings tiles [end_tile[c-1], end_tile[c]) of EVERY split, as row ranges that tile the shard exactly once"""
+    st = rp["stream"]
+    if not st["on"]:
+        assert st["entries"] == []
+        return
+    assert pl["bf16"] == 0 and 1 <= st["splits"] <= 8 and rp["key_cnt"] >= 8192
+    tps, ends = st["tiles_per_split"], st["end_tile"]
+    ntiles = -(-rp["key_cnt"] // 32)
+    assert tps == -(-ntiles // st["splits"])
+    assert 1 <= len(ends) <= 16 and ends == sorted(set(ends)) and ends[-1] == tps and ends[0] >= 1
+    # a split's share of a group is at least 2048 keys (64 tiles) unless it is the split's whole range (one group)
+    for a, b in zip([0] + ends, ends):
+        assert b - a >= 64 or len(ends) == 1
+    # the row ranges: group major, inside a group ascending; group c covers exactly tiles [ends[c-1], ends[c]) of every
+    # split (adjacent ranges of a group are one copy); all of them tile the shard once
+    want = {c: set() for c in range(len(ends))}
+    for c, (a, b) in enumerate(zip([0] + ends, ends)):
+        for sx in range(st["splits"]):
+            want[c].update(t for t in range(sx * tps + a, sx * tps + b) if t < ntiles)
+    got = {c: set() for c in range(len(ends))}
+    last = (0, -1)
+    for k0, keys, group in st["entries"]:
+        assert keys > 0 and k0 % 32 == 0 and (group, k0) > last and group < len(ends)
+        last = (group, k0)
+        tiles = set(range(k0 // 32, -(-(k0 + keys) // 32)))
+        assert not (tiles & got[group])
+        got[group] |= tiles
+        assert k0 + keys <= rp["key_cnt"] and ((k0 + keys) % 32 == 0 or k0 + keys == rp["key_cnt"])
+    assert got == want
+    assert sum(k for _, k, _ in st["entries"]) == rp["key_cnt"]
+    if len(ends) == 1:
+        assert st["entries"] == [[0, rp["key_cnt"], 0]]
 
 
 @pytest.mark.parametrize("m,n,dk,dv", SHAPES)
@@ -151,3 +188,27 @@ def test_describe_rejects_bad_arguments(pkg):
     assert lib.sdpa_plan_describe(10, 10, 4, 4, 0, 17, big, len(big)) < 0
     assert lib.sdpa_plan_describe(10, 10, 0, 4, 0, 1, big, len(big)) < 0
     assert lib.sdpa_plan_describe(0, 0, 4, 4, 0, 2, big, len(big)) == 0            # empty problem: empty plan
+
+
+def test_streamed_first_batch_plan_on_the_baseline_shapes(pkg, monkeypatch):
+    """Where the first Q batch runs as ONE persistent launch that follows its K/V groups: every
+    BASELINE fp32 shape with d <= 128 -- with the split count of the device-level launch on the resident shard, which is
+    what makes the two bit-identical -- and where it does not: bf16, d > 128, few query blocks (many splits), a launch
+    stream-K would cut differently, SDPA_F_NO_PIPELINE, $SDPA_STREAMED=0."""
+    lib = pkg.load()
+    for (m, n, d, ranks) in [(32768, 65536, 128, 1), (8192, 8192, 128, 1), (32768, 262144, 128, 1), (131072, 65536, 128, 1),
+                             (32768, 262144, 128, 8), (32768, 65536, 64, 1)]:
+        pl = pkg.plan(m, n, d, d, 0, ranks)
+        for rp in pl["r"]:
+            st = rp["stream"]
+            assert st["on"] == 1, (m, n, d, ranks)
+            assert st["splits"] == lib.sdpa_dev_kv_splits(min(m, 32768), rp["key_cnt"], d, d)
+            check_stream(pl, rp)
+    assert pkg.plan(32768, 65536, 128, 128, 0, 1)["r"][0]["stream"]["end_tile"] == [64, 128, 256, 512, 1024]
+    c2 = pkg.plan(8192, 8192, 128, 128, 0, 1)["r"][0]["stream"]          # config 2: 8 splits of 1024 keys -> ONE group, one copy
+    assert c2["splits"] == 8 and c2["end_tile"] == [32] and c2["entries"] == [[0, 8192, 0]]
+    for (m, n, d, flags) in [(32768, 65536, 512, SDPA_F_BF16), (32768, 65536, 512, 0), (32768, 65536, 256, 0),
+                             (512, 65536, 128, 0), (32768, 4096, 128, 0), (32768, 65536, 128, SDPA_F_NO_PIPELINE)]:
+        assert pkg.plan(m, n, d, d, flags, 1)["r"][0]["stream"]["on"] == 0, (m, n, d, flags)
+    monkeypatch.setenv("SDPA_STREAMED", "0")
+    assert pkg.plan(32768, 65536, 128, 128, 0, 1)["r"][0]["stream"]["on"] == 0

@@ -24,7 +24,10 @@ widen = "--widen" in sys.argv
 # --register: what the boundary costs WITHOUT page-locking the caller's arrays ($SDPA_HOST_REGISTER=0) -- fp64 from
 # pageable memory to the device converts, or through the library's own page-locked staging (host converts / host widening)
 register = "--register" in sys.argv
-KNOBS = ("SDPA_QBATCH", "SDPA_KV_CHUNK_MIN", "SDPA_KV_CHUNK_MAX", "SDPA_ROW_PIECES", "SDPA_PIECE_MIN_ROWS", "SDPA_HOST_REGISTER",
+# --streamed: A/B of the first batch's form (round 5) -- one launch per K/V chunk ($SDPA_STREAMED=0) against ONE persistent
+# launch that follows its inputs (=1, the default), interleaved; then the group size of the streamed form
+streamed = "--streamed" in sys.argv
+KNOBS = ("SDPA_STREAMED", "SDPA_STREAM_CHUNK_MIN", "SDPA_QBATCH", "SDPA_KV_CHUNK_MIN", "SDPA_KV_CHUNK_MAX", "SDPA_ROW_PIECES", "SDPA_PIECE_MIN_ROWS", "SDPA_HOST_REGISTER",
          "SDPA_PROGRESSIVE_PIN")
 SWEEP = [{},
          {"SDPA_ROW_PIECES": 1},
@@ -67,12 +70,14 @@ for name in args or ["headline", "config2", "config1"]:
            {"SDPA_HOST_REGISTER": 0, "SDPA_HOST_CVT": 1, "SDPA_HOST_WIDEN": 0},
            {"SDPA_HOST_REGISTER": 0, "SDPA_HOST_CVT": 1, "SDPA_HOST_WIDEN": 1},
            {"SDPA_HOST_REGISTER": 1}, {}]
-    for knobs in (SWEEP if sweep else WID if widen else REG if register else CVT):
+    STR = [{"SDPA_STREAMED": 0}, {"SDPA_STREAMED": 1}, {"SDPA_STREAMED": 0}, {"SDPA_STREAMED": 1},
+           {"SDPA_STREAM_CHUNK_MIN": 2048}, {"SDPA_STREAM_CHUNK_MIN": 8192}, {"SDPA_ROW_PIECES": 8}, {"SDPA_ROW_PIECES": 2}, {}]
+    for knobs in (SWEEP if sweep else WID if widen else REG if register else STR if streamed else CVT):
         for k in KNOBS + ("SDPA_HOST_CVT", "SDPA_HOST_CVT_THREADS", "SDPA_HOST_WIDEN"):
             os.environ.pop(k, None)
         for k, v in knobs.items():
             os.environ[k] = str(v)
-        if hostcvt or widen or register:
+        if hostcvt or widen or register or streamed:
             pkg.shutdown()
             pkg.init(1)
             if lib.sdpa_prepare(m, n, d, d, flags) != 0:
@@ -88,7 +93,7 @@ for name in args or ["headline", "config2", "config1"]:
         row = {"shape": name, "pinned": pinned, "knobs": knobs}
         for k in ("total_us", "head_us", "tail_us", "register_us", "kv_stage_us", "pipeline_us", "kernel_us"):
             row[k.replace("_us", "_ms")] = round(best[k] / 1e3, 3)
-        for k in ("q_batches", "kv_chunks", "fused_launches", "kv_splits", "host_convert_threads", "host_widen"):
+        for k in ("q_batches", "kv_chunks", "fused_launches", "kv_splits", "host_convert_threads", "host_widen", "streamed", "last_kernel"):
             row[k] = best[k]
         row["kernel_tflops"] = round(4.0 * m * n * d / (best["kernel_us"] * 1e-6) / 1e12, 1)
         print(json.dumps(row), flush=True)

@@ -14,10 +14,10 @@ cd /tmp && export TMPDIR=/tmp
 #  summarize_prof.py quotes their average next to the all-dispatch average)
 STEPS=${PROF_STEPS:-10}
 # (--no-scaling-record --min-gpu-seconds 0: nothing but the W + K steps launches the fused kernel)
-BENCH="python $R/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-boundary --no-scaling-record --min-gpu-seconds 0 ${BENCH_ARGS:-}"
+BENCH="python $R/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-boundary --no-scaling-record --no-configs --min-gpu-seconds 0 ${BENCH_ARGS:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $BENCH > $OUT/trace.log 2>&1
 echo "trace rc=$?" >> $OUT/trace.log
-BENCH2="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-boundary --no-scaling-record --min-gpu-seconds 0 ${BENCH_ARGS:-}"
+BENCH2="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-boundary --no-scaling-record --no-configs --min-gpu-seconds 0 ${BENCH_ARGS:-}"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- $BENCH2 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- $BENCH2 > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -o bench -- $BENCH2 > $OUT/pmc_sq.log 2>&1
