@@ -577,6 +577,28 @@ __device__ __forceinline__ float halfwave_max(float x) {
 #ifndef SDPA_TANDEM_KIMM
 #define SDPA_TANDEM_KIMM 1
 #endif
+// -DSDPA_TANDEM_STAGGER=1 (round 5): the four waves of a workgroup leave every barrier in lockstep and would issue their
+// LDS-DMA pieces in the SAME MFMA gaps -- four 1-KiB pieces meeting at the CU's one vector-memory path, each waiting for the
+// others with its wave's MFMA issue stalled behind it.  Staggered, wave w issues in gap (g + w) % 4 of every four: the
+// steady-state loop exists once per wave (a scalar branch on the wave index picks it), the work and its order per
+// accumulator are unchanged (bit-identical results)
+#ifndef SDPA_TANDEM_STAGGER
+#define SDPA_TANDEM_STAGGER 0
+#endif
+// -DSDPA_TANDEM_SKEW=n (experiment): behind every barrier wave w idles w * n * 16 cycles, so that the four waves run the SAME
+// code n * 16 cycles apart (the stagger without four copies of the loop)
+#ifndef SDPA_TANDEM_SKEW
+#define SDPA_TANDEM_SKEW 0
+#endif
+#ifndef SDPA_TANDEM_BLOCKSPLIT
+#define SDPA_TANDEM_BLOCKSPLIT 1
+#endif
+#ifndef SDPA_TANDEM_PIN
+#define SDPA_TANDEM_PIN SDPA_TANDEM_STAGGER   // the accumulators are pinned to the accumulator file again at the loop's entry
+#endif
+#ifndef SDPA_TANDEM_VSHIFT
+#define SDPA_TANDEM_VSHIFT 1          // wave w's Vt pieces go into gap (VSHIFT + w) % 4 of every four P.V MFMAs
+#endif
 #ifndef SDPA_TANDEM_KIMM_LDS_PER_PIECE
 #define SDPA_TANDEM_KIMM_LDS_PER_PIECE 0
 #endif
@@ -1139,6 +1161,24 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_tandem_kernel(
         constexpr int KEEP = decltype(keep)::value;
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
         if constexpr (!(SDPA_TANDEM_ABL & 8)) __syncthreads();
+        if constexpr (SDPA_TANDEM_BLOCKSPLIT) {
+            // never taken (m > 0): it only ends the basic block behind the barrier.  Without it hipcc's live-range split keeps
+            // ONE accumulator tile in architectural VGPRs across the loop's back edge -- 16 v_accvgpr_write + 16 v_accvgpr_read
+            // and a full MFMA drain in front of the reads, every two steps; with it the loop has none (676 -> 656
+            // instructions per two steps, +1.0 % measured: profiles/r05/bf16_tandem_blocksplit_ab.log).  Found by accident:
+            // the wave-skew experiment's branches had this side effect.
+            if (__builtin_expect(__builtin_amdgcn_readfirstlane(a.m) < 0, 0)) asm volatile("s_nop 0");
+        }
+        if constexpr (SDPA_TANDEM_SKEW > 0) {
+            if (wave & 1) {
+#pragma unroll
+                for (int i = 0; i < SDPA_TANDEM_SKEW; ++i) asm volatile("s_nop 15");
+            }
+            if (wave & 2) {
+#pragma unroll
+                for (int i = 0; i < 2 * SDPA_TANDEM_SKEW; ++i) asm volatile("s_nop 15");
+            }
+        }
     };
 
     // K fragment byte addresses inside a K buffer (chunk 2ks+hi of row li, un-swizzled); the buffer being
@@ -1219,7 +1259,9 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_tandem_kernel(
     };
     // `parity` = t & 1 as a compile-time value (the loop below runs two steps per trip): buffer indices and
     // the direction of the K address flip are immediates
-    auto step = [&](auto has_next, auto fenced, auto parity, const u32x4 (&pb)[2], u32x4 (&pn)[2], int t) __attribute__((always_inline)) {
+    auto step = [&](auto has_next, auto fenced, auto parity, const u32x4 (&pb)[2], u32x4 (&pn)[2], int t, auto phase) __attribute__((always_inline)) {
+        constexpr int PH = decltype(phase)::value;          // this wave's DMA gap inside every group of four MFMAs
+        if constexpr (SDPA_TANDEM_PIN >= 2) pin_o();
         constexpr bool HAS_NEXT = decltype(has_next)::value;
         constexpr bool FENCED = decltype(fenced)::value;
         constexpr int vbuf = decltype(parity)::value;
@@ -1239,7 +1281,7 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_tandem_kernel(
                 else mfma_bf16_vgpr(sx, kf, qf[ks]);
                 if (ks + KD < NKS) kq[ks % KD] = kfrag(ks + KD);
                 if constexpr (!(SDPA_TANDEM_ABL & 4)) {
-                    if (ks % 4 == 0) {                               // K(t+2) into the buffer K(t) left (NKS / KPW == 4)
+                    if (ks % 4 == PH) {                              // K(t+2) into the buffer K(t) left (NKS / KPW == 4)
                         if constexpr (WHOLE) dma_k_piece_whole(t + 2, vbuf, ks / 4);
                         else dma_k_piece(tk, vbuf, ks / 4);
                     }
@@ -1283,7 +1325,7 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_tandem_kernel(
             if (partner && f + VD < FRAGS) vq[f % VD] = vfrag(vbuf, f + VD);
             if constexpr (HAS_NEXT) {
                 if constexpr (!(SDPA_TANDEM_ABL & 4))
-                    if (slot % 4 == 1) dma_v_piece(t + 1, vbuf ^ 1, slot / 4);   // VPW == 8 pieces over 32 slots
+                    if (slot % 4 == (SDPA_TANDEM_VSHIFT + PH) % 4) dma_v_piece(t + 1, vbuf ^ 1, slot / 4);   // VPW == 8 pieces over 32 slots
                 // first read of the score tile: >= 11 issue slots behind the chain's last link
                 if (slot >= 12 && slot < 28) p_elem(slot - 12, pn);
                 if (slot == 28) p_close(pn);
@@ -1332,20 +1374,35 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_tandem_kernel(
         // VALU work, next to MFMAs that do not overlap with VALU issue -- profiles/r04/bf16_ragged_mask_hoist.log.)
         // (... and three short of it, so that no steady-state step LOADS the last tile either -- K(t+2) goes out in
         //  step t -- and the K pieces need no row clamp: dma_k_piece_whole)
-        for (; t + 4 < T; t += 2) {
-            step(std::true_type(), std::false_type(), even(), pA, pB, t);
-            step(std::true_type(), std::false_type(), odd(), pB, pA, t + 1);
+        using ph0 = std::integral_constant<int, 0>;
+        auto steady = [&](auto phase) __attribute__((always_inline)) {
+            if constexpr (SDPA_TANDEM_PIN) pin_o();      // (every copy of the loop starts from the accumulators IN the accumulator file)
+            for (; t + 4 < T; t += 2) {
+                step(std::true_type(), std::false_type(), even(), pA, pB, t, phase);
+                step(std::true_type(), std::false_type(), odd(), pB, pA, t + 1, phase);
+            }
+        };
+        if constexpr (SDPA_TANDEM_STAGGER && NKS / KPW == 4) {
+            constexpr int S = SDPA_TANDEM_STAGGER == 1 ? 1 : 0;      // (== 2: four copies of the SAME loop, to tell the copies' cost from the phases')
+            switch (wave) {
+                case 0: asm volatile("; copy 0"); steady(ph0()); break;
+                case 1: asm volatile("; copy 1"); steady(std::integral_constant<int, 1 * S>()); asm volatile("s_nop 1"); break;
+                case 2: asm volatile("; copy 2"); steady(std::integral_constant<int, 2 * S>()); asm volatile("s_nop 2"); break;
+                default: asm volatile("; copy 3"); steady(std::integral_constant<int, 3 * S>()); asm volatile("s_nop 3"); break;
+            }
+        } else {
+            steady(ph0());
         }
         if (T - t >= 3) {                                   // 3 or 4 steps left: two fenced ones, then the cases below
-            step(std::true_type(), std::true_type(), even(), pA, pB, t);
-            step(std::true_type(), std::true_type(), odd(), pB, pA, t + 1);
+            step(std::true_type(), std::true_type(), even(), pA, pB, t, ph0());
+            step(std::true_type(), std::true_type(), odd(), pB, pA, t + 1, ph0());
             t += 2;
         }
         if (T - t == 2) {
-            step(std::true_type(), std::true_type(), even(), pA, pB, t);
-            step(std::false_type(), std::true_type(), odd(), pB, pA, t + 1);
+            step(std::true_type(), std::true_type(), even(), pA, pB, t, ph0());
+            step(std::false_type(), std::true_type(), odd(), pB, pA, t + 1, ph0());
         } else {
-            step(std::false_type(), std::true_type(), even(), pA, pB, t);
+            step(std::false_type(), std::true_type(), even(), pA, pB, t, ph0());
         }
     }
     // range test and fold exponent of this wave's OWN rows (as the wide kernel), then both go to the

@@ -581,8 +581,9 @@ def test_streamed_launch_times_out_instead_of_hanging(engine, O):
     """A ready word that never comes (here: dropped on purpose) must end the launch -- bounded by $SDPA_STREAM_TIMEOUT_MS
     -- with an error from the call, not hang the GPU: every wait in the kernel watches the wall clock."""
     import time
-    Q, K, V = O.make_inputs(8192, 8192, 128, 128, "D1", seed=5)
+    Q, K, V = O.make_inputs(8192, 32768, 128, 128, "D1", seed=5)               # two K/V groups (config 2 is ONE group)
     pkg = engine(SDPA_STREAM_TIMEOUT_MS=200, SDPA_STREAM_DROP_WORD=2)          # the second K/V group is never announced
+    assert len(pkg.plan(8192, 32768, 128, 128, 0, 1)["r"][0]["stream"]["end_tile"]) == 2
     t0 = time.perf_counter()
     with pytest.raises(pkg.SdpaError):
         pkg.attention(Q, K, V)

@@ -117,14 +117,17 @@ def test_tandem_kernel_loop_is_spill_free_and_reads_50_fragments_per_64_mfmas(bf
     c = main_loop_mix(kernel_lines(bf16_asm, "fused_bf16_tandem_kernelILi512E"))
     assert c["v_mfma_f32_32x32x16_bf16"] == 128 and c["ds_read_b128"] == 100 and c["ds_write_b128"] == 4, c
     assert sum(v for k, v in c.items() if k.startswith("scratch_")) == 0, c
-    assert c["v_accvgpr_read_b32"] <= 16 and c["v_accvgpr_write_b32"] <= 16, c
+    # round 5: NO accumulator tile crosses the back edge through architectural VGPRs (a never-taken scalar branch behind each
+    # barrier ends the basic block there, SDPA_TANDEM_BLOCKSPLIT: 16 + 16 v_accvgpr moves and an MFMA drain per two steps gone,
+    # +1.0 % measured)
+    assert c["v_accvgpr_read_b32"] == 0 and c["v_accvgpr_write_b32"] == 0, c
     assert c["global_load_lds_dwordx4"] == 32 and c["s_barrier"] == 4 and c["v_exp_f32"] == 32, c
     # round 4: no ragged-tile mask and no K-row clamp in the steady state (they live in the tail steps) and ONE scalar
     # address per K tile (immediate-offset pieces): 758 -> 676 instructions per two steps.  A compiler that brings the
     # selects or the per-piece address arithmetic back shows up here.
     assert c["v_cndmask_b32_e32"] + c["v_cndmask_b32_e64"] == 0 and c["s_min_i32"] == 0, c
     assert c["s_lshl_b64"] <= 4 and c["s_add_u32"] <= 24, c
-    assert sum(c.values()) <= 700, (sum(c.values()), c)
+    assert sum(c.values()) <= 670, (sum(c.values()), c)
 
 
 @pytest.fixture(scope="module")
