@@ -541,6 +541,31 @@ def test_streamed_first_batch_is_the_device_level_launch_bit_for_bit(m, n, dk, d
     assert np.abs(old - got).max() <= 2 * fp32_tol(V)
 
 
+@pytest.mark.parametrize("m,n", [(8192, 8192), (8192, 32768), (16384, 8192)])
+def test_streamed_calls_back_to_back_on_different_inputs_never_see_the_previous_calls_bytes(m, n, engine, O):
+    """The operand images of a streamed call land in the SAME device buffers as the previous call's while the launch is
+    already resident -- after the runtime's invalidate at the launch's start.  What keeps a workgroup from multiplying the
+    previous call's K/V (or Q) out of an L2 / L1 line is the system-scope acquire behind each ready word.  Shapes whose
+    images fit the 4 MiB L2s (config 2; 16384 x 8192: 4 splits) and a two-group one, two different input sets alternating
+    in one engine: every call equals its own set's first result bit for bit and the fp64 restatement on a row subset."""
+    d = 128
+    sets = [O.make_inputs(m, n, d, d, dist, seed=seed) for dist, seed in (("D1", 11), ("D2", 12))]
+    pkg = engine()
+    rows = np.arange(0, m, max(1, m // 40))
+    first = []
+    for Q, K, V in sets:
+        got = pkg.attention(Q, K, V)
+        assert pkg.last_timing()["streamed"] == 1, pkg.last_timing()
+        check(got[rows], O.numpy_attention_f64(Q, K, V, rows), V, "first call of a set")
+        first.append(got)
+    assert np.abs(first[0] - first[1]).max() > 1e-3               # (the sets really differ)
+    for rep in range(6):
+        for (Q, K, V), want in zip(sets, first):
+            got = pkg.attention(Q, K, V)
+            assert np.array_equal(got, want), "round %d: %d values differ from the set's first result (max %.3e)" % (
+                rep, (got != want).sum(), np.abs(got - want).max())
+
+
 def test_streamed_launch_from_page_locked_caller_arrays_and_on_loopback_ranks(engine, orc, O):
     """the CLI's arrays (sdpa_host_alloc) take the streamed form too -- the host converts feed it, a device convert
     could not run beside the persistent launch; so do the ranks of a K/V-sharded call, each on its own shard"""
