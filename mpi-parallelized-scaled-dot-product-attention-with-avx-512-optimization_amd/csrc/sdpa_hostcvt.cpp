@@ -11,6 +11,8 @@
 #include <deque>
 #include <memory>
 #include <mutex>
+#include <chrono>
+#include <cstdio>
 #include <thread>
 #include <vector>
 
@@ -250,7 +252,18 @@ struct Batch {
     std::deque<Task> tasks;            // (deque: a Task holds an atomic and never moves)
     std::vector<Item> items;
     std::atomic<long> next{0};
+    // $SDPA_HOST_CVT_TRACE only (microseconds on the steady clock)
+    double t_kick = 0;
+    std::atomic<double> first_min{1e300}, first_max{0}, last_done{0}, busy_us{0};
+    std::atomic<int> workers{0};
 };
+
+inline double trace_now() {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+inline void atomic_min(std::atomic<double> &a, double v) { double c = a.load(); while (v < c && !a.compare_exchange_weak(c, v)) {} }
+inline void atomic_max(std::atomic<double> &a, double v) { double c = a.load(); while (v > c && !a.compare_exchange_weak(c, v)) {} }
+inline void atomic_add(std::atomic<double> &a, double v) { double c = a.load(); while (!a.compare_exchange_weak(c, c + v)) {} }
 
 class Pool final : public HostConverter {
 public:
@@ -293,8 +306,8 @@ public:
     }
     int submit(const double *src, void *dst, long rows, int cols, int ld, CvtKind kind, double mult) override {
         if (!mine_) mine_ = std::make_shared<Batch>();
-        // items of ~64 KiB of source: small enough to balance, large enough to stream
-        long per = 8192 / (cols > 0 ? cols : 1);
+        // items of ~64 KiB of source ($SDPA_HOST_CVT_ITEM_KB): small enough to balance, large enough to stream
+        long per = (long)item_kb_ * 128 / (cols > 0 ? cols : 1);
         if (per < 1) per = 1;
         const long n_items = rows > 0 ? (rows + per - 1) / per : 0;
         const int id = (int)mine_->tasks.size();
@@ -303,6 +316,7 @@ public:
         return id;
     }
     void kick() override {
+        if (trace_ && mine_) mine_->t_kick = trace_now();
         {
             std::lock_guard<std::mutex> lk(mu_);
             cur_ = mine_;               // complete: nothing is added to a batch after this
@@ -326,6 +340,17 @@ public:
         if (kicked)
             for (Task &t : mine_->tasks)
                 while (t.remaining.load(std::memory_order_acquire) > 0) relax();
+        if (trace_ && kicked && !mine_->items.empty()) {
+            // $SDPA_HOST_CVT_TRACE=1: where one call's conversions spent their time (one line on stderr per call)
+            Batch &b = *mine_;
+            double bytes = 0;
+            for (const Item &it : b.items) bytes += (double)it.rows * b.tasks[it.task].cols * 8.0;
+            const double first_lo = b.first_min.load(), first_hi = b.first_max.load(), last = b.last_done.load();
+            fprintf(stderr, "sdpa hostcvt trace: %zu items, %.1f MB of fp64 | workers that took items %d of %zu | first item taken %.0f .. %.0f us "
+                    "after the kick | last item done at %.0f us | sum of busy time %.0f us (%.1f GB/s per busy thread) | %.1f GB/s over the span\n",
+                    b.items.size(), bytes / 1e6, b.workers.load(), th_.size(), first_lo - b.t_kick, first_hi - b.t_kick, last - b.t_kick,
+                    b.busy_us.load(), bytes / 1e3 / std::max(1.0, b.busy_us.load()), bytes / 1e3 / std::max(1.0, last - b.t_kick));
+        }
         mine_.reset();
     }
 
@@ -381,9 +406,11 @@ private:
             if (w) w->work();
             if (!b) continue;
             const long total = (long)b->items.size();
+            double t_first = 0;
             for (;;) {
                 const long i = b->next.fetch_add(1, std::memory_order_relaxed);
                 if (i >= total) break;
+                if (trace_ && t_first == 0) t_first = trace_now();
                 const Item &it = b->items[i];
                 Task &t = b->tasks[it.task];
                 const double *s = t.src + it.row0 * t.cols;
@@ -392,6 +419,14 @@ private:
                 else
                     rows_to_bf16(s, (unsigned short *)t.dst + it.row0 * t.ld, it.rows, t.cols, t.ld, t.mult, nt_);
                 t.remaining.fetch_sub(1, std::memory_order_release);
+            }
+            if (trace_ && t_first != 0) {
+                const double t_end = trace_now();
+                atomic_min(b->first_min, t_first);
+                atomic_max(b->first_max, t_first);
+                atomic_max(b->last_done, t_end);
+                atomic_add(b->busy_us, t_end - t_first);
+                b->workers.fetch_add(1);
             }
         }
     }
@@ -406,6 +441,12 @@ private:
     std::shared_ptr<Batch> mine_;      // the calling thread's handle on the batch it is building / waiting for
     Buf buf_[4];
     const bool nt_ = stream_stores_default();
+    const bool trace_ = getenv("SDPA_HOST_CVT_TRACE") && atoi(getenv("SDPA_HOST_CVT_TRACE")) != 0;
+    const int item_kb_ = [] {
+        const char *v = getenv("SDPA_HOST_CVT_ITEM_KB");
+        const int kb = (v && *v) ? atoi(v) : 64;
+        return kb < 4 ? 4 : kb > 16384 ? 16384 : kb;
+    }();
 };
 
 }  // namespace

@@ -63,7 +63,7 @@ for name in args or ["headline", "config2", "config1"]:
     (Q, pq), (K, pk), (V, pv) = hostbuf(Q), hostbuf(K), hostbuf(V)
     R, pr = hostbuf(np.zeros((m, d)))
     flags = 2 if prec else 0
-    CVT = ([{"SDPA_HOST_CVT": 0}] + [{"SDPA_HOST_CVT": 1, "SDPA_HOST_CVT_THREADS": t} for t in (8, 16, 32, 64)] + [{}]) if hostcvt else [{}]
+    CVT = ([{"SDPA_HOST_CVT": 0}] + [{"SDPA_HOST_CVT": 1, "SDPA_HOST_CVT_THREADS": t} for t in (16, 32, 48, 64, 96)] + [{}]) if hostcvt else [{}]
     WID = [{"SDPA_HOST_WIDEN": 0}, {"SDPA_HOST_WIDEN": 1}, {"SDPA_HOST_WIDEN": 0}, {"SDPA_HOST_WIDEN": 1}, {}]
     REG = [{"SDPA_HOST_REGISTER": 1}, {"SDPA_HOST_REGISTER": 0},
            {"SDPA_HOST_REGISTER": 0, "SDPA_HOST_CVT": 0, "SDPA_HOST_WIDEN": 0},

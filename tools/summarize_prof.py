@@ -118,12 +118,12 @@ if disp:
             traffic / 1e6, f, w, traffic / algo, algo / 1e6))
         print("HBM-side rate              %.1f GB/s = %.2f %% of the 8 TB/s peak" % (gbps, gbps / 80.0))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    h = hashlib.sha256()
-    srcs = (("sdpa_fwd_bf16.hip", "sdpa_internal.h") if precision == "bf16" else       # = bench.KERNEL_SOURCES
-            ("sdpa_fwd_f32.hip", "sdpa_fwd_f32_dksplit.hip", "sdpa_f32_device.h", "sdpa_internal.h"))
-    for fn in srcs:                           # the fused kernels' sources (bench.py quotes the figures only for this build)
-        h.update(open(os.path.join(root, "mpi-parallelized-scaled-dot-product-attention-with-avx-512-optimization_amd", "csrc", fn), "rb").read())
-    entry["kernel_src_sha16"] = h.hexdigest()[:16]
+    # the fused kernels' sources (bench.py quotes the figures only for this build): bench.py's own list and hash, so the two cannot drift
+    # apart again (round 5: the .inc with the kernel body was missing here, the headline entry's stamp never matched)
+    sys.path.insert(0, root)
+    import bench as _bench
+    _stamp = _bench.kernel_source_stamp(precision)
+    entry["kernel_src_sha16"] = _stamp
     # provenance: bench.py copies these figures into its line -- say when, where and with what they were measured
     import datetime, subprocess
     entry["measured"] = datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ")
