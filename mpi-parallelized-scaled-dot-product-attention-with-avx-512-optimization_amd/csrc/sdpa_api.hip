@@ -262,6 +262,14 @@ int sdpa_host_cvt_rows(const double *src, void *dst, long rows, int cols, int ld
     return SDPA_OK;
 }
 
+int sdpa_host_cvt_vt(const double *src, unsigned short *dst, long keys, long keys_pad, int cols, int cols_pad, long ldt, int flags) {
+    if (keys < 0 || cols <= 0 || cols_pad < cols || keys_pad < keys || keys_pad % 32 != 0 || ldt < keys_pad) return SDPA_EINVAL;
+    if (keys_pad == 0) return SDPA_OK;
+    if ((!src && keys > 0) || !dst) return SDPA_EINVAL;
+    sdpa::host_convert_vt(src, dst, keys, keys_pad, cols, cols_pad, ldt, (flags & 1) != 0, (flags & 2) ? 1 : (flags & 4) ? 0 : -1);
+    return SDPA_OK;
+}
+
 int sdpa_host_widen(const float *src, double *dst, size_t n, int threads, int flags) {
     if (n == 0) return SDPA_OK;
     if (!src || !dst) return SDPA_EINVAL;

@@ -221,4 +221,11 @@ hipError_t launch_finish_f32(const float *contrib, int ldo, const float *lsum, f
     return hipGetLastError();
 }
 
+// (sdpa_internal.h: preload_kernels_*) touching one kernel makes the runtime load this translation unit's code object for the
+// current device NOW -- not in front of the first launch that needs it, possibly behind a resident persistent launch
+hipError_t preload_kernels_aux() {
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&cvt_d2f_kernel));
+}
+
 }  // namespace sdpa

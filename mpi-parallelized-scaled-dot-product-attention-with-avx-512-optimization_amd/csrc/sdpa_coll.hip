@@ -381,4 +381,11 @@ Collectives *make_loopback_collectives(int P, int dev) {
     return c;
 }
 
+// (sdpa_internal.h: preload_kernels_*) touching one kernel makes the runtime load this translation unit's code object for the
+// current device NOW -- not in front of the first launch that needs it, possibly behind a resident persistent launch
+hipError_t preload_kernels_coll() {
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&loop_gather_kernel));
+}
+
 }  // namespace sdpa

@@ -982,475 +982,12 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
     }
 }
 
-// ---------------------------------------------------------------------------
-// Tandem variant of the wide kernel (dv > 256; round 3): two waves share 64 query rows.
-// In the wide kernel every LDS fragment read feeds ONE MFMA, and four SIMDs issuing one
-// v_mfma_f32_32x32x16_bf16 per 32 cycles ask for exactly the 128 B/clk an LDS delivers (64 reads per 64
-// MFMAs per wave and tile).  The duo kernel's way out -- two query blocks per wave -- needs 2 x 256
-// accumulator registers at dv = 512.  Here the two waves of a PAIR split the VALUE COLUMNS instead:
-//   * wave w still scores its own 32 query rows (Q fragment 128 VGPRs, S^T = K.Q^T, 32 K fragment reads),
-//     turns them into P (bf16) and hands P to its partner through LDS (2 KiB per wave and tile);
-//   * in O^T += Vt.P^T it accumulates BOTH blocks of the pair over ITS 256 of the chunk's 512 columns:
-//     2 x 8 x 16 = 256 accumulator registers as before, but every Vt fragment now feeds two MFMAs
-//     (its own P and the partner's): 16 Vt reads + 2 P reads instead of 32.  50 fragment reads per 64 MFMAs.
-//   * the P buffers take 16 KiB, so K has two LDS buffers instead of three (64 + 64 + 16 KiB): K(t+3) and
-//     Vt(t+1) are both requested under step t's P.V MFMAs (independent accumulators: plenty of shadow),
-//     nothing is issued beside the dependent score chain, and the one barrier of a step -- behind the
-//     chain, with vmcnt(0) -- covers everything the next step reads.
-// Same outputs as the wide kernel bit for bit (same MFMA order per accumulator, same softmax
-// arithmetic): tests/test_gpu_bf16.py compares the two.
-// ---------------------------------------------------------------------------
-template <int DK>
-__global__ __launch_bounds__(256, 1) void fused_bf16_tandem_kernel(
-    Bf16Args a, int kv_per_split, int n_qblocks, int n_chunks, float scale) {
-    SDPA_AUDIT_LAUNCH(g_bf16_audit);
-    constexpr int DVC = 512;                   // value columns per workgroup (one chunk)
-    constexpr int NKS = DK / 16;               // QK^T k-steps = MFMAs per score tile
-    constexpr int NTW = 8;                     // 32-column blocks of O^T per wave (256 of the chunk's 512 columns)
-    constexpr int KCH = DK / 8;                // 16-byte chunks per K row
-    constexpr int KTILE = kKvTile * DK;        // bf16 elements, unpadded (swizzled)
-    constexpr int VTILE = DVC * kKvTile;       // bf16 elements: 64-byte rows, swizzled
-    constexpr int KPW = (kKvTile * KCH / 64) / 4;   // 1-KiB DMA pieces per wave per K tile
-    constexpr int RPP = 64 / KCH > 0 ? 64 / KCH : 1; // K rows per DMA piece
-    constexpr int VPW = (DVC * 4 / 64) / 4;         // 1-KiB DMA pieces per wave per Vt tile (16 rows each)
-    constexpr int SWZ = KCH >= 16 ? 15 : KCH - 1;
-    constexpr unsigned PBASE = (unsigned)(2 * KTILE + 2 * VTILE) * 2u;   // byte offset of the P exchange area
-    static_assert(KCH >= 8 && KPW >= 1, "DK must be 64..512");
-
-    extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
-    unsigned short *const Ks = smem16;                    // [2][KTILE]
-    unsigned short *const Vs = smem16 + 2 * KTILE;        // [2][VTILE]
-    char *const Ps = reinterpret_cast<char *>(smem16) + PBASE;   // [2 buffers][4 waves][2 key halves][64 lanes] x 16 B
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int role = wave & 1;                 // which half of the chunk's columns this wave accumulates
-    const int li = lane & 31;
-    const int hi = lane >> 5;
-
-    int work = xcd_remap_b(blockIdx.x, gridDim.x);
-    const int qblock = work % n_qblocks;
-    work /= n_qblocks;
-    const int chunk = work % n_chunks;
-    const int split = work / n_chunks;
-    const int qrow = qblock * kQRowsPerBlock + wave * 32 + li;          // the rows this wave SCORES
-    const int prow = qblock * kQRowsPerBlock + (wave ^ 1) * 32 + li;    // its partner's rows
-    const int dv0 = chunk * DVC + role * 256;
-
-    const int kv_begin = split * kv_per_split;
-    const int kv_end = min(a.n_local, kv_begin + kv_per_split);
-    const int T = kv_end > kv_begin ? (kv_end - kv_begin + kKvTile - 1) / kKvTile : 0;
-    (void)scale;                               // log2(e)/sqrtf(dk) lives in the Q image (sdpa_dev_cvt_d2bf_q)
-
-    u32x4 qf[NKS];
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        if (qrow < a.m)
-            qf[ks] = *reinterpret_cast<const u32x4 *>(a.Q + (size_t)qrow * DK + 16 * ks + 8 * hi);
-        else
-            qf[ks] = u32x4{0u, 0u, 0u, 0u};
-    }
-
-    f32x16 oown[NTW], opar[NTW];               // O^T of this wave's own rows / of its partner's rows
-#pragma unroll
-    for (int t = 0; t < NTW; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { oown[t][r] = 0.f; opar[t][r] = 0.f; }
-    auto pin_o = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int tt = 0; tt < NTW; ++tt) {
-            asm volatile("" : "+a"(oown[tt]));
-            asm volatile("" : "+a"(opar[tt]));
-        }
-    };
-    pin_o();
-    float l_run = 0.f;                                    // this half-wave's share of the row sum (own rows)
-
-    // ---- K and Vt staging by LDS-DMA (as the wide kernel)
-    const unsigned lds_base = __builtin_amdgcn_readfirstlane(
-        (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)smem16);
-    auto dma_piece = [&](const char *gbase, unsigned lane_off, unsigned lds_byte) __attribute__((always_inline)) {
-        SDPA_BF16_AUDIT(a, gbase + lane_off);
-        asm volatile("s_mov_b32 m0, %1\n\t"
-                     "s_nop 0\n\t"
-                     "global_load_lds_dwordx4 %0, %2"
-                     :
-                     : "v"(lane_off), "s"(lds_byte), "s"(gbase)
-                     : "memory" SDPA_M0_CLOBBER);
-    };
-    auto dma_piece_xor = [&](const char *gbase, unsigned lane_part, unsigned swz, unsigned lds_byte) __attribute__((always_inline)) {
-        SDPA_BF16_AUDIT(a, gbase + (lane_part ^ swz));
-        unsigned off;
-        asm volatile("s_mov_b32 m0, %2\n\t"
-                     "v_xor_b32 %0, %3, %1\n\t"
-                     "global_load_lds_dwordx4 %0, %4"
-                     : "=&v"(off)
-                     : "v"(lane_part), "s"(lds_byte), "s"(swz), "s"(gbase)
-                     : "memory" SDPA_M0_CLOBBER);
-    };
-    // the same with the piece's place inside the tile as an IMMEDIATE (steady-state steps, DK = 512: a piece is one
-    // K row = 1 KiB, a wave's eight rows are consecutive; `gmid` points at the wave's FIFTH row, so pieces 0..7 sit at
-    // -4096 .. +3072, inside the instruction's signed 13-bit offset): ONE scalar address per tile instead of
-    // clamp + shift + 64-bit add per piece -- five scalar instructions per piece that a one-wave-per-SIMD
-    // kernel pays for in issue slots (profiles/r04/bf16_tandem_ablations.log)
-#define SDPA_K_PIECE_IMM(J, OFF)                                                                          \
-    case J:                                                                                               \
-        asm volatile("s_mov_b32 m0, %2\n\t"                                                               \
-                     "v_xor_b32 %0, %3, %1\n\t"                                                           \
-                     "global_load_lds_dwordx4 %0, %4 offset:" #OFF                                         \
-                     : "=&v"(off)                                                                         \
-                     : "v"(lane_part), "s"(lds_byte), "s"(swz), "s"(gmid)                                 \
-                     : "memory" SDPA_M0_CLOBBER);                                                         \
-        break;
-    auto dma_piece_xor_imm = [&](const char *gmid, int j, unsigned lane_part, unsigned swz, unsigned lds_byte) __attribute__((always_inline)) {
-        SDPA_BF16_AUDIT(a, gmid + (j - 4) * 1024 + (lane_part ^ swz));
-        unsigned off;
-        switch (j) {
-            SDPA_K_PIECE_IMM(0, -4096)
-            SDPA_K_PIECE_IMM(1, -3072)
-            SDPA_K_PIECE_IMM(2, -2048)
-            SDPA_K_PIECE_IMM(3, -1024)
-            SDPA_K_PIECE_IMM(4, 0)
-            SDPA_K_PIECE_IMM(5, 1024)
-            SDPA_K_PIECE_IMM(6, 2048)
-            default: SDPA_K_PIECE_IMM(7, 3072)
-        }
-    };
-#undef SDPA_K_PIECE_IMM
-    const unsigned klane = (unsigned)((lane / KCH) * DK * 2 + (((lane % KCH) ^ ((lane / KCH) & SWZ)) << 4));
-    // a tile that is NOT the shard's last one is whole: no row clamp (the steady-state loop never loads the last tile)
-    auto dma_k_piece_whole = [&](int tile, int buf, int j) __attribute__((always_inline)) {
-        static_assert(true, "");
-        const int row0 = wave * KPW + j;
-        const unsigned swz = (unsigned)((row0 & SWZ) << 4);
-        // the instruction's immediate offset moves BOTH ends of an LDS-DMA -- the global address and the LDS
-        // address (M0 + offset + 16 * lane) -- so M0 names the wave's fifth row in the buffer as well, for every piece
-        // (-DSDPA_TANDEM_KIMM_LDS_PER_PIECE=1: M0 per piece, i.e. the offset taken as global-only -- call 9's bug, kept
-        // for the A/B that settled it)
-        const unsigned dst = lds_base + (unsigned)(buf * KTILE * 2 + (wave * KPW + (SDPA_TANDEM_KIMM_LDS_PER_PIECE ? j : 4)) * 1024);
-        const char *gmid = reinterpret_cast<const char *>(a.K + (size_t)(kv_begin + tile * kKvTile + wave * KPW + 4) * DK);
-        dma_piece_xor_imm(gmid, j, klane, swz, dst);
-    };
-    auto dma_k_piece = [&](int tile, int buf, int j) __attribute__((always_inline)) {
-        const int base = kv_begin + tile * kKvTile;
-        const int last = kv_end - 1 - base;
-        const char *kb = reinterpret_cast<const char *>(a.K + (size_t)base * DK);
-        const int row0 = (wave * KPW + j) * RPP;
-        const unsigned swz = (unsigned)((row0 & SWZ) << 4);
-        const unsigned dst = lds_base + (unsigned)(buf * KTILE * 2 + (wave * KPW + j) * 1024);
-        if constexpr (RPP == 1) {
-            dma_piece_xor(kb + (size_t)min(row0, last) * (DK * 2), klane, swz, dst);
-        } else {
-            unsigned off;
-            asm volatile("v_xor_b32 %0, %1, %2" : "=v"(off) : "s"(swz), "v"(klane));
-            const unsigned row = (unsigned)min(row0 + (int)(lane / KCH), last);
-            dma_piece(kb, row * (DK * 2) + (off % (DK * 2)), dst);
-        }
-    };
-    const unsigned vlane = (unsigned)((size_t)(lane >> 2) * a.ldvt * 2u) + (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
-    const int dvc0 = chunk * DVC;                          // the workgroup stages the WHOLE chunk's Vt tile
-    auto dma_v_piece = [&](int tile, int buf, int j) __attribute__((always_inline)) {
-        const char *vb = reinterpret_cast<const char *>(a.Vt + kv_begin + tile * kKvTile);
-        dma_piece(vb + (size_t)(dvc0 + (wave * VPW + j) * 16) * a.ldvt * 2u, vlane,
-                  lds_base + (unsigned)(2 * KTILE * 2 + buf * VTILE * 2 + (wave * VPW + j) * 1024));
-    };
-    // at most KEEP of this wave's DMA pieces are still in flight (they retire in issue order), then meet the
-    // other waves: everything older is in LDS for everybody
-    auto stage_fence = [&](auto keep) __attribute__((always_inline)) {
-        constexpr int KEEP = decltype(keep)::value;
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
-        if constexpr (!(SDPA_TANDEM_ABL & 8)) __syncthreads();
-        if constexpr (SDPA_TANDEM_BLOCKSPLIT) {
-            // never taken (m > 0): it only ends the basic block behind the barrier.  Without it hipcc's live-range split keeps
-            // ONE accumulator tile in architectural VGPRs across the loop's back edge -- 16 v_accvgpr_write + 16 v_accvgpr_read
-            // and a full MFMA drain in front of the reads, every two steps; with it the loop has none (676 -> 656
-            // instructions per two steps, +1.0 % measured: profiles/r05/bf16_tandem_blocksplit_ab.log).  Found by accident:
-            // the wave-skew experiment's branches had this side effect.
-            if (__builtin_expect(__builtin_amdgcn_readfirstlane(a.m) < 0, 0)) asm volatile("s_nop 0");
-        }
-        if constexpr (SDPA_TANDEM_SKEW > 0) {
-            if (wave & 1) {
-#pragma unroll
-                for (int i = 0; i < SDPA_TANDEM_SKEW; ++i) asm volatile("s_nop 15");
-            }
-            if (wave & 2) {
-#pragma unroll
-                for (int i = 0; i < 2 * SDPA_TANDEM_SKEW; ++i) asm volatile("s_nop 15");
-            }
-        }
-    };
-
-    // K fragment byte addresses inside a K buffer (chunk 2ks+hi of row li, un-swizzled); the buffer being
-    // read alternates, its byte offset lives IN kaddr[] (flipped in place once per step)
-    constexpr int NKA = NKS < 8 ? NKS : 8;
-    unsigned kaddr[NKA];
-#pragma unroll
-    for (int u = 0; u < NKA; ++u) kaddr[u] = (unsigned)(li * DK * 2 + (((2 * u + hi) ^ (li & SWZ)) << 4));
-    auto kfrag = [&](int ks) __attribute__((always_inline)) -> u32x4 {
-        if constexpr (SDPA_TANDEM_ABL & 2) return qf[(ks + 1) % NKS];
-        return *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(Ks) +
-                                                kaddr[ks % NKA] + (ks / NKA) * 256);
-    };
-    // Vt fragment f = (key half h = f / 8, column block tt = f % 8 of THIS wave's 256 columns):
-    // keys 16h + {4hi..+3, 8+4hi..+3} of dv row 256 role + 32 tt + li
-    unsigned vaddr[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-        vaddr[h] = (unsigned)(role * 8 * 2048 + li * 64 + (((2 * h + hi) ^ ((li >> 2) & 3)) << 4));
-    auto vfrag = [&](int buf, int f) __attribute__((always_inline)) -> u32x4 {
-        const int h = f / NTW, tt = f % NTW;
-        if constexpr (SDPA_TANDEM_ABL & 2) return qf[(f + 3) % NKS];
-        return *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(Vs + buf * VTILE) +
-                                                vaddr[h] + tt * 2048);
-    };
-    // the P exchange: this wave's P tile of key half h in buffer b, lane-linear 16-byte entries
-    const unsigned pmine = (unsigned)(wave * 2048 + lane * 16), ptheirs = (unsigned)((wave ^ 1) * 2048 + lane * 16);
-    auto p_store = [&](int b, const u32x4 (&pv)[2]) __attribute__((always_inline)) {
-        if constexpr (SDPA_TANDEM_ABL & 16) return;
-        *reinterpret_cast<u32x4 *>(Ps + b * 8192 + pmine) = pv[0];
-        *reinterpret_cast<u32x4 *>(Ps + b * 8192 + pmine + 1024) = pv[1];
-    };
-    auto p_load = [&](int b, u32x4 (&pv)[2]) __attribute__((always_inline)) {
-        if constexpr (SDPA_TANDEM_ABL & 16) {
-            pv[0] = qf[1];
-            pv[1] = qf[2];
-            return;
-        }
-        pv[0] = *reinterpret_cast<const u32x4 *>(Ps + b * 8192 + ptheirs);
-        pv[1] = *reinterpret_cast<const u32x4 *>(Ps + b * 8192 + ptheirs + 1024);
-    };
-    auto mask_ragged = [&](f32x16 &sx, int tile) __attribute__((always_inline)) {
-        const int valid = kv_end - (kv_begin + tile * kKvTile);
-        if (valid < kKvTile) {
-            mfma_result_fence(sx);
-            const int vh = valid - 4 * hi;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (crow16(r, 0) >= vh) sx[r] = -INFINITY;
-        }
-    };
-    // One step t, two barriers:
-    //   [A] S^T(t+1) = K(t+1).Q^T, the dependent chain, beside it its fragment reads and the DMA issue of K(t+2)
-    //   fence vmcnt(KPW): Vt(t) has landed (K(t+2) may fly); barrier: so has everybody's, and the partner's P(t)
-    //   [B] O^T += Vt(t).P(t)^T for the own and the partner's rows, 32 independent MFMAs  ||  softmax of
-    //       tile t+1 -> P(t+1), stored for the partner  ||  DMA issue of Vt(t+1)
-    //   fence vmcnt(VPW): K(t+2) has landed (Vt(t+1) may fly); barrier: the next chain may read it
-    // (a first version issued all 16 DMA pieces of a step under [B], with one barrier: 11 % SLOWER than the wide
-    //  kernel -- a DMA piece costs its issue slot wherever it sits, and 16 of them do not fit [B]'s shadow; with
-    //  the wide kernel's 8 + 8 distribution this kernel is 1.5-2 % faster than the wide one, and insensitive to
-    //  fragment ring depths and MFMA grouping: profiles/r03/bf16_tandem_ab.log)
-    f32x16 sx;
-    auto p_elem = [&](int r, u32x4 (&pout)[2]) __attribute__((always_inline)) {
-        if constexpr (SDPA_TANDEM_ABL & 1) {
-            if (r < 8) pout[r / 4][r % 4] = __builtin_bit_cast(unsigned, sx[r]);      // (the score registers as they are)
-            return;
-        }
-        asm volatile("v_exp_f32 %0, %0" : "+v"(sx[r]));
-        if (r >= 1) {
-            asm volatile("v_add_f32 %0, %0, %1" : "+v"(l_run) : "v"(sx[r - 1]));
-            if (((r - 1) & 1) == 1) pout[((r - 1) >> 1) / 4][((r - 1) >> 1) % 4] = bpin_pack(sx[r - 2], sx[r - 1]);
-        }
-    };
-    auto p_close = [&](u32x4 (&pout)[2]) __attribute__((always_inline)) {
-        if constexpr (SDPA_TANDEM_ABL & 1) return;
-        asm volatile("v_add_f32 %0, %0, %1" : "+v"(l_run) : "v"(sx[15]));
-        pout[1][3] = bpin_pack(sx[14], sx[15]);
-    };
-    // `parity` = t & 1 as a compile-time value (the loop below runs two steps per trip): buffer indices and
-    // the direction of the K address flip are immediates
-    auto step = [&](auto has_next, auto fenced, auto parity, const u32x4 (&pb)[2], u32x4 (&pn)[2], int t, auto phase) __attribute__((always_inline)) {
-        constexpr int PH = decltype(phase)::value;          // this wave's DMA gap inside every group of four MFMAs
-        if constexpr (SDPA_TANDEM_PIN >= 2) pin_o();
-        constexpr bool HAS_NEXT = decltype(has_next)::value;
-        constexpr bool FENCED = decltype(fenced)::value;
-        constexpr int vbuf = decltype(parity)::value;
-        const int tk = min(t + 2, T - 1);                  // past the end: a harmless reload into a free buffer
-        constexpr bool WHOLE = !FENCED && RPP == 1 && KPW == 8 && SDPA_TANDEM_KIMM;   // (steady state: t + 2 <= T - 2)
-        if constexpr (HAS_NEXT) {
-            // [A]
-            constexpr int KD = NKS < SDPA_TANDEM_KD ? NKS : SDPA_TANDEM_KD;
-            u32x4 kq[KD];
-#pragma unroll
-            for (int i = 0; i < KD; ++i) kq[i] = kfrag(i);
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                const u32x4 kf = kq[ks % KD];
-                __builtin_amdgcn_sched_barrier(0);
-                if (ks == 0) mfma_bf16_vgpr_first(sx, kf, qf[0]);
-                else mfma_bf16_vgpr(sx, kf, qf[ks]);
-                if (ks + KD < NKS) kq[ks % KD] = kfrag(ks + KD);
-                if constexpr (!(SDPA_TANDEM_ABL & 4)) {
-                    if (ks % 4 == PH) {                              // K(t+2) into the buffer K(t) left (NKS / KPW == 4)
-                        if constexpr (WHOLE) dma_k_piece_whole(t + 2, vbuf, ks / 4);
-                        else dma_k_piece(tk, vbuf, ks / 4);
-                    }
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (FENCED) mfma_result_fence(sx);
-            stage_fence(std::integral_constant<int, KPW>());          // Vt(t) has landed; K(t+2) may still fly
-        } else {
-            stage_fence(std::integral_constant<int, 0>());
-        }
-
-        // [B]
-        u32x4 pp[2];                                       // the partner's P(t)
-        p_load(vbuf, pp);
-        if constexpr (HAS_NEXT && (FENCED || SDPA_BF16_MASK_EVERY_STEP)) mask_ragged(sx, t + 1);    // (only a fenced step scores the last tile)
-        constexpr int FRAGS = 2 * NTW;                     // Vt fragments of this step, two MFMAs each
-        constexpr int VD = SDPA_TANDEM_VD;                 // fragment prefetch depth (>= GROUP)
-        constexpr int GRP = SDPA_TANDEM_GROUP;             // MFMA order: GRP own, then the same GRP fragments for the partner
-        const unsigned kflip = (unsigned)(KTILE * 2);      // next step reads the other K buffer
-        u32x4 vq[VD];
-#pragma unroll
-        for (int i = 0; i < VD; ++i) vq[i] = vfrag(vbuf, i);
-        // the first partner MFMA sits GRP MFMAs behind the read of the partner's P; per accumulator the key
-        // halves come in the wide kernel's order
-#pragma unroll
-        for (int slot = 0; slot < 2 * FRAGS; ++slot) {
-            const int g = slot / (2 * GRP), q = slot % (2 * GRP);
-            const int f = GRP * g + (q % GRP);             // fragment of this MFMA
-            const bool partner = q >= GRP;
-            const int tt = f % NTW, h = f / NTW;
-            const u32x4 vf = vq[f % VD];
-            __builtin_amdgcn_sched_barrier(0);
-            if (!partner)
-                oown[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
-                                                                   __builtin_bit_cast(bf16x8, pb[h]), oown[tt], 0, 0, 0);
-            else
-                opar[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
-                                                                   __builtin_bit_cast(bf16x8, pp[h]), opar[tt], 0, 0, 0);
-            // fragment f is dead behind its partner MFMA: refill its ring slot
-            if (partner && f + VD < FRAGS) vq[f % VD] = vfrag(vbuf, f + VD);
-            if constexpr (HAS_NEXT) {
-                if constexpr (!(SDPA_TANDEM_ABL & 4))
-                    if (slot % 4 == (SDPA_TANDEM_VSHIFT + PH) % 4) dma_v_piece(t + 1, vbuf ^ 1, slot / 4);   // VPW == 8 pieces over 32 slots
-                // first read of the score tile: >= 11 issue slots behind the chain's last link
-                if (slot >= 12 && slot < 28) p_elem(slot - 12, pn);
-                if (slot == 28) p_close(pn);
-                if (slot == 29) p_store(vbuf ^ 1, pn);     // P(t+1) for the partner, visible behind the next barrier
-                if (slot >= 20 && slot < 20 + NKA) kaddr[slot - 20] = vbuf ? kaddr[slot - 20] + kflip : kaddr[slot - 20] - kflip;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // second barrier of the step: K(t+2) has landed for everybody before anyone's next score chain reads it
-        // (Vt(t+1), issued under the MFMAs above, may still fly)
-        if constexpr (HAS_NEXT) stage_fence(std::integral_constant<int, VPW>());
-    };
-
-    if (T > 0) {
-#pragma unroll
-        for (int j = 0; j < KPW; ++j) dma_k_piece(0, 0, j);
-#pragma unroll
-        for (int j = 0; j < VPW; ++j) dma_v_piece(0, 0, j);
-#pragma unroll
-        for (int j = 0; j < KPW; ++j) dma_k_piece(min(1, T - 1), 1, j);
-        stage_fence(std::integral_constant<int, 0>());
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            const u32x4 kf = kfrag(ks);
-            if (ks == 0) mfma_bf16_vgpr_first(sx, kf, qf[0]);
-            else mfma_bf16_vgpr(sx, kf, qf[ks]);
-        }
-        mfma_result_fence(sx);
-        mask_ragged(sx, 0);
-        // P(0)
-        u32x4 pA[2], pB[2];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) p_elem(r, pA);
-        p_close(pA);
-        p_store(0, pA);
-        __syncthreads();                                // K(0) fully consumed before K(2) lands on it
-#pragma unroll
-        for (int u = 0; u < NKA; ++u) kaddr[u] += (unsigned)(KTILE * 2);   // step 0 reads K(1) in buffer 1
-
-        int t = 0;
-        using even = std::integral_constant<int, 0>;
-        using odd = std::integral_constant<int, 1>;
-        // Only the shard's LAST tile can be ragged, so only the step that scores it masks: the steady-state loop
-        // stops two tiles short of the end and the tail below runs the masking instantiation.  (Round 4: with the
-        // mask in every step hipcc turned its wave-uniform branch into ~45 selects per step, a third of the loop's
-        // VALU work, next to MFMAs that do not overlap with VALU issue -- profiles/r04/bf16_ragged_mask_hoist.log.)
-        // (... and three short of it, so that no steady-state step LOADS the last tile either -- K(t+2) goes out in
-        //  step t -- and the K pieces need no row clamp: dma_k_piece_whole)
-        using ph0 = std::integral_constant<int, 0>;
-        auto steady = [&](auto phase) __attribute__((always_inline)) {
-            if constexpr (SDPA_TANDEM_PIN) pin_o();      // (every copy of the loop starts from the accumulators IN the accumulator file)
-            for (; t + 4 < T; t += 2) {
-                step(std::true_type(), std::false_type(), even(), pA, pB, t, phase);
-                step(std::true_type(), std::false_type(), odd(), pB, pA, t + 1, phase);
-            }
-        };
-        if constexpr (SDPA_TANDEM_STAGGER && NKS / KPW == 4) {
-            constexpr int S = SDPA_TANDEM_STAGGER == 1 ? 1 : 0;      // (== 2: four copies of the SAME loop, to tell the copies' cost from the phases')
-            switch (wave) {
-                case 0: asm volatile("; copy 0"); steady(ph0()); break;
-                case 1: asm volatile("; copy 1"); steady(std::integral_constant<int, 1 * S>()); asm volatile("s_nop 1"); break;
-                case 2: asm volatile("; copy 2"); steady(std::integral_constant<int, 2 * S>()); asm volatile("s_nop 2"); break;
-                default: asm volatile("; copy 3"); steady(std::integral_constant<int, 3 * S>()); asm volatile("s_nop 3"); break;
-            }
-        } else {
-            steady(ph0());
-        }
-        if (T - t >= 3) {                                   // 3 or 4 steps left: two fenced ones, then the cases below
-            step(std::true_type(), std::true_type(), even(), pA, pB, t, ph0());
-            step(std::true_type(), std::true_type(), odd(), pB, pA, t + 1, ph0());
-            t += 2;
-        }
-        if (T - t == 2) {
-            step(std::true_type(), std::true_type(), even(), pA, pB, t, ph0());
-            step(std::false_type(), std::true_type(), odd(), pB, pA, t + 1, ph0());
-        } else {
-            step(std::false_type(), std::true_type(), even(), pA, pB, t, ph0());
-        }
-    }
-    // range test and fold exponent of this wave's OWN rows (as the wide kernel), then both go to the
-    // partner, which holds the other 256 columns of these rows
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const bool ok = l_tot >= 0x1p-80f && l_tot <= 0x1p80f;
-    if (T > 0 && __any(!ok) && lane == 0) a.redo[split * n_qblocks + qblock] = a.redo_gen;
-    const int fold_exp = ok ? __builtin_amdgcn_frexp_expf(l_tot) - 1 : 0;
-    __syncthreads();                                    // every wave is done with the P area
-    int *fx = reinterpret_cast<int *>(Ps);
-    if (hi == 0) fx[wave * 32 + li] = fold_exp;
-    __syncthreads();
-    const int fold_par = fx[(wave ^ 1) * 32 + li];
-
-    float *out = a.contrib;
-    float *omax = a.lmax, *osum = a.lsum;
-    int ldo = a.ldo;
-    if (a.kv_splits > 1) {
-        ldo = a.ws_ld;
-        out = a.ws_contrib + (size_t)split * a.ws_rows * ldo;
-        omax = a.ws_lmax + (size_t)split * a.ws_rows;
-        osum = a.ws_lsum + (size_t)split * a.ws_rows;
-    }
-    if (qrow < a.m) {
-        float *orow = out + (size_t)qrow * ldo + dv0;
-#pragma unroll
-        for (int tt = 0; tt < NTW; ++tt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int col = 32 * tt + crow16(r, hi);
-                if (dv0 + col < a.dv) orow[col] = __builtin_amdgcn_ldexpf(oown[tt][r], -fold_exp);
-            }
-        if (hi == 0 && chunk == 0) {
-            omax[qrow] = T > 0 ? (float)fold_exp * 0.69314718055994530942f : -INFINITY;
-            osum[qrow] = __builtin_amdgcn_ldexpf(l_tot, -fold_exp);
-        }
-    }
-    if (prow < a.m) {
-        float *orow = out + (size_t)prow * ldo + dv0;
-#pragma unroll
-        for (int tt = 0; tt < NTW; ++tt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int col = 32 * tt + crow16(r, hi);
-                if (dv0 + col < a.dv) orow[col] = __builtin_amdgcn_ldexpf(opar[tt][r], -fold_par);
-            }
-    }
-}
+#define SDPA_TD_STREAM 0
+#include "sdpa_fwd_bf16_tandem.inc"
+#undef SDPA_TD_STREAM
+#define SDPA_TD_STREAM 1
+#include "sdpa_fwd_bf16_tandem.inc"
+#undef SDPA_TD_STREAM
 
 // ---------------------------------------------------------------------------
 // Duo variant (dk, dv <= 256): one wave per SIMD, TWO 32-row query blocks per wave.
@@ -2118,6 +1655,30 @@ static hipError_t launch_bf16_tandem(const Bf16Args &a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// the persistent form (fused_bf16_tandem_stream_kernel): the same grid, the same arguments + where its ready words live
+template <int DK>
+static hipError_t launch_bf16_tandem_streamed(const Bf16Args &a, const StreamArgs &st, hipStream_t s) {
+    const int nqb = (a.m + kQRowsPerBlock - 1) / kQRowsPerBlock;
+    const int chunks = bf16_pad_dv(a.dv) / 512;
+    const int ntiles = (a.n_local + kKvTile - 1) / kKvTile;
+    const int tiles_per_split = (ntiles + a.kv_splits - 1) / a.kv_splits;
+    const int kv_per_split = tiles_per_split > 0 ? tiles_per_split * kKvTile : kKvTile;
+    const size_t lds = ((size_t)2 * kKvTile * DK + (size_t)2 * 512 * kKvTile) * sizeof(unsigned short) + 16384;
+    static std::atomic<bool> attr_done[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_bf16_tandem_stream_kernel<DK>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done[dev] = true;
+    }
+    hipLaunchKernelGGL((fused_bf16_tandem_stream_kernel<DK>), dim3(nqb * chunks * a.kv_splits), dim3(256), lds, s,
+                       a, kv_per_split, nqb, chunks, 1.0f, st);
+    note_launch("fused_bf16_tandem_stream_kernel", 1, DK, 0, 0, 0, 0, nqb * chunks * a.kv_splits, a.kv_splits, 0, a.m, a.n_local);
+    return hipGetLastError();
+}
+
 // dv > 256: the tandem kernel (two waves share 64 rows and split the columns; the default since round 3), or
 // the wide kernel it was derived from -- both exact, bit-identical to each other ($SDPA_BF16_TANDEM=0/1, A/B timing)
 static bool bf16_uses_tandem() {       // (from the launch-knob snapshot: no getenv on an enqueue thread)
@@ -2148,7 +1709,25 @@ static hipError_t launch_bf16_duo(const Bf16Args &a, hipStream_t s) {
     return hipGetLastError();
 }
 
+static hipError_t launch_shard_partial_bf16_impl(const Bf16Args &args, const StreamArgs *st, hipStream_t s);
+
 hipError_t launch_shard_partial_bf16(const Bf16Args &args, hipStream_t s) {
+    return launch_shard_partial_bf16_impl(args, nullptr, s);
+}
+
+// dims whose main kernel has a persistent form: the tandem kernel's (value columns in 512-wide chunks, i.e. dv > 256)
+bool bf16_stream_launch_supported(int dk, int dv) {
+    return dk >= 1 && dk <= 512 && bf16_chunk_dv(dv) == 512 && bf16_uses_tandem();
+}
+
+hipError_t launch_shard_partial_bf16_streamed(const Bf16Args &a, const StreamArgs &st, hipStream_t s) {
+    if (!bf16_stream_launch_supported(a.dk, a.dv) || !st.flags || !st.status || st.n_chunks < 1 ||
+        st.n_chunks > kStreamMaxChunks || a.n_local <= 0)
+        return hipErrorInvalidValue;
+    return launch_shard_partial_bf16_impl(a, &st, s);
+}
+
+static hipError_t launch_shard_partial_bf16_impl(const Bf16Args &args, const StreamArgs *st, hipStream_t s) {
     static std::atomic<int> generation{0x5d9a0000};
     Bf16Args a = args;
     if (a.ws_rows <= 0) a.ws_rows = a.m;
@@ -2189,7 +1768,14 @@ hipError_t launch_shard_partial_bf16(const Bf16Args &args, hipStream_t s) {
             }
         } else
 #endif
-        if (bf16_uses_tandem()) {
+        if (st) {                                            // (bf16_stream_launch_supported: the tandem kernel is in use)
+            switch (kp) {
+                case 64: e = launch_bf16_tandem_streamed<64>(a, *st, s); break;
+                case 128: e = launch_bf16_tandem_streamed<128>(a, *st, s); break;
+                case 256: e = launch_bf16_tandem_streamed<256>(a, *st, s); break;
+                default: e = launch_bf16_tandem_streamed<512>(a, *st, s); break;
+            }
+        } else if (bf16_uses_tandem()) {
             switch (kp) {
                 case 64: e = launch_bf16_tandem<64>(a, s); break;
                 case 128: e = launch_bf16_tandem<128>(a, s); break;
@@ -2297,6 +1883,13 @@ void dma_audit_read_bf16(unsigned long long out[2]) {
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bf16_audit), 2 * sizeof(unsigned long long));
 #endif
+}
+
+// (sdpa_internal.h: preload_kernels_*) touching one kernel makes the runtime load this translation unit's code object for the
+// current device NOW -- not in front of the first launch that needs it, possibly behind a resident persistent launch
+hipError_t preload_kernels_bf16() {
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&cvt_d2bf_kernel));
 }
 
 }  // namespace sdpa

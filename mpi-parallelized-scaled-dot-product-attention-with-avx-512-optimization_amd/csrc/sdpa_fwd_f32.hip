@@ -815,4 +815,11 @@ hipError_t launch_shard_partial(const PartialArgs &a_in, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
+// (sdpa_internal.h: preload_kernels_*) touching one kernel makes the runtime load this translation unit's code object for the
+// current device NOW -- not in front of the first launch that needs it, possibly behind a resident persistent launch
+hipError_t preload_kernels_f32() {
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&split_merge_kernel));
+}
+
 }  // namespace sdpa

@@ -750,4 +750,11 @@ void dma_audit_read_dksplit(unsigned long long out[2]) {
 #endif
 }
 
+// (sdpa_internal.h: preload_kernels_*) touching one kernel makes the runtime load this translation unit's code object for the
+// current device NOW -- not in front of the first launch that needs it, possibly behind a resident persistent launch
+hipError_t preload_kernels_dksplit() {
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&fused_dksplit_kernel<128, 128, 2>));
+}
+
 }  // namespace sdpa

@@ -383,6 +383,10 @@ struct Chunk {
     int splits;         // in-launch K/V splits of the full-row launch
     int slot0;          // first slot it writes
     int group = 0;      // streamed form: the ready word that announces it
+    // streamed form, bf16: the entry's columns of the Vt image travel as a PACKED block [padded dv rows][keys_pad] of the host
+    // staging, `img_off` elements into it; keys_pad = whole 32-key tiles (the shard's last entry: up to the image's row length)
+    long img_off = 0;
+    int keys_pad = 0;
 };
 
 // The streamed form of a rank's FIRST Q batch (round 5): ONE persistent launch over the whole shard
@@ -625,9 +629,21 @@ void make_plan(Plan &pl, int m, int n, int dk, int dv, int flags, int ranks = 0)
         const char *sv = getenv("SDPA_STREAMED");
         const bool stream_knob = !(sv && *sv) || atoi(sv) != 0;
         const int scmin = std::max(1024, env_int("SDPA_STREAM_CHUNK_MIN", cmin) / 1024 * 1024);
-        if (stream_knob && !pl.bf16 && !no_pipe && sdpa::stream_launch_supported(dk, dv) && rows0 > 0 &&
+        // bf16 (round 5, second half): the tandem kernel's shapes (value columns in 512-wide chunks) have a persistent form too;
+        // its K groups are row ranges of the bf16 image, its V groups COLUMN ranges of the Vt image, written by the host
+        // (sdpa_hostcvt: submit_t) and carried by pitched copies -- the copy engine's as well (profiles/r05/copy_engine_probes.log).
+        // A whole-chip launch only: the bf16 kernels have no stream-K form to size for a reservation.
+        const bool whole_chip = pl.cus >= ((ranks > 0 || E.chip_cus <= 0) ? sdpa::kChipCus : E.chip_cus);
+        const bool bf16_streamable = pl.bf16 && whole_chip && sdpa::bf16_stream_launch_supported(dk, dv);
+        if (stream_knob && (!pl.bf16 || bf16_streamable) && !no_pipe && (pl.bf16 || sdpa::stream_launch_supported(dk, dv)) && rows0 > 0 &&
             rp.key_cnt >= 2 * scmin) {
-            const sdpa::F32Plan fp = sdpa::plan_f32_launch(rows0, rp.key_cnt, dk, dv, pl.cus);
+            sdpa::F32Plan fp = {};
+            if (pl.bf16) {
+                fp.splits = sdpa::pick_kv_splits_bf16(rows0, rp.key_cnt, dk, dv);
+                fp.streamk = 0;
+            } else {
+                fp = sdpa::plan_f32_launch(rows0, rp.key_cnt, dk, dv, pl.cus);
+            }
             const long nqb = (rows0 + sdpa::kQRowsPerBlock - 1) / sdpa::kQRowsPerBlock;
             // (at most 8 splits: every group crosses PCIe as `splits` row ranges of K and of V, and below ~256 KiB a
             //  copy costs more to enqueue than to move -- few query blocks keep the launch-per-chunk schedule)
@@ -637,7 +653,9 @@ void make_plan(Plan &pl, int m, int n, int dk, int dv, int flags, int ranks = 0)
                 sp.splits = fp.splits;
                 const int ntiles = (rp.key_cnt + sdpa::kKvTile - 1) / sdpa::kKvTile;
                 sp.tiles_per_split = (ntiles + sp.splits - 1) / sp.splits;
-                const std::vector<int> gsz = chunk_sizes(rp.key_cnt, scmin, std::max(scmin, cmax));
+                // (at most kStreamMaxChunks groups: a long shard with a small largest chunk -- feed bound plans -- gets larger ones)
+                const int gmax = std::max(std::max(scmin, cmax), (int)(((long)rp.key_cnt / 12 + 1023) / 1024 * 1024));
+                const std::vector<int> gsz = chunk_sizes(rp.key_cnt, scmin, gmax);
                 // A group crosses PCIe as one row range per split and operand, and a copy costs ~10 us whatever its size:
                 // below ~2048 keys of a split per group (1 MiB at d = 128) the copies, not the link, set the pace (config 2
                 // with 2 groups x 8 splits: 32 copies of 256 KiB, 1.02-1.05 ms against 0.99 chunked -- profiles/r05/
@@ -673,8 +691,19 @@ void make_plan(Plan &pl, int m, int n, int dk, int dv, int flags, int ranks = 0)
                             e.k0 = (int)k0; e.keys = (int)(k1 - k0); e.splits = sp.splits; e.slot0 = -1; e.group = (int)gi;
                             sp.entries.push_back(e);
                         }
+                    if (pl.bf16) {
+                        const long ldn = sdpa::bf16_pad_n(rp.key_cnt), rows_img = sdpa::bf16_pad_dv(dv);
+                        long off = 0;
+                        for (Chunk &e : sp.entries) {
+                            const bool last = e.k0 + e.keys == rp.key_cnt;
+                            e.keys_pad = (int)(last ? ldn - e.k0 : (e.keys + 31) / 32 * 32);
+                            e.img_off = off;
+                            off += rows_img * e.keys_pad;
+                        }
+                    }
                     sp.on = true;
-                    rp.ws_bytes = std::max(rp.ws_bytes, sdpa::workspace_bytes_for(rows0, dv, sp.splits));
+                    if (!pl.bf16) rp.ws_bytes = std::max(rp.ws_bytes, sdpa::workspace_bytes_for(rows0, dv, sp.splits));
+                    // (bf16: the launch's own scratch -- launch_ws_bytes(rows0, key_cnt) above -- holds its splits and redo flags)
                 }
             }
         }
@@ -833,6 +862,7 @@ struct HostImages {
     sdpa::HostConverter *cv = nullptr;
     char *k = nullptr, *v = nullptr, *q = nullptr;
     int ldv_host = 0;                                      // row stride of the host V image (bf16: dense dv)
+    std::vector<size_t> v_rank_off;                        // bf16, streamed: byte offset of rank g's packed Vt image in `v`
     std::vector<char> streamed;                            // [rank]: chunk indices below name rp.stream.entries, not rp.chunks
     std::vector<std::vector<int>> k_task, v_task;          // [rank][chunk]
     std::vector<std::vector<std::vector<int>>> q_task;     // [rank][batch][row piece]
@@ -862,6 +892,16 @@ int stage_half(const Plan &pl, Rank &rk, const RankPlan &rp, const double *src, 
             if (bare) return SDPA_OK;
             HIP_TRY(hipEventRecord(copied, rk.s_cp));
             HIP_TRY(hipStreamWaitEvent(rk.s_in, copied, 0));
+            return SDPA_OK;
+        }
+        if (bare) {
+            // streamed: the host wrote the entry's columns of the Vt image (packed: keys_pad elements a row); a pitched copy puts
+            // them in place -- the copy engine's, like the linear ones (tools/probes/h2d_2d_probe.hip)
+            const long ldn = sdpa::bf16_pad_n(rp.key_cnt);
+            const unsigned short *img = (const unsigned short *)(HI.v + HI.v_rank_off[g]) + ch.img_off;
+            HIP_TRY(hipMemcpy2DAsync((unsigned short *)rk.vf.p + ch.k0, (size_t)ldn * sizeof(unsigned short), img,
+                                     (size_t)ch.keys_pad * sizeof(unsigned short), (size_t)ch.keys_pad * sizeof(unsigned short),
+                                     (size_t)sdpa::bf16_pad_dv(pl.dv), hipMemcpyHostToDevice, rk.s_cp));
             return SDPA_OK;
         }
         // bf16 V: the rows travel as dense bf16, the device transposes them into the Vt image
@@ -1245,7 +1285,21 @@ int rank_batch0_streamed(Call &c, int g) {
         return SDPA_OK;
     };
     SDPA_TRY(bracket());
-    HIP_TRY(sdpa::launch_shard_partial_streamed(a, st, rk.s_run));
+    if (pl.bf16) {
+        Bf16Args b = {};
+        b.Q = (const unsigned short *)rk.qf[s].p;  b.ldq = pl.ldq;
+        b.K = (const unsigned short *)rk.kf.p;     b.ldk = pl.ldk;
+        b.Vt = (const unsigned short *)rk.vf.p;    b.ldvt = sdpa::bf16_pad_n(rp.key_cnt);
+        b.m = bs; b.n_local = rp.key_cnt; b.dk = pl.dk; b.dv = pl.dv;
+        b.kv_splits = sp.splits;
+        b.contrib = (float *)rk.contrib[s].p; b.ldo = pl.ldo;
+        b.lmax = (float *)rk.stat[s].p;
+        b.lsum = (float *)rk.stat[s].p + bs;
+        sdpa::bf16_carve_workspace(b, rk.ws.p, pl.ldo);
+        HIP_TRY(sdpa::launch_shard_partial_bf16_streamed(b, st, rk.s_run));
+    } else {
+        HIP_TRY(sdpa::launch_shard_partial_streamed(a, st, rk.s_run));
+    }
     SDPA_TRY(bracket());
     if (c.first_kernel_us[g] == 0.0) c.first_kernel_us[g] = now_us() - c.t_enter;
     if (g == 0) {
@@ -1757,6 +1811,12 @@ void destroy_rank(Rank &g) {
 int create_rank(Rank &g, int dev, int reserve) {
     g.dev = dev;
     HIP_TRY(hipSetDevice(dev));
+    // every kernel's code object on this device now (sdpa_internal.h: preload_kernels_*)
+    HIP_TRY(sdpa::preload_kernels_f32());
+    HIP_TRY(sdpa::preload_kernels_dksplit());
+    HIP_TRY(sdpa::preload_kernels_bf16());
+    HIP_TRY(sdpa::preload_kernels_aux());
+    HIP_TRY(sdpa::preload_kernels_coll());
     // converts go first when a fused launch retires: they feed the next one
     int lo = 0, hi = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -2013,14 +2073,28 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
         const int ldv_h = pl.bf16 ? dv : pl.ldv;
         const size_t vel = pl.bf16 ? sizeof(unsigned short) : sizeof(float);
         char *hk = (char *)E.hc->staging(0, (size_t)n * pl.ldk * kel);
-        char *hv = (char *)E.hc->staging(1, (size_t)n * ldv_h * vel);
+        // bf16, first batch streamed: the staging holds the Vt IMAGES themselves (padded dv rows x padded keys per rank, packed
+        // entry by entry: Chunk::img_off), not dense rows -- all ranks or none (a call never mixes the two V stagings)
+        bool bf16_images = pl.bf16;
+        for (int g = 0; g < P && bf16_images; ++g) bf16_images = pl.r[g].stream.on;
+        size_t hv_bytes = (size_t)n * ldv_h * vel;
+        std::vector<size_t> hv_rank_off(P, 0);
+        if (bf16_images) {
+            hv_bytes = 0;
+            for (int g = 0; g < P; ++g) {
+                hv_rank_off[g] = hv_bytes;
+                hv_bytes += (size_t)sdpa::bf16_pad_dv(dv) * sdpa::bf16_pad_n(pl.r[g].key_cnt) * sizeof(unsigned short);
+            }
+        }
+        char *hv = (char *)E.hc->staging(1, hv_bytes);
         char *hq = (char *)E.hc->staging(2, (size_t)m * pl.ldq * qel);
         if (hk && hv && hq) {
             c.hostcvt = true;
             c.progressive = false;
             HI.streamed.assign(P, 0);
             for (int g = 0; g < P; ++g)
-                if (pl.r[g].stream.on) HI.streamed[g] = 1, c.streamed = true;
+                if (pl.r[g].stream.on && (!pl.bf16 || bf16_images)) HI.streamed[g] = 1, c.streamed = true;
+            HI.v_rank_off = hv_rank_off;
             if (c.streamed) {
                 if (++E.stream_gen == 0) ++E.stream_gen;
                 c.stream_gen = E.stream_gen;
@@ -2046,8 +2120,12 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
                 const size_t row0 = (size_t)rp.key_off + cc.k0;
                 HI.k_task[g].push_back(E.hc->submit(K + row0 * dk, hk + row0 * pl.ldk * kel, cc.keys, dk,
                                                      pl.ldk, kind, 1.0));
-                HI.v_task[g].push_back(E.hc->submit(V + row0 * dv, hv + row0 * ldv_h * vel, cc.keys, dv,
-                                                     ldv_h, kind, 1.0));
+                if (pl.bf16 && HI.streamed[g])        // the entry's columns of the Vt image, as a packed block of the staging
+                    HI.v_task[g].push_back(E.hc->submit_t(V + row0 * dv, (unsigned short *)(hv + hv_rank_off[g]) + cc.img_off, cc.keys,
+                                                           cc.keys_pad, dv, sdpa::bf16_pad_dv(dv), cc.keys_pad));
+                else
+                    HI.v_task[g].push_back(E.hc->submit(V + row0 * dv, hv + row0 * ldv_h * vel, cc.keys, dv,
+                                                         ldv_h, kind, 1.0));
             };
             auto submit_q = [&](int g, int b) {
                 const RankPlan &rp = pl.r[g];

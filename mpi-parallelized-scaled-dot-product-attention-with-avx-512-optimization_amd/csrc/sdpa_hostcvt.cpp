@@ -175,6 +175,10 @@ bool have_avx512() {
     return yes;
 }
 
+__attribute__((target("avx512f"))) inline void stream_line_64(void *dst, const void *src) {
+    _mm512_stream_si512((__m512i *)dst, _mm512_load_si512((const __m512i *)src));
+}
+
 inline void rows_to_f32(const double *src, float *dst, long rows, int cols, int ld, bool nt) {
     if (!have_avx512()) rows_to_f32_scalar(src, dst, rows, cols, ld);
     else if (nt) rows_to_f32_avx512_nt(src, dst, rows, cols, ld);
@@ -185,6 +189,109 @@ inline void rows_to_bf16(const double *src, unsigned short *dst, long rows, int 
     if (!have_avx512()) rows_to_bf16_scalar(src, dst, rows, cols, ld, mult);
     else if (nt) rows_to_bf16_avx512_nt(src, dst, rows, cols, ld, mult);
     else rows_to_bf16_avx512(src, dst, rows, cols, ld, mult);
+}
+
+// The Vt image of the bf16 kernels, made on the host (round 5: what a persistent bf16 launch is fed with -- a device transpose
+// kernel could not run beside it).  `keys` rows of V (fp64, `cols` columns) starting at row r0 of an entry, r0 a multiple of 32,
+// become columns of the entry's image: dst[c * ldt + r0 + kvpos(j)] = bf16((float)V[r0 + j][c]) for the keys of each 32-key tile,
+// zero for tile positions behind the entry's last key (`keys` may end inside a tile: the caller passes whole tiles up to the
+// padded key count), zero rows for c in [cols, cols_pad).  kvpos swaps bits 2 and 3 of the key's index (sdpa_internal.h:
+// bf16_kvpos -- each 16-key group is stored 0-3, 8-11, 4-7, 12-15).  The same two roundings as everywhere (RNE, RNE): bit for bit
+// cvt_d2bf_t_kernel's image.  Per tile: the rows through the row converter into a 32 x cols scratch (L1 / L2), then 32 x 32
+// blocks of it transposed into whole 64-byte lines of the image (streaming stores when the line is aligned).
+inline int kvpos32(int j) { return (j & ~12) | ((j & 4) << 1) | ((j & 8) >> 1); }
+
+// 32 x 32 block of 16-bit values, transposed in registers: out line c (64 bytes at out + c * ldt) = in[kvpos(p)][c], p = 0..31.
+// Three unpack stages (16, 32, 64 bits: rows pair up, then fours, then eights) leave, per 128-bit lane, eight rows of one column;
+// a 4 x 4 transpose of lanes puts a column's 32 rows into one register.  `nc` columns are stored (the scratch's pad columns are
+// transposed too, and dropped).
+__attribute__((target("avx512f,avx512bw,avx512vl")))
+void transpose_block_32x32(const unsigned short *in, int ldin, unsigned short *out, long ldt, int nc, bool nt) {
+    __m512i r[32], a[32];
+    for (int p = 0; p < 32; ++p) r[p] = _mm512_loadu_si512((const void *)(in + (size_t)kvpos32(p) * ldin));
+    for (int i = 0; i < 16; ++i) {
+        a[2 * i] = _mm512_unpacklo_epi16(r[2 * i], r[2 * i + 1]);
+        a[2 * i + 1] = _mm512_unpackhi_epi16(r[2 * i], r[2 * i + 1]);
+    }
+    for (int j = 0; j < 8; ++j) {
+        r[4 * j] = _mm512_unpacklo_epi32(a[4 * j], a[4 * j + 2]);
+        r[4 * j + 1] = _mm512_unpackhi_epi32(a[4 * j], a[4 * j + 2]);
+        r[4 * j + 2] = _mm512_unpacklo_epi32(a[4 * j + 1], a[4 * j + 3]);
+        r[4 * j + 3] = _mm512_unpackhi_epi32(a[4 * j + 1], a[4 * j + 3]);
+    }
+    for (int m = 0; m < 4; ++m)
+        for (int q = 0; q < 4; ++q) {
+            a[8 * m + 2 * q] = _mm512_unpacklo_epi64(r[8 * m + q], r[8 * m + 4 + q]);
+            a[8 * m + 2 * q + 1] = _mm512_unpackhi_epi64(r[8 * m + q], r[8 * m + 4 + q]);
+        }
+    // a[8m + k], lane l = rows 8m .. 8m+7 of column 8l + k
+    const bool aligned = nt && (((uintptr_t)out | (uintptr_t)(ldt * 2)) & 63u) == 0;
+    for (int k = 0; k < 8; ++k) {
+        const __m512i t0 = _mm512_shuffle_i32x4(a[k], a[8 + k], 0x44), t1 = _mm512_shuffle_i32x4(a[k], a[8 + k], 0xEE);
+        const __m512i t2 = _mm512_shuffle_i32x4(a[16 + k], a[24 + k], 0x44), t3 = _mm512_shuffle_i32x4(a[16 + k], a[24 + k], 0xEE);
+        const __m512i y[4] = {_mm512_shuffle_i32x4(t0, t2, 0x88), _mm512_shuffle_i32x4(t0, t2, 0xDD),
+                              _mm512_shuffle_i32x4(t1, t3, 0x88), _mm512_shuffle_i32x4(t1, t3, 0xDD)};
+        for (int l = 0; l < 4; ++l) {
+            const int c = 8 * l + k;
+            if (c >= nc) continue;
+            if (aligned) _mm512_stream_si512((__m512i *)(out + (size_t)c * ldt), y[l]);
+            else _mm512_storeu_si512((void *)(out + (size_t)c * ldt), y[l]);
+        }
+    }
+}
+
+void tiles_to_bf16_t(const double *src, unsigned short *dst, long keys, long tiles, int cols, int cols_pad, long ldt, bool nt,
+                     bool force_scalar = false) {
+    constexpr int TK = 32, TG = 8;             // keys per tile; tiles per group: an image row gets TG x 64 contiguous bytes at a time
+    const int ldtmp = (cols + 31) / 32 * 32;   // (one line per row and tile costs a DTLB miss and a DRAM page each: 4.9 -> x ms per 8192 keys)
+    const bool simd = !force_scalar && have_avx512();
+    // scratch of this thread: one group of rows, bf16, row-major (<= 256 x 1024 x 2 = 512 KiB), and one column block of its image
+    static thread_local std::vector<unsigned short> tmp_store;
+    const size_t need = (size_t)TG * TK * ldtmp + (size_t)32 * TG * TK + 128;
+    if (tmp_store.size() < need) tmp_store.resize(need);
+    unsigned short *tmp = (unsigned short *)(((uintptr_t)tmp_store.data() + 63) & ~(uintptr_t)63);
+    unsigned short *obuf = tmp + (size_t)TG * TK * ldtmp;               // [32 columns][TG tiles][32 positions], 64-byte aligned
+    for (long t0 = 0; t0 < tiles; t0 += TG) {
+        const int tg = (int)(tiles - t0 < TG ? tiles - t0 : TG);
+        const long r0 = t0 * TK, span = (long)tg * TK;
+        const long nr = keys - r0 < span ? (keys - r0 > 0 ? keys - r0 : 0) : span;
+        if (nr > 0) {
+            if (simd) rows_to_bf16_avx512(src + r0 * cols, tmp, nr, cols, ldtmp, 1.0);
+            else rows_to_bf16_scalar(src + r0 * cols, tmp, nr, cols, ldtmp, 1.0);
+        }
+        if (nr < span) memset(tmp + nr * ldtmp, 0, (size_t)(span - nr) * ldtmp * sizeof(unsigned short));
+        unsigned short *out = dst + r0;                       // the group's first key position of image row 0
+        const size_t run = (size_t)tg * TK;                   // elements of an image row this group fills
+        for (int c0 = 0; c0 < cols; c0 += 32) {
+            const int nc = cols - c0 < 32 ? cols - c0 : 32;
+            for (int g = 0; g < tg; ++g) {                    // tile g of the group -> obuf[c][g][0..31]
+                const unsigned short *in = tmp + (size_t)g * TK * ldtmp + c0;
+                if (simd) {
+                    transpose_block_32x32(in, ldtmp, obuf + (size_t)g * TK, (long)TG * TK, 32, false);
+                } else {
+                    for (int p = 0; p < TK; ++p) {
+                        const unsigned short *row = in + (size_t)kvpos32(p) * ldtmp;     // position p holds key kvpos(p) (an involution)
+                        for (int cc = 0; cc < 32; ++cc) obuf[((size_t)cc * TG + g) * TK + p] = row[cc];
+                    }
+                }
+            }
+            for (int cc = 0; cc < nc; ++cc) {
+                unsigned short *line = out + (size_t)(c0 + cc) * ldt;
+                const unsigned short *from = obuf + (size_t)cc * TG * TK;
+#if defined(__x86_64__)
+                if (nt && simd && ((uintptr_t)line & 63u) == 0) {
+                    for (size_t i = 0; i < run; i += 32) stream_line_64(line + i, from + i);
+                    continue;
+                }
+#endif
+                memcpy(line, from, run * sizeof(unsigned short));
+            }
+        }
+        for (int c = cols; c < cols_pad; ++c) memset(out + (size_t)c * ldt, 0, run * sizeof(unsigned short));
+    }
+#if defined(__x86_64__)
+    if (nt && simd) _mm_sfence();
+#endif
 }
 
 // fp32 -> fp64 of `n` contiguous values: the reference's cvt_f2d_avx512 (attention-mpi.c:68-101, called on the
@@ -237,6 +344,9 @@ struct Task {
     CvtKind kind;
     double mult;
     std::atomic<long> remaining;
+    // kCvtBf16T only: rows of the entry (the image holds whole 32-key tiles up to the padded count), image rows, row stride
+    long keys = 0, ldt = 0;
+    int cols_pad = 0;
     Task(const double *s, void *d, int c, int l, CvtKind k, double mu, long items)
         : src(s), dst(d), cols(c), ld(l), kind(k), mult(mu), remaining(items) {}
 };
@@ -313,6 +423,20 @@ public:
         const int id = (int)mine_->tasks.size();
         mine_->tasks.emplace_back(src, dst, cols, ld, kind, mult, n_items);
         for (long r = 0; r < rows; r += per) mine_->items.push_back({id, r, rows - r < per ? rows - r : per});
+        return id;
+    }
+    int submit_t(const double *src, unsigned short *dst, long keys, long keys_pad, int cols, int cols_pad, long ldt) override {
+        if (!mine_) mine_ = std::make_shared<Batch>();
+        // items of whole 32-key tiles, ~$SDPA_HOST_CVT_ITEM_KB of source each (at least one tile)
+        long per = (long)item_kb_ * 128 / (cols > 0 ? cols : 1);
+        per = per < 32 ? 32 : (per + 31) / 32 * 32;
+        const long total = (keys_pad + 31) / 32 * 32;
+        const long n_items = total > 0 ? (total + per - 1) / per : 0;
+        const int id = (int)mine_->tasks.size();
+        mine_->tasks.emplace_back(src, (void *)dst, cols, 0, kCvtBf16T, 1.0, n_items);
+        Task &t = mine_->tasks.back();
+        t.keys = keys; t.ldt = ldt; t.cols_pad = cols_pad;
+        for (long r = 0; r < total; r += per) mine_->items.push_back({id, r, total - r < per ? total - r : per});
         return id;
     }
     void kick() override {
@@ -416,6 +540,8 @@ private:
                 const double *s = t.src + it.row0 * t.cols;
                 if (t.kind == kCvtF32)
                     rows_to_f32(s, (float *)t.dst + it.row0 * t.ld, it.rows, t.cols, t.ld, nt_);
+                else if (t.kind == kCvtBf16T)          // it.row0, it.rows: whole tiles; keys left of the entry from row0 on
+                    tiles_to_bf16_t(s, (unsigned short *)t.dst + it.row0, t.keys - it.row0, it.rows / 32, t.cols, t.cols_pad, t.ldt, nt_);
                 else
                     rows_to_bf16(s, (unsigned short *)t.dst + it.row0 * t.ld, it.rows, t.cols, t.ld, t.mult, nt_);
                 t.remaining.fetch_sub(1, std::memory_order_release);
@@ -462,6 +588,12 @@ void host_convert_rows(const double *src, void *dst, long rows, int cols, int ld
         if (force_scalar) rows_to_bf16_scalar(src, (unsigned short *)dst, rows, cols, ld, mult);
         else rows_to_bf16(src, (unsigned short *)dst, rows, cols, ld, mult, nt);
     }
+}
+
+void host_convert_vt(const double *src, unsigned short *dst, long keys, long keys_pad, int cols, int cols_pad, long ldt,
+                     bool force_scalar, int stream_stores) {
+    const bool nt = stream_stores < 0 ? stream_stores_default() : stream_stores != 0;
+    tiles_to_bf16_t(src, dst, keys, (keys_pad + 31) / 32, cols, cols_pad, ldt, nt && !force_scalar, force_scalar);
 }
 
 void host_widen(const float *src, double *dst, size_t n, bool force_scalar) { widen_range(src, dst, n, force_scalar); }

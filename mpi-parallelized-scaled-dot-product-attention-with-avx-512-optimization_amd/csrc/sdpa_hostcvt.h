@@ -15,6 +15,7 @@ namespace sdpa {
 enum CvtKind {
     kCvtF32 = 0,      // float image, rows padded with zero columns to ld floats (cvt_d2f_kernel)
     kCvtBf16 = 1,     // bf16 image, rows padded to ld, values bf16((float)(x * mult)) (cvt_d2bf_kernel)
+    kCvtBf16T = 2,    // the TRANSPOSED bf16 image of V (cvt_d2bf_t_kernel): submit_t() / host_convert_vt() only
 };
 
 // Streaming (non-temporal) stores in the AVX-512 rows: whole 64-byte lines written past the cache wherever a row's
@@ -27,6 +28,12 @@ enum CvtKind {
 // stream_stores: 1 / 0 = streaming stores on / off, -1 = the default)
 void host_convert_rows(const double *src, void *dst, long rows, int cols, int ld, CvtKind kind, double mult,
                        bool force_scalar, int stream_stores = -1);
+
+// `keys` rows of V (fp64, `cols` columns) -> the columns [0, keys_pad) of a Vt image whose rows are `ldt` elements apart (dst = its
+// row 0 at the first key's tile; keys_pad = keys rounded up to whole 32-key tiles, or more: zero tiles): dst[c * ldt + kvpos(j)] for
+// key j (sdpa_internal.h: bf16_kvpos), zero behind the last key, zero rows [cols, cols_pad) -- cvt_d2bf_t_kernel's image bit for bit
+void host_convert_vt(const double *src, unsigned short *dst, long keys, long keys_pad, int cols, int cols_pad, long ldt,
+                     bool force_scalar, int stream_stores = -1);
 
 // dst[i] = (double)src[i] on the calling thread (cvt_f2d_avx512, attention-mpi.c:68-101)
 void host_widen(const float *src, double *dst, size_t n, bool force_scalar);
@@ -43,6 +50,8 @@ public:
     // are handed back (also on error paths)
     virtual void begin() = 0;
     virtual int submit(const double *src, void *dst, long rows, int cols, int ld, CvtKind kind, double mult) = 0;
+    // the same for a column range of a Vt image (host_convert_vt's arguments; whole 32-key tiles per work item)
+    virtual int submit_t(const double *src, unsigned short *dst, long keys, long keys_pad, int cols, int cols_pad, long ldt) = 0;
     virtual void kick() = 0;
     virtual void wait(int task) = 0;
     virtual void finish() = 0;

@@ -156,6 +156,10 @@ int  pick_kv_splits_bf16(int m, int n_local, int dk, int dv);
 size_t bf16_workspace_bytes(int m, int n_local, int dk, int dv);
 void bf16_carve_workspace(Bf16Args &a, void *ws, int ws_ld);   // needs a.m, a.dv, a.kv_splits
 hipError_t launch_shard_partial_bf16(const Bf16Args &a, hipStream_t s);
+// the persistent, input-following form of the same launch (StreamArgs as for the fp32 one; tile = kKvTile keys of a split's
+// range): dims with bf16_stream_launch_supported() only.  Triples bit for bit those of launch_shard_partial_bf16().
+bool bf16_stream_launch_supported(int dk, int dv);
+hipError_t launch_shard_partial_bf16_streamed(const Bf16Args &a, const StreamArgs &st, hipStream_t s);
 hipError_t launch_cvt_d2bf(const double *src, unsigned short *dst, long rows, int cols, int ld, hipStream_t s);
 hipError_t launch_cvt_d2bf_q(const double *src, unsigned short *dst, long rows, int dk, int ld, hipStream_t s);
 hipError_t launch_cvt_d2bf_t(const double *src, unsigned short *dst, long rows, int cols, int cols_pad,
@@ -168,6 +172,15 @@ hipError_t launch_cvt_d2bf_t_part(const double *src, unsigned short *dst, long r
 hipError_t launch_cvt_bf_t_part(const unsigned short *src, unsigned short *dst, long rows, long rows_pad, int cols,
                                 int cols_pad, long ldt, hipStream_t s);
 hipError_t launch_split_merge(const PartialArgs &a, hipStream_t s);
+// The runtime loads a translation unit's device code object when one of its kernels is first used -- an upload that needs the GPU and
+// so WAITS for a resident persistent launch: the split merge enqueued right behind the first streamed bf16 launch of a process blocked
+// its enqueuing thread for the launch's whole timeout, in FRONT of the copies the launch was waiting for (round 5, call 22).  The engine
+// loads every unit's code object when it creates a rank (current device).
+hipError_t preload_kernels_f32();
+hipError_t preload_kernels_dksplit();
+hipError_t preload_kernels_bf16();
+hipError_t preload_kernels_aux();
+hipError_t preload_kernels_coll();
 
 // In-GPU K/V splits against TAIL QUANTISATION.  `blocks * s` workgroups run in ceil(blocks * s / slots) rounds of
 // `slots` resident workgroups; once there is more than one round, a thinly filled last round idles most of the

@@ -485,11 +485,11 @@ def test_convert_placement_is_chosen_per_problem(engine, orc, O):
 
 
 # ------------------------------------------------- the streamed first batch (round 5): ONE persistent launch that follows its inputs -----
-def device_level(pkg, Q, K, V, batch):
+def device_level(pkg, Q, K, V, batch, precision="f32"):
     """the device-level path on resident inputs, batch after batch: converts, ONE fused launch per batch on the whole
-    shard (sdpa_dev_shard_partial_f32), finish -- what the streamed launch must reproduce bit for bit"""
+    shard (sdpa_dev_shard_partial_f32 / _bf16), finish -- what the streamed launch must reproduce bit for bit"""
     be = pkg.HipBackend("cuda:0")
-    sa = pkg.ShardedAttention(be)
+    sa = pkg.ShardedAttention(be, precision=precision)
     n, dk = K.shape
     dv = V.shape[1]
     sa.load_kv_shard_f64(torch.from_numpy(K).cuda(), torch.from_numpy(V).cuda(), n, dk, dv)
@@ -616,3 +616,98 @@ def test_streamed_launch_times_out_instead_of_hanging(engine, O):
     pkg = engine()
     got = pkg.attention(Q, K, V)                                               # and the engine is usable afterwards
     assert pkg.last_timing()["streamed"] == 1 and np.isfinite(got).all()
+
+
+# ------------------------------------------------- ... and its bf16 form (the tandem kernel's shapes: dv > 256) ------------------------------
+def bf16_tol(V):
+    return 1e-2 * max(1.0, float(np.abs(V).max()))
+
+
+@pytest.mark.parametrize("m,n,dk,dv,dist,env", [
+    (8192, 16384, 512, 512, "D1", {}),                        # BASELINE config 5's dims: 64 query blocks x 4 splits, several groups
+    (32768, 8192, 512, 512, "D2", {}),                        # a whole-chip grid of 256 query blocks, ONE split
+    (4096, 20011, 300, 400, "D3", {}),                        # padded dims (dk 512, 112 zero rows in the Vt image), ragged last tile
+    (16384, 9001, 128, 512, "D4", {}),                        # the dk = 128 instantiation; adversarial spike late in the last group
+    (20000, 16384, 256, 1024, "D2", {"SDPA_QBATCH": 8192}),   # dv = 1024: two 512-column chunks per query block; 3 batches
+    (8192, 40000, 64, 320, "D2", {"SDPA_STREAM_CHUNK_MIN": 1024, "SDPA_KV_CHUNK_MAX": 4096}),   # many small groups
+])
+def test_streamed_bf16_first_batch_is_the_device_level_launch_bit_for_bit(m, n, dk, dv, dist, env, engine, orc, O):
+    """The bf16 form of the streamed first batch (round 5): fused_bf16_tandem_stream_kernel is the tandem kernel's text with waits in
+    front of the Q fragment load and of the LDS-DMA requests that cross into a new K/V group.  K travels as bf16 rows, V as column
+    ranges of the Vt IMAGE the host writes (sdpa_host_cvt_vt's transposing converter on the pool) carried by pitched copies.  Same
+    work, same order as sdpa_dev_shard_partial_bf16 on resident images (device converters): the same result bit for bit -- which
+    also says the host's Vt image IS the device converter's; deterministic from call to call; the launch-per-chunk schedule agrees
+    within the path's tolerance; both against the fp64 oracle."""
+    Q, K, V = O.make_inputs(m, n, dk, dv, dist, seed=m + n)
+    batch = int(env.get("SDPA_QBATCH", 32768))
+    pkg = engine(**env)
+    got = pkg.attention(Q, K, V, precision="bf16")
+    t = pkg.last_timing()
+    assert t["streamed"] == 1 and t["host_convert_threads"] > 0, t
+    assert "fused_bf16_tandem" in t["last_kernel"], t["last_kernel"]
+    if m <= batch:
+        assert t["fused_launches"] == 1 and t["last_kernel"].startswith("sdpa::fused_bf16_tandem_stream_kernel<"), t
+    want = device_level(pkg, Q, K, V, batch, precision="bf16")
+    assert np.array_equal(got, want), "streamed bf16 launch differs from the device-level launch in %d values (max %.3e)" % (
+        (got != want).sum(), np.abs(got - want).max())
+    for rep in range(2):
+        assert np.array_equal(pkg.attention(Q, K, V, precision="bf16"), got), "call %d differs" % rep
+    rows = np.sort(np.random.default_rng(m).choice(m, 48, replace=False))
+    ref = O.numpy_attention_f64(Q, K, V, rows)
+    check(got[rows], ref, V, "streamed bf16", bf16_tol(V))
+    pkg = engine(SDPA_STREAMED=0, **env)
+    old = pkg.attention(Q, K, V, precision="bf16")
+    assert pkg.last_timing()["streamed"] == 0 and pkg.last_timing()["fused_launches"] > 1
+    check(old[rows], ref, V, "launch per chunk, bf16", bf16_tol(V))
+    assert np.abs(old - got).max() <= 2 * bf16_tol(V)
+
+
+def test_streamed_bf16_calls_back_to_back_on_different_inputs_and_the_timeout(engine, O):
+    """two input sets alternating in one engine (the images of a call land in the SAME device buffers as the previous call's while the
+    launch is resident): every call equals its own set's first result bit for bit; and a ready word that never comes ends the call
+    with an error inside $SDPA_STREAM_TIMEOUT_MS, after which the engine still works"""
+    import time
+    m, n, d = 8192, 16384, 512
+    sets = [O.make_inputs(m, n, d, d, dist, seed=seed) for dist, seed in (("D1", 21), ("D2", 22))]
+    pkg = engine()
+    rows = np.arange(0, m, max(1, m // 40))
+    first = []
+    for Q, K, V in sets:
+        got = pkg.attention(Q, K, V, precision="bf16")
+        assert pkg.last_timing()["streamed"] == 1, pkg.last_timing()
+        check(got[rows], O.numpy_attention_f64(Q, K, V, rows), V, "first call of a set", bf16_tol(V))
+        first.append(got)
+    assert np.abs(first[0] - first[1]).max() > 1e-3
+    for rep in range(4):
+        for (Q, K, V), want in zip(sets, first):
+            got = pkg.attention(Q, K, V, precision="bf16")
+            assert np.array_equal(got, want), "round %d: %d values differ (max %.3e)" % (rep, (got != want).sum(), np.abs(got - want).max())
+    Q, K, V = sets[0]
+    pkg = engine(SDPA_STREAM_TIMEOUT_MS=200, SDPA_STREAM_DROP_WORD=2)
+    assert len(pkg.plan(m, n, d, d, 2, 1)["r"][0]["stream"]["end_tile"]) >= 2
+    t0 = time.perf_counter()
+    with pytest.raises(pkg.SdpaError):
+        pkg.attention(Q, K, V, precision="bf16")
+    assert time.perf_counter() - t0 < 5.0
+    pkg = engine()
+    got = pkg.attention(Q, K, V, precision="bf16")
+    assert pkg.last_timing()["streamed"] == 1 and np.array_equal(got, first[0])
+
+
+@pytest.mark.parametrize("P,m,n,dk,dv", [(2, 8192, 32768, 512, 512), (3, 8192, 40000, 300, 512)])
+def test_streamed_bf16_shards_on_loopback_ranks(P, m, n, dk, dv, engine, O):
+    """every rank of a K/V-sharded call streams ITS shard (its own packed Vt image in the staging, its own ready words); the merged
+    result agrees with the fp64 oracle and with the launch-per-chunk schedule; page-locked caller arrays take the same path"""
+    Q, K, V = O.make_inputs(m, n, dk, dv, "D2", seed=P)
+    pkg = engine(SDPA_VIRTUAL_GPUS=P)
+    got = pkg.attention(Q, K, V, precision="bf16")
+    t = pkg.last_timing()
+    assert t["streamed"] == 1 and t["n_gpus"] == P, t
+    rows = np.arange(0, m, 97)
+    ref = O.numpy_attention_f64(Q, K, V, rows)
+    check(got[rows], ref, V, "%d loopback ranks, streamed bf16 shards" % P, bf16_tol(V))
+    assert np.array_equal(pkg.attention(Q, K, V, precision="bf16"), got)
+    pkg = engine(SDPA_VIRTUAL_GPUS=P, SDPA_STREAMED=0)
+    old = pkg.attention(Q, K, V, precision="bf16")
+    assert pkg.last_timing()["streamed"] == 0
+    assert np.abs(old - got).max() <= 2 * bf16_tol(V)

@@ -51,7 +51,9 @@ def check_stream(pl, rp):
     if not st["on"]:
         assert st["entries"] == []
         return
-    assert pl["bf16"] == 0 and 1 <= st["splits"] <= 8 and rp["key_cnt"] >= 8192
+    assert 1 <= st["splits"] <= 8 and rp["key_cnt"] >= 8192
+    if pl["bf16"]:       # the bf16 form (second half of round 5): the tandem kernel's shapes only, and a whole-chip launch only
+        assert pl["compute_cus"] == 256
     tps, ends = st["tiles_per_split"], st["end_tile"]
     ntiles = -(-rp["key_cnt"] // 32)
     assert tps == -(-ntiles // st["splits"])
@@ -193,7 +195,7 @@ def test_describe_rejects_bad_arguments(pkg):
 def test_streamed_first_batch_plan_on_the_baseline_shapes(pkg, monkeypatch):
     """Where the first Q batch runs as ONE persistent launch that follows its K/V groups: every
     BASELINE fp32 shape with d <= 128 -- with the split count of the device-level launch on the resident shard, which is
-    what makes the two bit-identical -- and where it does not: bf16, d > 128, few query blocks (many splits), a launch
+    what makes the two bit-identical -- and where it does not: bf16 with dv <= 256, fp32 with d > 128, few query blocks (many splits), a launch
     stream-K would cut differently, SDPA_F_NO_PIPELINE, $SDPA_STREAMED=0."""
     lib = pkg.load()
     for (m, n, d, ranks) in [(32768, 65536, 128, 1), (8192, 8192, 128, 1), (32768, 262144, 128, 1), (131072, 65536, 128, 1),
@@ -207,7 +209,19 @@ def test_streamed_first_batch_plan_on_the_baseline_shapes(pkg, monkeypatch):
     assert pkg.plan(32768, 65536, 128, 128, 0, 1)["r"][0]["stream"]["end_tile"] == [64, 128, 256, 512, 1024]
     c2 = pkg.plan(8192, 8192, 128, 128, 0, 1)["r"][0]["stream"]          # config 2: 8 splits of 1024 keys -> ONE group, one copy
     assert c2["splits"] == 8 and c2["end_tile"] == [32] and c2["entries"] == [[0, 8192, 0]]
-    for (m, n, d, flags) in [(32768, 65536, 512, SDPA_F_BF16), (32768, 65536, 512, 0), (32768, 65536, 256, 0),
+    # bf16 (second half of round 5): the tandem kernel's shapes (dv > 256) have a persistent form -- config 5 in bf16 is ONE launch over
+    # 9 groups, with the device-level launch's split count; narrower value matrices (duo / pipe kernels) keep the launch per chunk
+    c5 = pkg.plan(32768, 65536, 512, 512, SDPA_F_BF16, 1)
+    st = c5["r"][0]["stream"]
+    assert c5["bf16"] == 1 and st["on"] == 1 and st["splits"] == lib.sdpa_dev_kv_splits_bf16(32768, 65536, 512, 512) == 1
+    assert st["end_tile"] == [128, 256, 512, 768, 1024, 1280, 1536, 1792, 2048] and len(st["entries"]) == 9
+    check_stream(c5, c5["r"][0])
+    for (m, n, dk, dv) in [(8192, 16384, 512, 512), (20000, 16384, 256, 1024), (4096, 20011, 300, 400), (32768, 262144, 512, 512)]:
+        pl = pkg.plan(m, n, dk, dv, SDPA_F_BF16, 1)
+        st = pl["r"][0]["stream"]
+        assert st["on"] == 1 and st["splits"] == lib.sdpa_dev_kv_splits_bf16(min(m, 32768), n, dk, dv), (m, n, dk, dv)
+        check_stream(pl, pl["r"][0])
+    for (m, n, d, flags) in [(32768, 65536, 256, SDPA_F_BF16), (32768, 65536, 128, SDPA_F_BF16), (32768, 65536, 512, 0), (32768, 65536, 256, 0),
                              (512, 65536, 128, 0), (32768, 4096, 128, 0), (32768, 65536, 128, SDPA_F_NO_PIPELINE)]:
         assert pkg.plan(m, n, d, d, flags, 1)["r"][0]["stream"]["on"] == 0, (m, n, d, flags)
     monkeypatch.setenv("SDPA_STREAMED", "0")

@@ -130,3 +130,72 @@ def test_host_widen_argument_errors(pkg):
     assert lib.sdpa_host_widen(None, a.ctypes.data, 4, 1, 0) == pkg._lib.SDPA_EINVAL
     assert lib.sdpa_host_widen(a.ctypes.data, None, 4, 1, 0) == pkg._lib.SDPA_EINVAL
     assert lib.sdpa_host_widen(None, None, 0, 1, 0) == 0
+
+
+# ---- the transposed V image of the bf16 kernels, made on the host (sdpa_host_cvt_vt; round 5) ----------------------------------
+def _kvpos(j):
+    return (j & ~12) | ((j & 4) << 1) | ((j & 8) >> 1)
+
+
+def _vt_reference(V, keys_pad, cols_pad, ldt):
+    """cvt_d2bf_t_kernel restated in numpy: dst[c, kvpos(j)] = bf16(float(V[j, c])), RNE twice, zeros elsewhere"""
+    keys, cols = V.shape
+    f = V.astype(np.float32)
+    u = f.view(np.uint32).astype(np.uint64)
+    b = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)          # (finite inputs: no carry out of 32 bits matters)
+    img = np.zeros((cols_pad, ldt), np.uint16)
+    pos = np.array([(j & ~31) | _kvpos(j & 31) for j in range(keys)], dtype=np.int64)
+    img[:cols, pos] = b.T
+    return img
+
+
+@pytest.mark.parametrize("keys,cols,cols_pad,extra_tiles,scalar", [
+    (64, 32, 32, 0, False), (96, 512, 512, 0, False), (33, 300, 512, 0, False), (1, 7, 64, 1, False), (255, 129, 256, 2, False),
+    (64, 40, 64, 0, True), (95, 512, 512, 0, True), (0, 16, 32, 1, False)])
+def test_host_vt_image_is_the_device_converters_image(keys, cols, cols_pad, extra_tiles, scalar, pkg):
+    """every key position of the padded range is written (stale staging bytes must not survive), the pad rows are zero, the values
+    and their places are cvt_d2bf_t_kernel's; AVX-512 rows + streaming lines == the plain C rows"""
+    lib = pkg.load()
+    rng = np.random.default_rng(keys * 1000 + cols)
+    V = rng.uniform(-3, 3, (keys, cols))
+    if keys:
+        V[0, 0] = 1.0 + 2.0 ** -9                        # an RNE tie of the fp32 -> bf16 rounding (to even: down)
+        V[-1, -1] = -(1.0 + 3 * 2.0 ** -9)               # ... and one that rounds up
+    keys_pad = (keys + 31) // 32 * 32 + 32 * extra_tiles
+    ldt = keys_pad + 64                                  # the image is wider than the entry: the neighbours must stay untouched
+    img = np.full((cols_pad, ldt), 0xABCD, np.uint16)
+    rc = lib.sdpa_host_cvt_vt(V.ctypes.data if keys else None, img.ctypes.data, keys, keys_pad, cols, cols_pad, ldt, 1 if scalar else 0)
+    assert rc == 0
+    want = _vt_reference(V, keys_pad, cols_pad, ldt)
+    assert np.array_equal(img[:, :keys_pad], want[:, :keys_pad])
+    assert (img[:, keys_pad:] == 0xABCD).all()
+
+
+def test_host_vt_entries_tile_by_tile_equal_one_call(pkg):
+    """submit_t through a pool (sdpa_host_cvt_vt has no pool form: the engine's streamed bf16 call is the user) is covered on the GPU;
+    here: an offset entry inside a larger image, tile by tile, equals one call over the whole range"""
+    lib = pkg.load()
+    rng = np.random.default_rng(5)
+    keys, cols = 200, 96
+    V = rng.uniform(-1, 1, (keys, cols))
+    keys_pad, ldt = 224, 512
+    whole = np.zeros((128, ldt), np.uint16)
+    assert lib.sdpa_host_cvt_vt(V.ctypes.data, whole.ctypes.data, keys, keys_pad, cols, 128, ldt, 0) == 0
+    parts = np.zeros((128, ldt), np.uint16)
+    for r0 in range(0, keys_pad, 64):
+        left = max(0, min(64, keys - r0))
+        src = V[r0:r0 + left] if left else V[:0]
+        src = np.ascontiguousarray(src)
+        assert lib.sdpa_host_cvt_vt(src.ctypes.data if left else None, parts.ctypes.data + 2 * r0, left, 64 if r0 + 64 <= keys_pad else keys_pad - r0,
+                                    cols, 128, ldt, 0) == 0
+    assert np.array_equal(whole, parts)
+
+
+def test_host_vt_rejects_bad_arguments(pkg):
+    lib = pkg.load()
+    x = np.zeros(64)
+    d = np.zeros(4096, np.uint16)
+    assert lib.sdpa_host_cvt_vt(x.ctypes.data, d.ctypes.data, 8, 30, 8, 8, 64, 0) == pkg._lib.SDPA_EINVAL     # keys_pad not whole tiles
+    assert lib.sdpa_host_cvt_vt(x.ctypes.data, d.ctypes.data, 8, 32, 8, 4, 64, 0) == pkg._lib.SDPA_EINVAL     # cols_pad < cols
+    assert lib.sdpa_host_cvt_vt(x.ctypes.data, d.ctypes.data, 8, 32, 8, 8, 16, 0) == pkg._lib.SDPA_EINVAL     # ldt < keys_pad
+    assert lib.sdpa_host_cvt_vt(None, d.ctypes.data, 8, 32, 8, 8, 64, 0) == pkg._lib.SDPA_EINVAL

@@ -73,8 +73,8 @@ for name in args or ["headline", "config2", "config1"]:
     STR = [{"SDPA_STREAMED": 0}, {"SDPA_STREAMED": 1}, {"SDPA_STREAMED": 0}, {"SDPA_STREAMED": 1},
            {"SDPA_STREAM_CHUNK_MIN": 2048}, {"SDPA_STREAM_CHUNK_MIN": 8192}, {"SDPA_ROW_PIECES": 8}, {"SDPA_ROW_PIECES": 2}, {}]
     for knobs in (SWEEP if sweep else WID if widen else REG if register else STR if streamed else CVT):
-        for k in KNOBS + ("SDPA_HOST_CVT", "SDPA_HOST_CVT_THREADS", "SDPA_HOST_WIDEN"):
-            os.environ.pop(k, None)
+        for k in KNOBS + (("SDPA_HOST_CVT", "SDPA_HOST_CVT_THREADS", "SDPA_HOST_WIDEN") if (hostcvt or widen or register) else ()):
+            os.environ.pop(k, None)           # (outside those modes a caller's $SDPA_HOST_CVT_THREADS etc. stay in force)
         for k, v in knobs.items():
             os.environ[k] = str(v)
         if hostcvt or widen or register or streamed:
