@@ -173,11 +173,13 @@ SDPA_API void sdpa_reload_env(void);
  * owner_count/owner_disp (:19-27) and merged with the algebra of :340-380
  * (flags choose the collective schedule).  The first Q batch streams the K/V
  * shard host->device in groups of rows and computes as they land: for the
- * fp32 shapes with dk, dv in (32, 128] ONE persistent launch whose workgroups
- * wait, in the kernel, for the ready word of the rows they are about to read
- * (raised by the copy engine behind the rows; sdpa_timing.streamed = 1; the
- * same triples, bit for bit, as sdpa_dev_shard_partial_f32 on the resident
- * shard; $SDPA_STREAMED=0: one launch per K/V chunk, as for every other shape).
+ * fp32 shapes with dk, dv in (32, 128] and the bf16 shapes with dv > 256 ONE
+ * persistent launch whose workgroups wait, in the kernel, for the ready word
+ * of the rows they are about to read (raised by the copy engine behind the
+ * rows; bf16: V travels as column ranges of the transposed image the host
+ * writes, sdpa_host_cvt_vt; sdpa_timing.streamed = 1; the same triples, bit
+ * for bit, as sdpa_dev_shard_partial_f32 / _bf16 on the resident shard;
+ * $SDPA_STREAMED=0: one launch per K/V chunk, as for every other shape).
  * Every shape has a kernel: any dk, dv in fp32 (dk > 1024 on a VALU-only
  * kernel); SDPA_F_BF16 beyond the bf16 kernels' dims (dk <= 512, dv <= 1024,
  * 4 GiB of Vt per rank) runs the fp32 path and says so on stderr.

@@ -172,8 +172,8 @@ def test_host_vt_image_is_the_device_converters_image(keys, cols, cols_pad, extr
 
 
 def test_host_vt_entries_tile_by_tile_equal_one_call(pkg):
-    """submit_t through a pool (sdpa_host_cvt_vt has no pool form: the engine's streamed bf16 call is the user) is covered on the GPU;
-    here: an offset entry inside a larger image, tile by tile, equals one call over the whole range"""
+    """an entry converted 64 keys at a time at its offsets inside a larger image equals one call over the whole range -- what the
+    converter pool's work items do (the pool itself runs inside the engine's streamed bf16 call: tests/test_gpu_host_pipeline.py)"""
     lib = pkg.load()
     rng = np.random.default_rng(5)
     keys, cols = 200, 96
