@@ -259,9 +259,10 @@ SDPA_API int sdpa_host_cvt_rows(const double *src, void *dst, long rows, int col
  * elements apart -- dst[c * ldt + p] = bf16((float)V[j][c]) with p = j with bits 2 and 3 swapped (each 16-key group is stored
  * 0-3, 8-11, 4-7, 12-15: one MFMA lane's eight keys are 16 contiguous bytes), zero for positions behind the last key (keys_pad: a
  * multiple of 32 >= keys), zero rows for c in [cols, cols_pad).  The device converter's image bit for bit; flags as
- * sdpa_host_cvt_rows.  The reference converts V on the host as well (cvt_d2f_avx512 at attention-mpi.c:225); needs no GPU.   */
+ * sdpa_host_cvt_rows; threads <= 1: on the calling thread, threads > 1: on a pool of that many threads, in work items of whole
+ * 32-key tiles -- the way sdpa_attention_f64 runs it.  The reference converts V on the host as well (cvt_d2f_avx512 at attention-mpi.c:225); needs no GPU.   */
 SDPA_API int sdpa_host_cvt_vt(const double *src, unsigned short *dst, long keys, long keys_pad, int cols, int cols_pad,
-                              long ldt, int flags);
+                              long ldt, int threads, int flags);
 
 /* The host-side widening of result rows: dst[i] = (double)src[i] for i < n (cvt_f2d_avx512, attention-mpi.c:68-101,
  * called on the root at :373 / :396), exact.  threads <= 1: on the calling thread; threads > 1: on a pool of that many

@@ -262,11 +262,24 @@ int sdpa_host_cvt_rows(const double *src, void *dst, long rows, int cols, int ld
     return SDPA_OK;
 }
 
-int sdpa_host_cvt_vt(const double *src, unsigned short *dst, long keys, long keys_pad, int cols, int cols_pad, long ldt, int flags) {
+int sdpa_host_cvt_vt(const double *src, unsigned short *dst, long keys, long keys_pad, int cols, int cols_pad, long ldt, int threads,
+                     int flags) {
     if (keys < 0 || cols <= 0 || cols_pad < cols || keys_pad < keys || keys_pad % 32 != 0 || ldt < keys_pad) return SDPA_EINVAL;
     if (keys_pad == 0) return SDPA_OK;
     if ((!src && keys > 0) || !dst) return SDPA_EINVAL;
-    sdpa::host_convert_vt(src, dst, keys, keys_pad, cols, cols_pad, ldt, (flags & 1) != 0, (flags & 2) ? 1 : (flags & 4) ? 0 : -1);
+    if (threads <= 1) {
+        sdpa::host_convert_vt(src, dst, keys, keys_pad, cols, cols_pad, ldt, (flags & 1) != 0, (flags & 2) ? 1 : (flags & 4) ? 0 : -1);
+        return SDPA_OK;
+    }
+    // the way the engine's streamed bf16 call runs it: work items of whole 32-key tiles on a pool of host threads
+    sdpa::HostConverter *pool = sdpa::HostConverter::create(threads);
+    if (!pool) return SDPA_ENOMEM;
+    pool->begin();
+    const int task = pool->submit_t(src, dst, keys, keys_pad, cols, cols_pad, ldt);
+    pool->kick();
+    pool->wait(task);
+    pool->finish();
+    delete pool;
     return SDPA_OK;
 }
 

@@ -164,7 +164,7 @@ def test_host_vt_image_is_the_device_converters_image(keys, cols, cols_pad, extr
     keys_pad = (keys + 31) // 32 * 32 + 32 * extra_tiles
     ldt = keys_pad + 64                                  # the image is wider than the entry: the neighbours must stay untouched
     img = np.full((cols_pad, ldt), 0xABCD, np.uint16)
-    rc = lib.sdpa_host_cvt_vt(V.ctypes.data if keys else None, img.ctypes.data, keys, keys_pad, cols, cols_pad, ldt, 1 if scalar else 0)
+    rc = lib.sdpa_host_cvt_vt(V.ctypes.data if keys else None, img.ctypes.data, keys, keys_pad, cols, cols_pad, ldt, 1, 1 if scalar else 0)
     assert rc == 0
     want = _vt_reference(V, keys_pad, cols_pad, ldt)
     assert np.array_equal(img[:, :keys_pad], want[:, :keys_pad])
@@ -180,14 +180,14 @@ def test_host_vt_entries_tile_by_tile_equal_one_call(pkg):
     V = rng.uniform(-1, 1, (keys, cols))
     keys_pad, ldt = 224, 512
     whole = np.zeros((128, ldt), np.uint16)
-    assert lib.sdpa_host_cvt_vt(V.ctypes.data, whole.ctypes.data, keys, keys_pad, cols, 128, ldt, 0) == 0
+    assert lib.sdpa_host_cvt_vt(V.ctypes.data, whole.ctypes.data, keys, keys_pad, cols, 128, ldt, 1, 0) == 0
     parts = np.zeros((128, ldt), np.uint16)
     for r0 in range(0, keys_pad, 64):
         left = max(0, min(64, keys - r0))
         src = V[r0:r0 + left] if left else V[:0]
         src = np.ascontiguousarray(src)
         assert lib.sdpa_host_cvt_vt(src.ctypes.data if left else None, parts.ctypes.data + 2 * r0, left, 64 if r0 + 64 <= keys_pad else keys_pad - r0,
-                                    cols, 128, ldt, 0) == 0
+                                    cols, 128, ldt, 1, 0) == 0
     assert np.array_equal(whole, parts)
 
 
@@ -195,7 +195,23 @@ def test_host_vt_rejects_bad_arguments(pkg):
     lib = pkg.load()
     x = np.zeros(64)
     d = np.zeros(4096, np.uint16)
-    assert lib.sdpa_host_cvt_vt(x.ctypes.data, d.ctypes.data, 8, 30, 8, 8, 64, 0) == pkg._lib.SDPA_EINVAL     # keys_pad not whole tiles
-    assert lib.sdpa_host_cvt_vt(x.ctypes.data, d.ctypes.data, 8, 32, 8, 4, 64, 0) == pkg._lib.SDPA_EINVAL     # cols_pad < cols
-    assert lib.sdpa_host_cvt_vt(x.ctypes.data, d.ctypes.data, 8, 32, 8, 8, 16, 0) == pkg._lib.SDPA_EINVAL     # ldt < keys_pad
-    assert lib.sdpa_host_cvt_vt(None, d.ctypes.data, 8, 32, 8, 8, 64, 0) == pkg._lib.SDPA_EINVAL
+    assert lib.sdpa_host_cvt_vt(x.ctypes.data, d.ctypes.data, 8, 30, 8, 8, 64, 1, 0) == pkg._lib.SDPA_EINVAL     # keys_pad not whole tiles
+    assert lib.sdpa_host_cvt_vt(x.ctypes.data, d.ctypes.data, 8, 32, 8, 4, 64, 1, 0) == pkg._lib.SDPA_EINVAL     # cols_pad < cols
+    assert lib.sdpa_host_cvt_vt(x.ctypes.data, d.ctypes.data, 8, 32, 8, 8, 16, 1, 0) == pkg._lib.SDPA_EINVAL     # ldt < keys_pad
+    assert lib.sdpa_host_cvt_vt(None, d.ctypes.data, 8, 32, 8, 8, 64, 1, 0) == pkg._lib.SDPA_EINVAL
+
+
+@pytest.mark.parametrize("keys,cols,cols_pad,threads,item_kb", [(4096, 512, 512, 8, 64), (1000, 300, 512, 3, 4), (8192, 64, 64, 5, 1024)])
+def test_host_vt_on_a_pool_of_threads_is_the_single_thread_image(keys, cols, cols_pad, threads, item_kb, pkg, monkeypatch):
+    """the pool's work items (whole 32-key tiles, $SDPA_HOST_CVT_ITEM_KB of source each, taken by whichever thread is free) write the
+    same image as one thread does, including the zero tail and the pad rows"""
+    lib = pkg.load()
+    monkeypatch.setenv("SDPA_HOST_CVT_ITEM_KB", str(item_kb))
+    V = np.random.default_rng(keys + threads).normal(0, 2, (keys, cols))
+    keys_pad = (keys + 31) // 32 * 32 + 64
+    one = np.full((cols_pad, keys_pad), 0x1234, np.uint16)
+    many = np.full((cols_pad, keys_pad), 0x4321, np.uint16)
+    assert lib.sdpa_host_cvt_vt(V.ctypes.data, one.ctypes.data, keys, keys_pad, cols, cols_pad, keys_pad, 1, 0) == 0
+    assert lib.sdpa_host_cvt_vt(V.ctypes.data, many.ctypes.data, keys, keys_pad, cols, cols_pad, keys_pad, threads, 0) == 0
+    assert np.array_equal(one, many)
+    assert np.array_equal(one, _vt_reference(V, keys_pad, cols_pad, keys_pad))
