@@ -2437,7 +2437,11 @@ int sdpa_prepare(int m, int n, int dk, int dv, int flags) {
     if (want_host_cvt(pl, !register_caller_arrays())) {
         SDPA_TRY(ensure_host_converter());
         const size_t vrow = pl.bf16 ? (size_t)dv * sizeof(unsigned short) : (size_t)pl.ldv * sizeof(float);
-        if (!E.hc->staging(0, (size_t)n * pl.ldk * pl.kv_elem) || !E.hc->staging(1, (size_t)n * vrow) ||
+        size_t v_bytes = (size_t)n * vrow;
+        if (pl.bf16)                      // (a streamed bf16 first batch stages the Vt images: padded dv rows x padded keys per rank)
+            for (const RankPlan &rp : pl.r)
+                if (rp.stream.on) v_bytes += (size_t)(sdpa::bf16_pad_dv(dv) - dv) * rp.key_cnt * 2 + (size_t)sdpa::bf16_pad_dv(dv) * 64;
+        if (!E.hc->staging(0, (size_t)n * pl.ldk * pl.kv_elem) || !E.hc->staging(1, v_bytes) ||
             !E.hc->staging(2, (size_t)m * pl.ldq * pl.q_elem))
             return SDPA_ENOMEM;
     }
