@@ -35,7 +35,8 @@ class SdpaTiming(ctypes.Structure):
                 ("compute_cus", _c_int), ("stream_k", _c_int), ("host_widen", _c_int), ("rccl_selftest", _c_int),
                 ("merge_us", ctypes.c_double), ("reduce_us", ctypes.c_double), ("egress_us", ctypes.c_double),
                 # ABI 5
-                ("last_kernel", ctypes.c_char * 96), ("last_grid", _c_int), ("streamed", _c_int)]
+                ("last_kernel", ctypes.c_char * 96), ("last_grid", _c_int), ("streamed", _c_int),
+                ("host_convert_node", _c_int)]
 
 
 SDPA_ABI_VERSION = 5          # the SDPA_ABI_VERSION of include/sdpa_hip.h this binding was written against

@@ -2162,6 +2162,11 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
             for (int b = 1; b < pl.nb; ++b)
                 for (int g = 0; g < q_ranks; ++g) submit_q(g, b);
             for (int g = q_ranks; g < P; ++g) HI.q_task[g] = HI.q_task[0];
+            {
+                const void *arrays[3] = {K, V, Q};
+                const size_t bytes[3] = {c.k_bytes, c.v_bytes, (size_t)m * dk * sizeof(double)};
+                E.hc->place_near(arrays, bytes, 3);
+            }
             E.hc->kick();
         }
     }
@@ -2271,6 +2276,7 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
     const bool streamed0 = c.streamed && pl.r[0].stream.on;
     T.kv_chunks = streamed0 ? (int)pl.r[0].stream.end_tile.size() : (int)pl.r[0].chunks.size();
     T.streamed = streamed0 ? 1 : 0;
+    T.host_convert_node = (c.hostcvt && E.hc) ? E.hc->placed_node() : -1;
     T.fused_launches = n_brackets / 2;
     T.plan = pl.qrows ? 1 : 0;
     T.merge = !pl.collectives ? 0 : (pl.merge_allreduce ? 2 : 1);

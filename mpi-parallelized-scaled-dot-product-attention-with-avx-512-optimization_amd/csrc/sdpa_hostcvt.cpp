@@ -13,6 +13,10 @@
 #include <mutex>
 #include <chrono>
 #include <cstdio>
+#include <pthread.h>
+#include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <thread>
 #include <vector>
 
@@ -240,16 +244,21 @@ void transpose_block_32x32(const unsigned short *in, int ldin, unsigned short *o
     }
 }
 
+// this thread's scratch of the transposing converter (a group of rows in bf16 + one column block of its image), grown on demand;
+// the pool's workers size and touch it when they start, not inside a caller's timed call
+unsigned short *vt_scratch(size_t elems) {
+    static thread_local std::vector<unsigned short> store;
+    if (store.size() < elems + 64) store.assign(elems + 64, 0);
+    return (unsigned short *)(((uintptr_t)store.data() + 63) & ~(uintptr_t)63);
+}
+
 void tiles_to_bf16_t(const double *src, unsigned short *dst, long keys, long tiles, int cols, int cols_pad, long ldt, bool nt,
                      bool force_scalar = false) {
     constexpr int TK = 32, TG = 8;             // keys per tile; tiles per group: an image row gets TG x 64 contiguous bytes at a time
     const int ldtmp = (cols + 31) / 32 * 32;   // (one line per row and tile costs a DTLB miss and a DRAM page each: 4.9 -> x ms per 8192 keys)
     const bool simd = !force_scalar && have_avx512();
     // scratch of this thread: one group of rows, bf16, row-major (<= 256 x 1024 x 2 = 512 KiB), and one column block of its image
-    static thread_local std::vector<unsigned short> tmp_store;
-    const size_t need = (size_t)TG * TK * ldtmp + (size_t)32 * TG * TK + 128;
-    if (tmp_store.size() < need) tmp_store.resize(need);
-    unsigned short *tmp = (unsigned short *)(((uintptr_t)tmp_store.data() + 63) & ~(uintptr_t)63);
+    unsigned short *tmp = vt_scratch((size_t)TG * TK * ldtmp + (size_t)32 * TG * TK + 64);
     unsigned short *obuf = tmp + (size_t)TG * TK * ldtmp;               // [32 columns][TG tiles][32 positions], 64-byte aligned
     for (long t0 = 0; t0 < tiles; t0 += TG) {
         const int tg = (int)(tiles - t0 < TG ? tiles - t0 : TG);
@@ -375,6 +384,53 @@ inline void atomic_min(std::atomic<double> &a, double v) { double c = a.load(); 
 inline void atomic_max(std::atomic<double> &a, double v) { double c = a.load(); while (v > c && !a.compare_exchange_weak(c, v)) {} }
 inline void atomic_add(std::atomic<double> &a, double v) { double c = a.load(); while (!a.compare_exchange_weak(c, c + v)) {} }
 
+// ---- where the pool's threads run ($SDPA_HOST_CVT_PIN, default on) ----------------------------------------------------------
+// On the GPU box's two-socket host the converter reads its fp64 source at 250-420 GB/s from threads on the source pages' NUMA
+// node and at 110 GB/s flat from the other one (tools/probes/hostcvt_placement_probe.cpp, profiles/r05/config5_bf16_feed_analysis.log);
+// unpinned threads land on either, and a one-shot process (both CLI hosts) that draws the far node converts config 5's K and V in
+// 7 ms instead of 3.5 (profiles/r05/cli_one_shot_cold_call25.log: 9.4 ms against 6.7 for the same call).  So before a call's
+// conversions start, a few pages of its source arrays are asked for their node (move_pages with no target: a query), and the
+// pool's threads are confined to that node's CPUs -- or to all CPUs again when the samples disagree or nothing can be learnt.
+struct NumaMap {
+    std::vector<cpu_set_t> node_cpus;      // per node: its CPUs that this process may use
+    cpu_set_t allowed;
+    bool usable = false;
+    NumaMap() {
+        CPU_ZERO(&allowed);
+        if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
+        for (int nd = 0; nd < 64; ++nd) {
+            char path[128];
+            snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", nd);
+            FILE *f = fopen(path, "r");
+            if (!f) break;
+            char buf[4096];
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            if (fgets(buf, sizeof buf, f)) {
+                char *p = buf;
+                while (*p && *p != '\n') {
+                    long a = strtol(p, &p, 10), b = a;
+                    if (*p == '-') b = strtol(p + 1, &p, 10);
+                    for (long c = a; c <= b && c < CPU_SETSIZE; ++c)
+                        if (c >= 0 && CPU_ISSET((int)c, &allowed)) CPU_SET((int)c, &set);
+                    if (*p == ',') ++p;
+                    else if (*p != '\n' && *p != 0 && *p != '-') break;
+                }
+            }
+            fclose(f);
+            node_cpus.push_back(set);
+        }
+        usable = node_cpus.size() > 1;
+    }
+    // node of the page that holds p, or -1
+    static int node_of(const void *p) {
+        void *page = (void *)((uintptr_t)p & ~(uintptr_t)4095);
+        int status = -1;
+        const long rc = syscall(SYS_move_pages, 0, 1UL, &page, nullptr, &status, 0);
+        return rc == 0 ? status : -1;
+    }
+};
+
 class Pool final : public HostConverter {
 public:
     ~Pool() override {
@@ -387,6 +443,28 @@ public:
         for (Buf &b : buf_)
             if (b.p && hipHostFree(b.p) != hipSuccess) (void)hipGetLastError();
     }
+    // confine the workers to the NUMA node the call's source pages live on (class comment above); a handful of syscalls per call
+    void place_near(const void *const *arrays, const size_t *bytes, int n_arrays) override {
+        if (!pin_ || !numa_.usable || th_.empty()) return;
+        int node = -2;                                      // -2: nothing sampled yet; -1: unknown or mixed
+        for (int a = 0; a < n_arrays && node != -1; ++a) {
+            if (!arrays[a] || bytes[a] == 0) continue;
+            for (int k = 0; k < 4 && node != -1; ++k) {
+                const char *p = (const char *)arrays[a] + (k == 3 ? bytes[a] - 1 : (bytes[a] - 1) / 3 * (size_t)k);    // first, 1/3, 2/3, last byte
+                const int nd = NumaMap::node_of(p);
+                if (nd < 0 || nd >= (int)numa_.node_cpus.size()) node = -1;
+                else if (node == -2) node = nd;
+                else if (node != nd) node = -1;
+            }
+        }
+        if (node == -2) node = -1;
+        if (node >= 0 && CPU_COUNT(&numa_.node_cpus[node]) < 4) node = -1;       // (a node this process may hardly use)
+        if (node == placed_) return;
+        const cpu_set_t &set = node >= 0 ? numa_.node_cpus[node] : numa_.allowed;
+        for (std::thread &t : th_) (void)pthread_setaffinity_np(t.native_handle(), sizeof set, &set);
+        placed_ = node;
+    }
+    int placed_node() const override { return placed_; }
     bool start(int n) {
         for (int i = 0; i < n; ++i) th_.emplace_back([this] { loop(); });
         return true;
@@ -471,9 +549,9 @@ public:
             for (const Item &it : b.items) bytes += (double)it.rows * b.tasks[it.task].cols * 8.0;
             const double first_lo = b.first_min.load(), first_hi = b.first_max.load(), last = b.last_done.load();
             fprintf(stderr, "sdpa hostcvt trace: %zu items, %.1f MB of fp64 | workers that took items %d of %zu | first item taken %.0f .. %.0f us "
-                    "after the kick | last item done at %.0f us | sum of busy time %.0f us (%.1f GB/s per busy thread) | %.1f GB/s over the span\n",
+                    "after the kick | last item done at %.0f us | sum of busy time %.0f us (%.1f GB/s per busy thread) | %.1f GB/s over the span | workers on NUMA node %d\n",
                     b.items.size(), bytes / 1e6, b.workers.load(), th_.size(), first_lo - b.t_kick, first_hi - b.t_kick, last - b.t_kick,
-                    b.busy_us.load(), bytes / 1e3 / std::max(1.0, b.busy_us.load()), bytes / 1e3 / std::max(1.0, last - b.t_kick));
+                    b.busy_us.load(), bytes / 1e3 / std::max(1.0, b.busy_us.load()), bytes / 1e3 / std::max(1.0, last - b.t_kick), placed_);
         }
         mine_.reset();
     }
@@ -510,6 +588,7 @@ private:
         size_t cap = 0;
     };
     void loop() {
+        (void)vt_scratch((size_t)8 * 32 * 512 + (size_t)32 * 8 * 32 + 64);       // (the transposing converter's scratch at dv = 512, touched now)
         unsigned long seen = 0;
         bool hot = false;
         for (;;) {
@@ -568,6 +647,9 @@ private:
     Buf buf_[4];
     const bool nt_ = stream_stores_default();
     const bool trace_ = getenv("SDPA_HOST_CVT_TRACE") && atoi(getenv("SDPA_HOST_CVT_TRACE")) != 0;
+    const bool pin_ = !(getenv("SDPA_HOST_CVT_PIN") && atoi(getenv("SDPA_HOST_CVT_PIN")) == 0);
+    NumaMap numa_;
+    int placed_ = -1;                  // the node the workers are confined to (-1: every allowed CPU)
     const int item_kb_ = [] {
         const char *v = getenv("SDPA_HOST_CVT_ITEM_KB");
         const int kb = (v && *v) ? atoi(v) : 64;

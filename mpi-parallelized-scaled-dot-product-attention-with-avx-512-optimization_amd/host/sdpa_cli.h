@@ -227,13 +227,13 @@ static void report_verbose(int m, int n, int dk, int dv, double worst)
     fprintf(stderr,
             "%s: m=%d n=%d dk=%d dv=%d gpus=%d%s plan=%s merge=%s q_batches=%d kv_chunks=%d fused_launches=%d kv_splits=%d\n"
             "%s: total %.1f us | head %.1f us (page-lock %.1f) | fused kernels %.1f us | tail %.1f us | kv stage (overlapped) %.1f us\n"
-            "%s: last fused launch %s, first batch %s\n"
+            "%s: last fused launch %s, first batch %s, converter pool: %d threads on NUMA node %d\n"
             "%s: max |result - answer| = %.3e\n",
             cli_name, m, n, dk, dv, t.n_gpus, t.virtual_ranks ? " (virtual)" : "", t.plan ? "qrows" : "kv",
             t.merge == 0 ? "none" : t.merge == 1 ? "all-gather" : "all-reduce x2", t.q_batches, t.kv_chunks,
             t.fused_launches, t.kv_splits, cli_name, t.total_us, t.head_us, t.register_us, t.kernel_us, t.tail_us,
             t.kv_stage_us, cli_name, t.last_kernel, t.streamed ? "streamed (one persistent launch)" : "one launch per K/V chunk",
-            cli_name, worst);
+            t.host_convert_threads, t.host_convert_node, cli_name, worst);
 }
 
 /* The engine on the GPUs this run drives: $SDPA_GPUS (a count, or 0 / "all"), otherwise the library's default --
