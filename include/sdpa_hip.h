@@ -115,8 +115,9 @@ struct sdpa_timing {
     int    last_grid;     /* its workgroups                                                          */
     int    streamed;      /* 1 = the first Q batch ran as ONE persistent launch that followed the K/V */
                           /* chunks as they arrived (round 5), 0 = one launch per chunk               */
-    int    host_convert_node; /* NUMA node the converter pool's threads were confined to for this call */
-                          /* (where the source arrays' pages live), -1 = every CPU the process may use */
+    int    host_convert_node; /* $SDPA_HOST_CVT_PIN=1 (opt-in): the NUMA node the converter pool's threads */
+                          /* were confined to for this call (where the source arrays' pages live);     */
+                          /* -1 = every CPU the process may use (the default)                          */
 };
 
 /* ---- lifecycle ---------------------------------------------------------- */

@@ -384,13 +384,15 @@ inline void atomic_min(std::atomic<double> &a, double v) { double c = a.load(); 
 inline void atomic_max(std::atomic<double> &a, double v) { double c = a.load(); while (v > c && !a.compare_exchange_weak(c, v)) {} }
 inline void atomic_add(std::atomic<double> &a, double v) { double c = a.load(); while (!a.compare_exchange_weak(c, c + v)) {} }
 
-// ---- where the pool's threads run ($SDPA_HOST_CVT_PIN, default on) ----------------------------------------------------------
-// On the GPU box's two-socket host the converter reads its fp64 source at 250-420 GB/s from threads on the source pages' NUMA
-// node and at 110 GB/s flat from the other one (tools/probes/hostcvt_placement_probe.cpp, profiles/r05/config5_bf16_feed_analysis.log);
-// unpinned threads land on either, and a one-shot process (both CLI hosts) that draws the far node converts config 5's K and V in
-// 7 ms instead of 3.5 (profiles/r05/cli_one_shot_cold_call25.log: 9.4 ms against 6.7 for the same call).  So before a call's
-// conversions start, a few pages of its source arrays are asked for their node (move_pages with no target: a query), and the
-// pool's threads are confined to that node's CPUs -- or to all CPUs again when the samples disagree or nothing can be learnt.
+// ---- where the pool's threads run ($SDPA_HOST_CVT_PIN=1, OPT-IN: a measured negative result) -----------------------------------
+// On the GPU box's two-socket host a standalone probe reads the fp64 source at 250-420 GB/s from threads pinned one per core on
+// the source pages' NUMA node and at 110 GB/s flat from the other one (tools/probes/hostcvt_placement_probe.cpp), and one-shot CLI
+// runs of config 5 in bf16 are bimodal box to box (6.6-7.4 ms against 9.3-9.5).  Confining the pool to the source's node -- a few
+// pages of the call's arrays are asked for their node (move_pages with no target: a query), the threads get that node's CPUs, or
+// all CPUs again when the samples disagree -- does NOT fix that: warm calls are unchanged (6.42-6.60 against 6.46-6.68 ms), and
+// three of five cold CLI runs took 20-28 ms with the pool confined (kv stage 13-22 ms) where every unconfined one took 6.6-7.1
+// (profiles/r05/converter_pool_numa_pin_ab.log; the box's container has a CPU quota of 16 cores -- 32 runnable threads on one
+// socket's CPUs meet it differently than threads spread over both).  Kept behind the knob, off by default.
 struct NumaMap {
     std::vector<cpu_set_t> node_cpus;      // per node: its CPUs that this process may use
     cpu_set_t allowed;
@@ -647,7 +649,7 @@ private:
     Buf buf_[4];
     const bool nt_ = stream_stores_default();
     const bool trace_ = getenv("SDPA_HOST_CVT_TRACE") && atoi(getenv("SDPA_HOST_CVT_TRACE")) != 0;
-    const bool pin_ = !(getenv("SDPA_HOST_CVT_PIN") && atoi(getenv("SDPA_HOST_CVT_PIN")) == 0);
+    const bool pin_ = getenv("SDPA_HOST_CVT_PIN") && atoi(getenv("SDPA_HOST_CVT_PIN")) != 0;       // opt-in: see the class comment
     NumaMap numa_;
     int placed_ = -1;                  // the node the workers are confined to (-1: every allowed CPU)
     const int item_kb_ = [] {

@@ -53,7 +53,8 @@ public:
     // the same for a column range of a Vt image (host_convert_vt's arguments; whole 32-key tiles per work item)
     virtual int submit_t(const double *src, unsigned short *dst, long keys, long keys_pad, int cols, int cols_pad, long ldt) = 0;
     // before kick(): confine the pool's threads to the NUMA node the call's source arrays live on (sampled pages; all CPUs again
-    // when the samples disagree or the host says nothing).  $SDPA_HOST_CVT_PIN=0: never.  placed_node(): where they are (-1: anywhere)
+    // when the samples disagree or the host says nothing) -- only with $SDPA_HOST_CVT_PIN=1 (opt-in: it did not pay, sdpa_hostcvt.cpp).
+    // placed_node(): where they are (-1: anywhere)
     virtual void place_near(const void *const *arrays, const size_t *bytes, int n_arrays) = 0;
     virtual int placed_node() const = 0;
     virtual void kick() = 0;
