@@ -170,7 +170,7 @@ def cpu_baseline(m, n, d, budget_rows=8192):
 
 # the translation units (and their shared headers) that define the fused kernels of one precision
 KERNEL_SOURCES = {"f32": ("sdpa_fwd_f32.hip", "sdpa_fwd_f32_pipelined.inc", "sdpa_fwd_f32_dksplit.hip", "sdpa_f32_device.h", "sdpa_internal.h"),
-                  "bf16": ("sdpa_fwd_bf16.hip", "sdpa_internal.h")}
+                  "bf16": ("sdpa_fwd_bf16.hip", "sdpa_fwd_bf16_tandem.inc", "sdpa_internal.h")}
 
 
 def kernel_source_stamp(precision="f32"):
