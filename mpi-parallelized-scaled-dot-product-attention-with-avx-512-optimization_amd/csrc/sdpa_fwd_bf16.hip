@@ -1754,6 +1754,27 @@ static hipError_t launch_shard_partial_bf16_impl(const Bf16Args &args, const Str
     if (vc == 512) {
         if ((reinterpret_cast<uintptr_t>(a.K) & 15) || (reinterpret_cast<uintptr_t>(a.Vt) & 15) || !a.redo)
             return hipErrorInvalidValue;
+#ifdef SDPA_ABLATIONS   // tools/ builds only ($SDPA_TUNE bit 12): the STREAM kernel on resident images, every ready word raised beforehand --
+        // what the persistent form's waits and extra arguments cost the kernel itself (profiles/r05/bf16_stream_kernel_resident_ab.log)
+        static StreamArgs self_st = {};
+        if (!st && (tune & 4096) && bf16_uses_tandem()) {
+            if (!self_st.flags) {
+                unsigned *w = nullptr;
+                int *stat = nullptr;
+                const size_t words = (size_t)(kStreamMaxChunks + kStreamMaxPieces) * kStreamFlagStride;
+                if (hipMalloc((void **)&w, words * sizeof(unsigned)) != hipSuccess || hipMalloc((void **)&stat, 64) != hipSuccess) return hipErrorOutOfMemory;
+                (void)hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(w), 0x5eed0001u, words);
+                (void)hipMemset(stat, 0, 64);
+                self_st.flags = w; self_st.gen = 0x5eed0001u; self_st.status = stat;
+                self_st.timeout_ticks = 100000000ull;
+            }
+            const int ntiles_ = (a.n_local + kKvTile - 1) / kKvTile;
+            self_st.n_chunks = 1;
+            self_st.chunk_end[0] = (ntiles_ + a.kv_splits - 1) / a.kv_splits;
+            self_st.q_piece_blocks = 64;
+            st = &self_st;
+        }
+#endif
 #ifdef SDPA_ABLATIONS
         if (kp == 512 && ((tune >> 8) & 15)) {                // timing-only ablations
             switch ((tune >> 8) & 15) {
