@@ -727,8 +727,9 @@ def test_converter_pool_on_the_numa_node_of_the_source_arrays_is_opt_in(engine, 
     pkg = engine(SDPA_HOST_CVT_PIN=1)
     b = pkg.attention(Q, K, V)
     t = pkg.last_timing()
-    if nodes > 1:
-        assert 0 <= t["host_convert_node"] < nodes, t
-    else:
+    # (a node when every sampled page of Q, K and V lives on the same one; -1 when they do not -- the arrays were written by a thread the
+    #  scheduler may have moved between them -- or when the host has one node)
+    assert -1 <= t["host_convert_node"] < max(nodes, 1), t
+    if nodes <= 1:
         assert t["host_convert_node"] == -1, t
     assert np.array_equal(a, b)
