@@ -215,3 +215,38 @@ def test_host_vt_on_a_pool_of_threads_is_the_single_thread_image(keys, cols, col
     assert lib.sdpa_host_cvt_vt(V.ctypes.data, many.ctypes.data, keys, keys_pad, cols, cols_pad, keys_pad, threads, 0) == 0
     assert np.array_equal(one, many)
     assert np.array_equal(one, _vt_reference(V, keys_pad, cols_pad, keys_pad))
+
+
+def test_host_vt_image_fuzz(pkg):
+    """seeded random shapes (keys, cols, pad rows, extra zero tiles, row stride, thread count, item size): the image is the numpy
+    restatement's, everything outside [0, keys_pad) x [0, cols_pad) is untouched -- 60 cases, special values included"""
+    import os
+    lib = pkg.load()
+    rng = np.random.default_rng(20260922)
+    old = os.environ.get("SDPA_HOST_CVT_ITEM_KB")
+    try:
+        for case in range(60):
+            keys = int(rng.integers(0, 700))
+            cols = int(rng.integers(1, 200))
+            cols_pad = cols + int(rng.integers(0, 70))
+            keys_pad = (keys + 31) // 32 * 32 + 32 * int(rng.integers(0, 3))
+            if keys_pad == 0:
+                keys_pad = 32
+            ldt = keys_pad + 32 * int(rng.integers(0, 3))
+            threads = int(rng.choice([1, 1, 2, 5]))
+            os.environ["SDPA_HOST_CVT_ITEM_KB"] = str(int(rng.choice([4, 64, 300])))
+            V = rng.normal(0, 3, (keys, cols))
+            if keys:
+                V.flat[rng.integers(0, V.size, min(V.size, 6))] = [0.0, -0.0, 1e-45, -3.0e38, 65504.0, 1.0 + 2.0 ** -9][:min(V.size, 6)]
+            img = np.full((cols_pad + 1, ldt), 0x5A5A, np.uint16)        # (+1 row: the converter must not write behind cols_pad)
+            rc = lib.sdpa_host_cvt_vt(V.ctypes.data if keys else None, img.ctypes.data, keys, keys_pad, cols, cols_pad, ldt, threads,
+                                      int(rng.choice([0, 1, 2, 4])))
+            assert rc == 0, (case, keys, cols)
+            want = _vt_reference(V, keys_pad, cols_pad, ldt)
+            assert np.array_equal(img[:cols_pad, :keys_pad], want[:, :keys_pad]), (case, keys, cols, cols_pad, keys_pad, ldt, threads)
+            assert (img[:cols_pad, keys_pad:] == 0x5A5A).all() and (img[cols_pad] == 0x5A5A).all(), (case, "wrote outside its range")
+    finally:
+        if old is None:
+            os.environ.pop("SDPA_HOST_CVT_ITEM_KB", None)
+        else:
+            os.environ["SDPA_HOST_CVT_ITEM_KB"] = old
