@@ -130,6 +130,21 @@ def test_tandem_kernel_loop_is_spill_free_and_reads_50_fragments_per_64_mfmas(bf
     assert sum(c.values()) <= 670, (sum(c.values()), c)
 
 
+def test_tandem_stream_kernel_loop_does_the_classic_loops_work(bf16_asm):
+    """The persistent form (round 5: the same text from sdpa_fwd_bf16_tandem.inc with waits for ready words) must pay for its waits
+    with scalar instructions only: per two steps the same 128 MFMAs, 100 fragment reads, 4 P stores, 32 DMA pieces, 4 barriers, 32
+    exponentials as the classic loop, no scratch, no accumulator tile through VGPRs -- the polling (a system-scope load, a sleep,
+    the acquire's invalidate) sits on a branch the steady state does not take."""
+    c = main_loop_mix(kernel_lines(bf16_asm, "fused_bf16_tandem_stream_kernelILi512E"))
+    classic = main_loop_mix(kernel_lines(bf16_asm, "fused_bf16_tandem_kernelILi512E"))
+    for k in ("v_mfma_f32_32x32x16_bf16", "ds_read_b128", "ds_write_b128", "global_load_lds_dwordx4", "s_barrier", "v_exp_f32"):
+        assert c[k] == classic[k], (k, c[k], classic[k])
+    assert sum(v for k, v in c.items() if k.startswith("scratch_")) == 0, c
+    assert c["v_accvgpr_read_b32"] == 0 and c["v_accvgpr_write_b32"] == 0, c
+    assert c["buffer_inv"] <= 2 and c["global_load_dword"] <= 4, c            # (the polls: once in the loop's text)
+    assert sum(c.values()) <= sum(classic.values()) + 90, (sum(c.values()), sum(classic.values()))
+
+
 @pytest.fixture(scope="module")
 def f32_asm(tmp_path_factory):
     if not os.path.exists(HIPCC):
@@ -275,8 +290,8 @@ def test_nothing_but_the_dma_asm_touches_m0(f32_asm, bf16_asm):
     than assumed: in every kernel with such a statement, no compiler-generated instruction reads
     or writes M0 at all -- there is nothing the DMA's leftover address could be mistaken for.  A compiler that starts
     using M0 in these kernels (LDS-direct loads, s_movrel, GWS) trips this test, and build() with it."""
-    names = [(f32_asm, r"fused_pipelined_(sk_)?kernelILi\d+ELi\d+E"),
-             (bf16_asm, r"fused_bf16_(wide|tandem|duo|pipe)_kernelI")]
+    names = [(f32_asm, r"fused_pipelined_(sk_|stream_)?kernelILi\d+ELi\d+E"),
+             (bf16_asm, r"fused_bf16_(wide|tandem|tandem_stream|duo|pipe)_kernelI")]
     seen = 0
     for lines, pat in names:
         for i, l in enumerate(lines):
