@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, call 15: (a) config 5 in bf16 at the boundary with the last 2048 keys as a chunk of their own ($SDPA_KV_TAIL_CHUNK) against
+# round 5, call 15 ($SDPA_KV_TAIL_CHUNK was an experiment that was NOT kept -- profiles/r05/config5_bf16_feed_analysis.log): (a) config 5 in bf16 at the boundary with the last 2048 keys as a chunk of their own ($SDPA_KV_TAIL_CHUNK) against
 # the 8192-key last chunk, interleaved; (b) tools/probes/d2h_pattern on the HIP runtime the Python processes load (PyTorch's bundled
 # ROCm 7.0.2 libamdhip64) -- the standalone probe (ROCm 7.2) had every device->host copy on the copy engine
 O=gpurun_out/r05_15; mkdir -p $O

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, call 27: does the one timed call of a fresh process run at the warm rate when prepare's clock warm-up ran on pseudo-random operands
+# round 5, call 27 (an experiment in sdpa_prepare that was NOT kept -- profiles/r05/cli_cold_prepare_experiments.log; $SDPA_PREPARE_WARM_DATA no longer exists): does the one timed call of a fresh process run at the warm rate when prepare's clock warm-up ran on pseudo-random operands
 # ($SDPA_PREPARE_WARM_DATA=1) instead of zeros?  the one-shot CLI cold at the metric shape and config 5 (bf16), interleaved
 O=gpurun_out/r05_27; mkdir -p $O
 R=$GRAFT_REPO_ROOT

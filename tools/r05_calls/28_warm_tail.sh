@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, call 28 / 29 (29: + the staging areas touched in prepare, $SDPA_PREPARE_TOUCH): a short second clock burst BEHIND prepare's small call ($SDPA_PREPARE_WARM_TAIL_MS) -- the one-shot CLI cold at the metric shape
+# round 5, calls 28 / 29 (experiments in sdpa_prepare that were NOT kept -- profiles/r05/cli_cold_prepare_experiments.log; the knobs below no longer exist) (29: + the staging areas touched in prepare, $SDPA_PREPARE_TOUCH): a short second clock burst BEHIND prepare's small call ($SDPA_PREPARE_WARM_TAIL_MS) -- the one-shot CLI cold at the metric shape
 O=gpurun_out/r05_29; mkdir -p $O
 R=$GRAFT_REPO_ROOT
 python - <<'PY'

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, call 30: early egress of the streamed bf16 launch (rows of a Q row piece leave when its workgroups have retired): its test, the streamed tests,
+# round 5, call 30 (the early-egress code this call measured was NOT kept -- profiles/r05/bf16_stream_kernel_resident_ab.log; the knob below no longer exists): early egress of the streamed bf16 launch (rows of a Q row piece leave when its workgroups have retired): its test, the streamed tests,
 # and config 5 in bf16 at the boundary with $SDPA_STREAM_EARLY_EGRESS=1 / 0, interleaved
 O=gpurun_out/r05_30; mkdir -p $O
 export TMPDIR=/tmp
