@@ -154,11 +154,11 @@ SDPA_API const char *sdpa_strerror(int code);
 SDPA_API const char *sdpa_version(void);
 /* Bumped whenever a struct of this header changes size or a documented behaviour changes; hosts compare it
  * with the SDPA_ABI_VERSION they were compiled against (the package's ctypes loader and both C hosts do). */
-#define SDPA_ABI_VERSION 5
+#define SDPA_ABI_VERSION 6
 SDPA_API int sdpa_abi_version(void);
 
 /* The launch paths read their environment knobs ($SDPA_STREAMK, $SDPA_SPLIT_MERGE, $SDPA_DKSPLIT_PIPE,
- * $SDPA_BF16_TANDEM) from ONE snapshot, taken at first use and by every host-level entry point on the
+ * from ONE snapshot, taken at first use and by every host-level entry point on the
  * calling thread: the launchers run on the engine's enqueue threads, and the C environment must not be
  * read there while the application may setenv().  A device-level host that changes one of these knobs
  * between launches calls this (from the thread that changed it, with no launch in flight elsewhere).      */
@@ -190,7 +190,7 @@ SDPA_API void sdpa_reload_env(void);
  * when a row maximum rises by more than 2^24), which spends that much of
  * fp32's exponent headroom: the un-normalised contrib of a row overflows for
  * |V|*n above ~2^104, where the reference's eager rescale would not.  The
- * bf16 duo and wide kernels keep NO reference exponent (P = 2^score) while
+ * bf16 duo and tandem kernels keep NO reference exponent (P = 2^score) while
  * the row's sum of 2^score stays inside [2^-80, 2^80] -- roughly every score
  * within |q.k/sqrt(dk)| <= 55; rows outside are recomputed by the rescaling
  * kernel, no loss: there contrib overflows for |V| above ~2^47.            */
@@ -250,7 +250,9 @@ SDPA_API void  sdpa_host_free(void *p);
 /* The host-side converter: `rows` rows of fp64 -> rows of an operand image, on the calling thread, with
  * the device converters' roundings bit for bit.  kind 0: float rows of `ld` floats, pad columns zero
  * (cvt_d2f_avx512, attention-mpi.c:31-64: vcvtpd2ps, 8 doubles at a time, where the CPU has AVX-512);
- * kind 1: bf16 rows, bf16((float)(x * mult)), both roundings to nearest even.  flags bit 0: the plain C
+ * kind 1: bf16 rows, bf16((float)(x * mult)), both roundings to nearest even; kind 2 (ABI 6): rows of the TILED K image of a
+ * dv > 256 shape -- kind 1's values with 16-byte chunk c of row r (counted from dst, which must be an image row that is a multiple
+ * of 16) stored at chunk position c ^ (r & min(15, ld/8 - 1)), ld = the padded dk.  flags bit 0: the plain C
  * rows instead of the AVX-512 ones; bit 1 / bit 2: streaming (non-temporal) stores for line-aligned
  * destination rows on / off (neither: the pool's default, $SDPA_HOST_CVT_NT) -- the same bytes either way.  This is what $SDPA_HOST_CVT=1 runs on a pool of host threads inside
  * sdpa_attention_f64 (the reference's own placement of the converts, :224-225, :303); it needs no GPU.  */
@@ -261,7 +263,8 @@ SDPA_API int sdpa_host_cvt_rows(const double *src, void *dst, long rows, int col
  * fed with): `keys` rows of V (fp64, `cols` columns) become the key positions [0, keys_pad) of an image whose rows are `ldt`
  * elements apart -- dst[c * ldt + p] = bf16((float)V[j][c]) with p = j with bits 2 and 3 swapped (each 16-key group is stored
  * 0-3, 8-11, 4-7, 12-15: one MFMA lane's eight keys are 16 contiguous bytes), zero for positions behind the last key (keys_pad: a
- * multiple of 32 >= keys), zero rows for c in [cols, cols_pad).  The device converter's image bit for bit; flags as
+ * multiple of 32 >= keys), zero rows for c in [cols, cols_pad).  cols > 256 (ABI 6): the TILED image instead -- dst = the block of
+ * the first key's tile, [keys_pad/32 tiles][cols_pad/512][512][32], ldt unused (see the device-level section).  The device converter's image bit for bit; flags as
  * sdpa_host_cvt_rows; threads <= 1: on the calling thread, threads > 1: on a pool of that many threads, in work items of whole
  * 32-key tiles -- the way sdpa_attention_f64 runs it.  The reference converts V on the host as well (cvt_d2f_avx512 at attention-mpi.c:225); needs no GPU.   */
 SDPA_API int sdpa_host_cvt_vt(const double *src, unsigned short *dst, long keys, long keys_pad, int cols, int cols_pad,
@@ -361,22 +364,39 @@ SDPA_API int sdpa_dev_finish_f64(const float *contrib, int ldo, const float *lsu
 /* ---- device level, bf16-input MFMA variant (BASELINE.json config 5) ---------- */
 /* Same stage as sdpa_dev_shard_partial_f32 with operands rounded to bf16 (RNE) and
  * fp32 accumulation; tolerance 1e-2*max(1,max|V|).  Operand images:
- *   Kb[n_local x ld]               bf16 row-major, ld = sdpa_dev_bf16_ld(dk) (dk padded to
- *                                  64/128/256/512), pad columns zero (sdpa_dev_cvt_d2bf);
- *   Qb[m x ld]                     the same layout, but holding bf16(Q * log2(e)/sqrtf(dk)): the
- *                                  softmax scale (attention-mpi.c:208) and the change of base for
- *                                  v_exp_f32 are folded into the operand BEFORE its one rounding
+ *   Qb[m x ld]                     bf16 row-major, ld = sdpa_dev_bf16_ld(dk) (dk padded to
+ *                                  64/128/256/512), pad columns zero, holding
+ *                                  bf16(Q * log2(e)/sqrtf(dk)): the softmax scale
+ *                                  (attention-mpi.c:208) and the change of base for v_exp_f32 are
+ *                                  folded into the operand BEFORE its one rounding
  *                                  (sdpa_dev_cvt_d2bf_q) -- the kernels' score chains deliver
  *                                  exp2-domain scores and a softmax weight costs one instruction;
- *   Vt[dvp x ldvt]                 bf16, V TRANSPOSED with the keys of a row permuted inside
- *                                  16-key groups: Vt[c*ldvt + sdpa_dev_bf16_kvpos(j)] = V[j][c],
- *                                  kvpos(j) = j with bits 2 and 3 swapped (group order 0-3, 8-11,
- *                                  4-7, 12-15: the eight keys one MFMA lane multiplies are then
- *                                  16 contiguous bytes);
- *                                  dvp = sdpa_dev_bf16_dvp(dv), ldvt = sdpa_dev_bf16_ldn(n_local)
- *                                  (n_local padded to 32), pads zero.
- * sdpa_dev_cvt_d2bf_q (Q), sdpa_dev_cvt_d2bf (K) and sdpa_dev_cvt_d2bf_t (V) write these images
- * from dense fp64.  dk <= 512, dv <= 1024.  contrib/lsum are those of the scores so computed,
+ *   K and V                        as operand IMAGES whose layout belongs to the kernel of the
+ *                                  shape's dv (ABI 6).  Write them with sdpa_dev_cvt_d2bf_k /
+ *                                  sdpa_dev_cvt_d2bf_v (or, on the host, sdpa_host_cvt_rows kind 1 / 2
+ *                                  and sdpa_host_cvt_vt); sizes: K ldn x ld elements, V dvp x ldn
+ *                                  elements, ldn = sdpa_dev_bf16_ldn(n_local) (n_local padded to
+ *                                  32), dvp = sdpa_dev_bf16_dvp(dv) -- ALLOCATE the pad rows of K.
+ *     dv <= 256 (sdpa_dev_bf16_tiled(dv) == 0), "row images":
+ *       Kb[n_local x ld]           row-major, pad columns zero;
+ *       Vt[dvp x ldvt]             V TRANSPOSED with the keys of a row permuted inside 16-key
+ *                                  groups: Vt[c*ldvt + sdpa_dev_bf16_kvpos(j)] = V[j][c], kvpos(j) =
+ *                                  j with bits 2 and 3 swapped (group order 0-3, 8-11, 4-7, 12-15:
+ *                                  the eight keys one MFMA lane multiplies are then 16 contiguous
+ *                                  bytes); ldvt = ldn, pads zero.
+ *     dv > 256 (== 1), "tiled images" (round 6): every 32-key tile is one contiguous block in the
+ *     byte order of the kernel's LDS buffers, so that its LDS-DMA pieces are lane-linear at both ends
+ *     (one scalar base per tile, immediates per piece -- DESIGN.md 4.2):
+ *       Kb[ldn x ld]               the rows above with 16-byte chunk c of row r stored at chunk
+ *                                  position c ^ (r & min(15, ld/8 - 1)); rows [n_local, ldn) are
+ *                                  read and masked (sdpa_dev_cvt_d2bf_k zeroes them);
+ *       Vt[ldn/32][dvp/512][512][32]  per key tile and 512-column chunk a block of 512 columns x
+ *                                  32 key positions (kvpos order), a column's 16-byte chunk q stored
+ *                                  at q ^ ((column >> 2) & 3); zero for keys >= n_local and
+ *                                  columns >= dv.  ldvt is not used (pass ldn).
+ * sdpa_dev_cvt_d2bf (plain rows) and sdpa_dev_cvt_d2bf_t (the V image by its arguments: tiled when
+ * cols > 256) remain; a K image for dv > 256 must come from sdpa_dev_cvt_d2bf_k.
+ * dk <= 512, dv <= 1024.  contrib/lsum are those of the scores so computed,
  * relative to lmax (natural-log units) as in the fp32 variant -- but lmax is here a REFERENCE
  * EXPONENT, not necessarily the row max: the fixed-reference kernels (dk, dv <= 256, and dv > 256)
  * return the power of two that puts lsum in [1, 2), so lmax + ln(lsum) is the row's log-sum-exp
@@ -392,6 +412,11 @@ SDPA_API int  sdpa_dev_cvt_d2bf_q(const double *src, void *dst, long rows, int d
                                   void *stream);
 SDPA_API int  sdpa_dev_cvt_d2bf_t(const double *src, void *dst, long rows, int cols, int cols_pad,
                                   long ldt, void *stream);
+/* ABI 6: the images of a (dk, dv) shape, in the layout its kernel reads.  K: `rows` rows of fp64 [rows x dk] into
+ * dst[ldn(rows) x ld(dk)] (pad rows zeroed for tiled images).  V: fp64 [rows x dv] into dst[dvp(dv) x ldn(rows)] elements.  */
+SDPA_API int  sdpa_dev_bf16_tiled(int dv);
+SDPA_API int  sdpa_dev_cvt_d2bf_k(const double *src, void *dst, long rows, int dk, int dv, void *stream);
+SDPA_API int  sdpa_dev_cvt_d2bf_v(const double *src, void *dst, long rows, int dv, void *stream);
 SDPA_API int    sdpa_dev_kv_splits_bf16(int m, int n_local, int dk, int dv);
 SDPA_API size_t sdpa_dev_workspace_bytes_bf16(int m, int n_local, int dk, int dv);
 SDPA_API int  sdpa_dev_shard_partial_bf16(const void *Qb, int ldq, const void *Kb, int ldk,

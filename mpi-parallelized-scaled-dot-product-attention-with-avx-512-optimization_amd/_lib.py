@@ -39,7 +39,7 @@ class SdpaTiming(ctypes.Structure):
                 ("host_convert_node", _c_int)]
 
 
-SDPA_ABI_VERSION = 5          # the SDPA_ABI_VERSION of include/sdpa_hip.h this binding was written against
+SDPA_ABI_VERSION = 6          # the SDPA_ABI_VERSION of include/sdpa_hip.h this binding was written against
 
 
 class SdpaError(RuntimeError):
@@ -95,6 +95,9 @@ _PROTOS = {
     "sdpa_dev_cvt_d2bf": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p]),
     "sdpa_dev_cvt_d2bf_q": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p]),
     "sdpa_dev_cvt_d2bf_t": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_long, _c_void_p]),
+    "sdpa_dev_bf16_tiled": (_c_int, [_c_int]),
+    "sdpa_dev_cvt_d2bf_k": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_void_p]),
+    "sdpa_dev_cvt_d2bf_v": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_void_p]),
     "sdpa_dev_kv_splits_bf16": (_c_int, [_c_int] * 4),
     "sdpa_dev_workspace_bytes_bf16": (_c_size_t, [_c_int] * 4),
     "sdpa_dev_shard_partial_bf16": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_long,

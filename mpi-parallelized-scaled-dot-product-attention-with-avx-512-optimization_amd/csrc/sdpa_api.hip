@@ -70,8 +70,6 @@ const LaunchKnobs *read_knobs() {
     k->split_merge_kernel = (v && strcmp(v, "kernel") == 0) ? 1 : 0;
     v = getenv("SDPA_DKSPLIT_PIPE");
     k->dksplit_pipe = !(v && *v) || atoi(v) != 0;
-    v = getenv("SDPA_BF16_TANDEM");
-    k->bf16_tandem = !(v && *v) || atoi(v) != 0;
     v = getenv("SDPA_STREAMK");
     k->streamk = (!(v && *v) || strcmp(v, "auto") == 0) ? -1 : (atoi(v) != 0 ? 1 : 0);
     return k;
@@ -136,7 +134,7 @@ extern "C" {
 #ifndef SDPA_BUILD_STAMP
 #define SDPA_BUILD_STAMP "hipcc unknown; src unknown"
 #endif
-const char *sdpa_version(void) { return "sdpa-hip 0.5 abi 5 (gfx950, f32 + bf16 MFMA; " SDPA_BUILD_STAMP ")"; }
+const char *sdpa_version(void) { return "sdpa-hip 0.6 abi 6 (gfx950, f32 + bf16 MFMA; " SDPA_BUILD_STAMP ")"; }
 int sdpa_abi_version(void) { return SDPA_ABI_VERSION; }
 
 void sdpa_reload_env(void) { sdpa::reload_launch_knobs(); }
@@ -254,17 +252,19 @@ int sdpa_dev_shard_partial_f32(const float *Qf, int ldq, const float *Kf, int ld
 }
 
 int sdpa_host_cvt_rows(const double *src, void *dst, long rows, int cols, int ld, int kind, double mult, int flags) {
-    if (rows < 0 || cols <= 0 || ld < cols || (kind != 0 && kind != 1)) return SDPA_EINVAL;
+    if (rows < 0 || cols <= 0 || ld < cols || kind < 0 || kind > 2) return SDPA_EINVAL;
+    if (kind == 2 && ld != sdpa::bf16_pad_dk(cols)) return SDPA_EINVAL;       // (the tiled K image: rows of the padded dk)
     if (rows == 0) return SDPA_OK;
     if (!src || !dst) return SDPA_EINVAL;
-    sdpa::host_convert_rows(src, dst, rows, cols, ld, kind == 0 ? sdpa::kCvtF32 : sdpa::kCvtBf16, kind == 0 ? 1.0 : mult,
-                            (flags & 1) != 0, (flags & 2) ? 1 : (flags & 4) ? 0 : -1);
+    sdpa::host_convert_rows(src, dst, rows, cols, ld, kind == 0 ? sdpa::kCvtF32 : kind == 1 ? sdpa::kCvtBf16 : sdpa::kCvtBf16Swz,
+                            kind == 0 ? 1.0 : mult, (flags & 1) != 0, (flags & 2) ? 1 : (flags & 4) ? 0 : -1);
     return SDPA_OK;
 }
 
 int sdpa_host_cvt_vt(const double *src, unsigned short *dst, long keys, long keys_pad, int cols, int cols_pad, long ldt, int threads,
                      int flags) {
     if (keys < 0 || cols <= 0 || cols_pad < cols || keys_pad < keys || keys_pad % 32 != 0 || ldt < keys_pad) return SDPA_EINVAL;
+    if (cols > 256 && cols_pad % 512 != 0) return SDPA_EINVAL;                 // (the tiled image: whole 512-column chunks)
     if (keys_pad == 0) return SDPA_OK;
     if ((!src && keys > 0) || !dst) return SDPA_EINVAL;
     if (threads <= 1) {
@@ -372,6 +372,27 @@ int sdpa_dev_cvt_d2bf(const double *src, void *dst, long rows, int cols, int ld,
     return SDPA_OK;
 }
 
+int sdpa_dev_bf16_tiled(int dv) { return dv <= 0 ? SDPA_EINVAL : (sdpa::bf16_tiled(dv) ? 1 : 0); }
+
+int sdpa_dev_cvt_d2bf_k(const double *src, void *dst, long rows, int dk, int dv, void *stream) {
+    if (rows < 0 || dk <= 0 || dk > 512 || dv <= 0 || dv > 1024) return SDPA_EINVAL;
+    if (rows == 0) return SDPA_OK;
+    if (!src || !dst) return SDPA_EINVAL;
+    SDPA_TRY(require_device());
+    HIP_TRY(sdpa::launch_cvt_d2bf_k(src, (unsigned short *)dst, rows, sdpa::bf16_tiled(dv) ? sdpa::bf16_pad_n(rows) : rows, dk, dv,
+                                    (hipStream_t)stream));
+    return SDPA_OK;
+}
+
+int sdpa_dev_cvt_d2bf_v(const double *src, void *dst, long rows, int dv, void *stream) {
+    if (rows < 0 || dv <= 0 || dv > 1024) return SDPA_EINVAL;
+    if (!dst || (rows > 0 && !src)) return SDPA_EINVAL;
+    SDPA_TRY(require_device());
+    HIP_TRY(sdpa::launch_cvt_d2bf_t(src, (unsigned short *)dst, rows, dv, sdpa::bf16_pad_dv(dv), sdpa::bf16_pad_n(rows),
+                                    (hipStream_t)stream));
+    return SDPA_OK;
+}
+
 int sdpa_dev_cvt_d2bf_q(const double *src, void *dst, long rows, int dk, int ld, void *stream) {
     if (rows < 0 || dk <= 0 || dk > 512 || ld != sdpa::bf16_pad_dk(dk)) return SDPA_EINVAL;
     if (rows == 0) return SDPA_OK;
@@ -387,6 +408,7 @@ int sdpa_dev_cvt_d2bf_t(const double *src, void *dst, long rows, int cols, int c
     // keys are permuted inside 16-key groups and written in 32-key blocks: a row stride that is
     // not a multiple of 32 would let the last block spill into the next Vt row
     if (ldt % 32 != 0) return SDPA_EINVAL;
+    if (sdpa::bf16_tiled(cols) && cols_pad % 512 != 0) return SDPA_EINVAL;    // (the tiled image: whole 512-column chunks)
     if (!dst || (rows > 0 && !src)) return SDPA_EINVAL;
     SDPA_TRY(require_device());
     HIP_TRY(sdpa::launch_cvt_d2bf_t(src, (unsigned short *)dst, rows, cols, cols_pad, ldt,

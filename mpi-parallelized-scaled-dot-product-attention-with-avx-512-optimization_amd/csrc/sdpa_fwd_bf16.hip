@@ -45,9 +45,11 @@ namespace sdpa {
 #ifdef SDPA_DMA_ASSERT
 // a DMA source of 16 bytes must lie inside the K image or inside the Vt image of the launch
 __device__ inline void bf16_audit_src(const Bf16Args &a, const char *src) {
-    const char *k0 = reinterpret_cast<const char *>(a.K), *k1 = k0 + (size_t)a.n_local * a.ldk * 2;
+    // (tiled images hold whole 32-key tiles of K rows; both Vt layouts hold padded dv x padded keys elements)
+    const size_t npad = ((size_t)a.n_local + 31) / 32 * 32;
+    const char *k0 = reinterpret_cast<const char *>(a.K), *k1 = k0 + (a.tiled ? npad : (size_t)a.n_local) * a.ldk * 2;
     const int ch = a.dv <= 64 ? 64 : a.dv <= 128 ? 128 : a.dv <= 256 ? 256 : 512;
-    const char *v0 = reinterpret_cast<const char *>(a.Vt), *v1 = v0 + (size_t)((a.dv + ch - 1) / ch * ch) * a.ldvt * 2;
+    const char *v0 = reinterpret_cast<const char *>(a.Vt), *v1 = v0 + (size_t)((a.dv + ch - 1) / ch * ch) * (a.tiled ? npad : (size_t)a.ldvt) * 2;
     const bool in_k = src >= k0 && src + 16 <= k1, in_v = src >= v0 && src + 16 <= v1;
     if (!(in_k || in_v) || (reinterpret_cast<unsigned long long>(src) & 15ull) != 0) atomicAdd(&g_bf16_audit[0], 1ull);
 }
@@ -199,12 +201,15 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
     float m_ref = 0.f, max_rel = 0.f, l_run = 0.f;       // exp2 domain, see the fp32 kernel
 
     // ---- K staging by LDS-DMA
+    // (as the redo pass of a dv > 256 shape -- DVC = 256 -- this kernel reads the TILED images, sdpa_internal.h: the K rows carry
+    //  their chunk swizzle already, the Vt tiles are contiguous blocks)
+    const bool tiled = DVC == 256 && a.tiled != 0;
     unsigned koff[KPW];
 #pragma unroll
     for (int j = 0; j < KPW; ++j) {
         const int row = (wave * KPW + j) * RPP + lane / KCH;
         const int cpos = lane % KCH;
-        koff[j] = (unsigned)(row * DK * 2 + ((cpos ^ (row & SWZ)) << 4));
+        koff[j] = (unsigned)(row * DK * 2 + ((tiled ? cpos : (cpos ^ (row & SWZ))) << 4));
     }
     const unsigned lds_base = __builtin_amdgcn_readfirstlane(
         (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)smem16);
@@ -244,11 +249,15 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
         const int idx = tid + 256 * i;
-        voff[i] = (unsigned)(((size_t)(dv0 + idx / 4) * a.ldvt + 8 * (idx % 4)) * 2u);
+        const int vrow = dv0 + idx / 4, vch = idx % 4;
+        voff[i] = tiled ? (unsigned)(((size_t)(vrow >> 9) * (512 * kKvTile) + (size_t)(vrow & 511) * kKvTile + ((vch ^ ((vrow >> 2) & 3)) << 3)) * 2u)
+                        : (unsigned)(((size_t)vrow * a.ldvt + 8 * vch) * 2u);
     }
+    const size_t vtile_stride = (size_t)((a.dv + 511) / 512 * 512) * kKvTile;      // tiled: elements between two key tiles
     auto v_gload = [&](int tile) __attribute__((always_inline)) {
         if constexpr (ABL & 1) return;
-        const char *vb = reinterpret_cast<const char *>(a.Vt + kv_begin + tile * kKvTile);
+        const char *vb = tiled ? reinterpret_cast<const char *>(a.Vt + (size_t)(kv_begin / kKvTile + tile) * vtile_stride)
+                               : reinterpret_cast<const char *>(a.Vt + kv_begin + tile * kKvTile);
 #pragma unroll
         for (int i = 0; i < VPT; ++i) vreg[i] = *reinterpret_cast<const u32x4 *>(vb + voff[i]);
     };
@@ -491,33 +500,26 @@ __global__ __launch_bounds__(256, (DK + 2 * DVC > 512) ? 1 : 2) void fused_bf16_
 }
 
 // ---------------------------------------------------------------------------
-// Wide variant (dv > 256): one wave per SIMD, the wave's whole 32 x 512 fp32 O^T tile in the
-// accumulator file (all 256 AGPRs), so dv up to 512 is ONE chunk and S^T is computed once.
-//   * the 512-register mode of hipcc puts every MFMA-builtin result in AGPRs; with O filling them
-//     the score tile must be a VGPR value, so the QK^T chain is issued as inline-asm MFMAs with
-//     VGPR C/D operands (first link with the inline constant 0 as C).  The compiler does not see
-//     an MFMA in an asm statement and inserts no MFMA->VALU wait states for it: the first VALU
-//     read of the score tile is placed four MFMAs + four LDS reads (>= 11 issue slots) behind the
-//     last link, or behind an explicit s_nop pair (prologue, ragged mask, tail steps).
-//   * O is touched by nothing but MFMAs between the zero-fill and the epilogue.  Any VALU access
-//     to those 256 registers in or around the loop -- a rescale on a never-taken branch, an early
-//     exit -- makes hipcc copy and spill accumulator tiles on the hot path.  So the kernel has NO
-//     rescale: the reference exponent is fixed by the first tile, a wave whose later row max
-//     exceeds it by more than 2^32 stamps its (q block, split) flag with the launch's generation number
-//     (nothing to clear beforehand), and the launcher runs the general
-//     kernel (256-column chunks, in-loop rescale) behind this one over the flagged blocks only.
-//   * K (three buffers) and Vt (two) arrive by LDS-DMA issued piece by piece between MFMAs, one
-//     barrier per tile in the middle of the step; no staging registers.  Vt rows are 64 bytes
-//     per tile (32 keys); 16-byte chunk c of dv row r sits at position c ^ ((r >> 2) & 3), which
-//     makes the P.V operand read -- one ds_read_b128 per lane per MFMA thanks to the kvpos() key
-//     order -- conflict-free across each 16-lane group.  160 KiB of LDS at dk = 512.
-//   * all softmax VALU work of tile t+1 runs under step t's P.V MFMAs (independent
-//     accumulators), never beside the dependent score chain; one score tile is live.
-//   * per step and wave at d = 512: 32 + 32 MFMAs, ~75 VALU instructions, 64 ds_read_b128,
-//     16 DMA pieces.  Measured (BASELINE config 5): 4.0 ms = 1.18 PFLOP/s; the MFMA skeleton alone
-//     (no LDS, no DMA, no VALU) takes 2.95 ms = 1.65 PFLOP/s, which is what this part sustains on
-//     v_mfma_f32_32x32x16_bf16 with toggling operands at all (tools/probes/mfma_probe.hip:
-//     2.2 PFLOP/s with constant operands, 1.66-1.80 with random ones -- power, not issue).
+// dv > 256 (BASELINE config 5): the tandem kernel, sdpa_fwd_bf16_tandem.inc (included below, twice).  One wave per
+// SIMD; the pair's 64 x 256 fp32 O^T tiles fill the accumulator file (all 256 AGPRs), so the value columns of a
+// 512-wide chunk are ONE pass and S^T is computed once.  What its text rests on:
+//   * the 512-register mode of hipcc puts every MFMA-builtin result in AGPRs; with O filling them the score tile
+//     must be a VGPR value, so the QK^T chain is issued as inline-asm MFMAs with VGPR C/D operands (first link
+//     with the inline constant 0 as C).  The compiler does not see an MFMA in an asm statement and inserts no
+//     MFMA->VALU wait states for it: the first VALU read of the score tile is placed >= 8 MFMAs behind the last
+//     link, or behind an explicit s_nop pair (prologue, ragged mask, tail steps).
+//   * O is touched by nothing but MFMAs between the zero-fill and the epilogue.  Any VALU access to those 256
+//     registers in or around the loop -- a rescale on a never-taken branch, an early exit -- makes hipcc copy and
+//     spill accumulator tiles on the hot path.  So the kernel has NO rescale and no row max: P = 2^score, a row whose
+//     sum leaves [2^-80, 2^80] stamps its (q block, split) flag with the launch's generation number (nothing to
+//     clear beforehand), and the launcher runs the general kernel (256-column chunks, in-loop rescale) behind this
+//     one over the flagged blocks only.
+//   * K and Vt (two LDS buffers each) arrive by LDS-DMA from the TILED images (sdpa_internal.h), issued piece by
+//     piece between MFMAs.  Vt rows are 64 bytes per tile (32 keys); 16-byte chunk c of dv row r sits at position
+//     c ^ ((r >> 2) & 3), which makes the P.V operand read -- one ds_read_b128 per lane per MFMA thanks to the
+//     kvpos() key order -- conflict-free across each 16-lane group.
+//   * the ceiling: the MFMA skeleton alone (no LDS, no DMA, no VALU) runs at 1.65-1.87 PFLOP/s with toggling operands
+//     (tools/probes/mfma_probe.hip: 2.2 with constant ones) -- the part clocks to its power budget.
 // ---------------------------------------------------------------------------
 // hipcc does not see an MFMA inside an asm statement, so its hazard recogniser inserts none of the
 // wait states an MFMA needs.  Two of them lead every statement: whatever VALU instruction the
@@ -556,430 +558,39 @@ __device__ __forceinline__ float halfwave_max(float x) {
     return fmaxf(lo, up);
 }
 
-// tandem kernel schedule knobs (tools/build_variant.sh A/Bs)
+// tandem kernel schedule knobs (tools/build_variant.sh A/Bs; the defaults are what profiles/r06/bf16_tiled_ab.log measured)
 #ifndef SDPA_TANDEM_KD
-#define SDPA_TANDEM_KD 3
+#define SDPA_TANDEM_KD 3              // K fragment ring depth
 #endif
 #ifndef SDPA_TANDEM_VD
-#define SDPA_TANDEM_VD 4
+#define SDPA_TANDEM_VD 4              // Vt fragment ring depth
 #endif
 #ifndef SDPA_TANDEM_GROUP
 #define SDPA_TANDEM_GROUP 2
 #endif
+#ifndef SDPA_TANDEM_XA
+#define SDPA_TANDEM_XA 3              // chain links issued behind [B]'s first fragment reads
+#endif
+#ifndef SDPA_TANDEM_XB
+#define SDPA_TANDEM_XB 4              // P.V MFMAs issued behind the step's barrier
+#endif
 // tools/build_variant.sh -DSDPA_TANDEM_ABL=bits: TIMING-ONLY ablations of the tandem kernel's steady-state loop (results
 // are wrong), never in the shipped library: 1 = no softmax VALU (exp2 / row sum / pack), 2 = no LDS fragment reads
 // (operands taken from the Q registers), 4 = no LDS-DMA issue in the loop (the prologue's tiles stay in LDS),
-// 8 = no barriers, 16 = no P exchange.  profiles/r04/bf16_tandem_ablations.log
+// 8 = no barriers, 16 = no P exchange.  -DSDPA_TANDEM_STAMP=1: s_memtime stamps per step, written over lsum (tools/gpu_bf16_ab.py)
 #ifndef SDPA_TANDEM_ABL
 #define SDPA_TANDEM_ABL 0
 #endif
-// -DSDPA_TANDEM_KIMM=0: the steady-state K pieces with per-piece scalar address arithmetic again (rounds 1-3), for the A/B
-#ifndef SDPA_TANDEM_KIMM
-#define SDPA_TANDEM_KIMM 1
+#ifndef SDPA_TANDEM_STAMP
+#define SDPA_TANDEM_STAMP 0
 #endif
-// -DSDPA_TANDEM_STAGGER=1 (round 5): the four waves of a workgroup leave every barrier in lockstep and would issue their
-// LDS-DMA pieces in the SAME MFMA gaps -- four 1-KiB pieces meeting at the CU's one vector-memory path, each waiting for the
-// others with its wave's MFMA issue stalled behind it.  Staggered, wave w issues in gap (g + w) % 4 of every four: the
-// steady-state loop exists once per wave (a scalar branch on the wave index picks it), the work and its order per
-// accumulator are unchanged (bit-identical results)
-#ifndef SDPA_TANDEM_STAGGER
-#define SDPA_TANDEM_STAGGER 0
-#endif
-// -DSDPA_TANDEM_SKEW=n (experiment): behind every barrier wave w idles w * n * 16 cycles, so that the four waves run the SAME
-// code n * 16 cycles apart (the stagger without four copies of the loop)
-#ifndef SDPA_TANDEM_SKEW
-#define SDPA_TANDEM_SKEW 0
-#endif
-#ifndef SDPA_TANDEM_BLOCKSPLIT
-#define SDPA_TANDEM_BLOCKSPLIT 1
-#endif
-#ifndef SDPA_TANDEM_PIN
-#define SDPA_TANDEM_PIN SDPA_TANDEM_STAGGER   // the accumulators are pinned to the accumulator file again at the loop's entry
-#endif
-#ifndef SDPA_TANDEM_VSHIFT
-#define SDPA_TANDEM_VSHIFT 1          // wave w's Vt pieces go into gap (VSHIFT + w) % 4 of every four P.V MFMAs
-#endif
-#ifndef SDPA_TANDEM_KIMM_LDS_PER_PIECE
-#define SDPA_TANDEM_KIMM_LDS_PER_PIECE 0
-#endif
-// which kernel dv > 256 takes when $SDPA_BF16_TANDEM is not set (0 = wide, 1 = tandem)
-#ifndef SDPA_BF16_TANDEM_DEFAULT
-#define SDPA_BF16_TANDEM_DEFAULT 1
-#endif
-
-// fragment prefetch depths (K ring under the score chain, Vt ring under the P.V MFMAs)
-#ifndef SDPA_WIDE_KD
-#define SDPA_WIDE_KD 3
-#endif
-#ifndef SDPA_WIDE_VD
-#define SDPA_WIDE_VD 2
-#endif
-
-// experiment switch (tools/build_variant.sh): which of the in-loop O pins of the wide kernel are active
-#ifndef SDPA_WIDE_PINMASK
-#define SDPA_WIDE_PINMASK 0x0
-#endif
-#define PIN_O_IN_LOOP(n) do { if constexpr ((SDPA_WIDE_PINMASK >> (n)) & 1) pin_o(); } while (0)
-template <int DK, int ABL = 0>
-__global__ __launch_bounds__(256, 1) void fused_bf16_wide_kernel(
-    Bf16Args a, int kv_per_split, int n_qblocks, int n_chunks, float scale) {
-    SDPA_AUDIT_LAUNCH(g_bf16_audit);
-    constexpr int DVC = 512;
-    constexpr int NKS = DK / 16;               // QK^T k-steps = MFMAs per score tile
-    constexpr int NT = DVC / 32;               // 32-row blocks of O^T
-    constexpr int KCH = DK / 8;                // 16-byte chunks per K row
-    constexpr int KTILE = kKvTile * DK;        // bf16 elements, unpadded (swizzled)
-    constexpr int VTILE = DVC * kKvTile;       // bf16 elements: 64-byte rows, swizzled
-    constexpr int KPW = (kKvTile * KCH / 64) / 4;   // 1-KiB DMA pieces per wave per K tile
-    constexpr int RPP = 64 / KCH > 0 ? 64 / KCH : 1; // K rows per DMA piece
-    constexpr int VPW = (DVC * 4 / 64) / 4;         // 1-KiB DMA pieces per wave per Vt tile (16 rows each)
-    constexpr int SWZ = KCH >= 16 ? 15 : KCH - 1;
-    static_assert(KCH >= 8 && KPW >= 1, "DK must be 64..512");
-
-    extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
-    unsigned short *const Ks = smem16;                    // [3][KTILE]
-    unsigned short *const Vs = smem16 + 3 * KTILE;        // [2][VTILE]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31;
-    const int hi = lane >> 5;
-
-    int work = xcd_remap_b(blockIdx.x, gridDim.x);
-    const int qblock = work % n_qblocks;
-    work /= n_qblocks;
-    const int chunk = work % n_chunks;
-    const int split = work / n_chunks;
-    const int qrow = qblock * kQRowsPerBlock + wave * 32 + li;
-    const int dv0 = chunk * DVC;
-
-    const int kv_begin = split * kv_per_split;
-    const int kv_end = min(a.n_local, kv_begin + kv_per_split);
-    const int T = kv_end > kv_begin ? (kv_end - kv_begin + kKvTile - 1) / kKvTile : 0;
-    // the Q image is pre-multiplied by log2(e)/sqrtf(dk) by its converter (sdpa_dev_cvt_d2bf_q), so
-    // the MFMA chains deliver exp2-domain scores: the multiplier of the softmax argument is 1
-    (void)scale;
-
-    u32x4 qf[NKS];
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        if (qrow < a.m)
-            qf[ks] = *reinterpret_cast<const u32x4 *>(a.Q + (size_t)qrow * DK + 16 * ks + 8 * hi);
-        else
-            qf[ks] = u32x4{0u, 0u, 0u, 0u};
-    }
-
-    f32x16 oacc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
-    auto pin_o = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt) asm volatile("" : "+a"(oacc[tt]));
-    };
-    pin_o();
-    // Reference exponent ZERO: P = exp2(score), nothing else per element (the Q image carries
-    // log2e/sqrt(dk)).  No row max is tracked: the row sum tells after the last tile whether the row
-    // stayed in range (redo flag) and which power of two to fold out.  VALU issue does not overlap
-    // MFMA issue on a SIMD (profiles/r02/mfma_valu_overlap_bf16.log): every VALU op is matrix-pipe time.
-    float l_run = 0.f;                                    // this half-wave's share of the row sum
-
-    // ---- K and Vt staging by LDS-DMA
-    const unsigned lds_base = __builtin_amdgcn_readfirstlane(
-        (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)smem16);
-    // M0 (the LDS destination of a DMA) is written without save/restore here: hipcc treats M0 as
-    // reserved and re-initialises it next to each of its own uses, and every instruction issued by
-    // the single wave of a SIMD counts in this kernel.  One independent instruction has to sit
-    // between the M0 write and the load that reads it (s_nop, or the address XOR below).
-    auto dma_piece = [&](const char *gbase, unsigned lane_off, unsigned lds_byte) __attribute__((always_inline)) {
-        SDPA_BF16_AUDIT(a, gbase + lane_off);
-        if constexpr (ABL & 1) return;
-        asm volatile("s_mov_b32 m0, %1\n\t"
-                     "s_nop 0\n\t"
-                     "global_load_lds_dwordx4 %0, %2"
-                     :
-                     : "v"(lane_off), "s"(lds_byte), "s"(gbase)
-                     : "memory" SDPA_M0_CLOBBER);
-    };
-    // same, lane offset = lane_part ^ swz computed in the wait slot
-    auto dma_piece_xor = [&](const char *gbase, unsigned lane_part, unsigned swz, unsigned lds_byte) __attribute__((always_inline)) {
-        SDPA_BF16_AUDIT(a, gbase + (lane_part ^ swz));
-        if constexpr (ABL & 1) return;
-        unsigned off;
-        asm volatile("s_mov_b32 m0, %2\n\t"
-                     "v_xor_b32 %0, %3, %1\n\t"
-                     "global_load_lds_dwordx4 %0, %4"
-                     : "=&v"(off)
-                     : "v"(lane_part), "s"(lds_byte), "s"(swz), "s"(gbase)
-                     : "memory" SDPA_M0_CLOBBER);
-    };
-    // K tile: piece p (1 KiB of LDS) = RPP rows; lane -> row p*RPP + lane/KCH, LDS chunk position
-    // lane%KCH, which holds global chunk (lane%KCH) ^ (row & SWZ).  Only the per-lane part of the
-    // address lives in a register: the piece's row base goes into the scalar base pointer and the
-    // row-dependent swizzle bits are XORed in at issue (wave-uniform, one VALU op).
-    const unsigned klane = (unsigned)((lane / KCH) * DK * 2 + (((lane % KCH) ^ ((lane / KCH) & SWZ)) << 4));
-    // One K piece (j of this wave's KPW) of tile `tile` into K buffer `buf` (both wave-uniform
-    // run-time values).  Rows past the shard's end re-read its last row (finite data; their
-    // scores are masked); with one row per piece (DK = 512) that clamp is scalar.
-    auto dma_k_piece = [&](int tile, int buf, int j) __attribute__((always_inline)) {
-        const int base = kv_begin + tile * kKvTile;
-        const int last = kv_end - 1 - base;
-        const char *kb = reinterpret_cast<const char *>(a.K + (size_t)base * DK);
-        const int row0 = (wave * KPW + j) * RPP;                  // wave-uniform, a multiple of RPP:
-        const unsigned swz = (unsigned)((row0 & SWZ) << 4);       // (row0 + x) & SWZ == (row0 & SWZ) ^ x
-        const unsigned dst = lds_base + (unsigned)(buf * KTILE * 2 + (wave * KPW + j) * 1024);
-        if constexpr (RPP == 1) {
-            dma_piece_xor(kb + (size_t)min(row0, last) * (DK * 2), klane, swz, dst);
-        } else {
-            unsigned off;                                         // volatile: not hoisted into KPW live registers
-            asm volatile("v_xor_b32 %0, %1, %2" : "=v"(off) : "s"(swz), "v"(klane));
-            const unsigned row = (unsigned)min(row0 + (int)(lane / KCH), last);
-            dma_piece(kb, row * (DK * 2) + (off % (DK * 2)), dst);
-        }
-    };
-    // Vt tile: piece p = 16 dv rows x 64 bytes; lane -> row p*16 + lane/4, LDS chunk position
-    // lane%4, which holds global chunk (lane%4) ^ ((row >> 2) & 3) = (lane%4) ^ ((lane >> 4) & 3).
-    // Rows past dv and keys past n_local are zero in the image, so no clamps.
-    const unsigned vlane = (unsigned)((size_t)(lane >> 2) * a.ldvt * 2u) + (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
-    auto dma_v_piece = [&](int tile, int buf, int j) __attribute__((always_inline)) {
-        const char *vb = reinterpret_cast<const char *>(a.Vt + kv_begin + tile * kKvTile);
-        dma_piece(vb + (size_t)(dv0 + (wave * VPW + j) * 16) * a.ldvt * 2u, vlane,
-                  lds_base + (unsigned)(3 * KTILE * 2 + buf * VTILE * 2 + (wave * VPW + j) * 1024));
-    };
-    // Wait until at most `KEEP` of this wave's DMA pieces are in flight (they retire in issue
-    // order), then meet the other waves: everything older is in LDS for everybody.
-    auto stage_fence = [&](auto keep) __attribute__((always_inline)) {
-        constexpr int KEEP = decltype(keep)::value;
-        if constexpr (ABL & 8) return;
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
-        __syncthreads();
-    };
-
-    // K fragment byte addresses inside a K buffer (chunk 2ks+hi of row li, un-swizzled)
-    constexpr int NKA = NKS < 8 ? NKS : 8;
-    unsigned kaddr[NKA];
-#pragma unroll
-    for (int u = 0; u < NKA; ++u) kaddr[u] = (unsigned)(li * DK * 2 + (((2 * u + hi) ^ (li & SWZ)) << 4));
-    // the K buffer being read rotates through three: its byte offset lives IN kaddr[] (advanced
-    // in place once per step), so a fragment read is still one ds_read_b128 with an immediate
-    auto kfrag = [&](int ks) __attribute__((always_inline)) -> u32x4 {
-        if constexpr (ABL & 2) return qf[(ks + 1) % NKS];
-        return *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(Ks) +
-                                                kaddr[ks % NKA] + (ks / NKA) * 256);
-    };
-    // Vt fragment: keys 16h + {4hi..+3, 8+4hi..+3} of dv row 32tt + li = chunk 2h+hi of that row
-    unsigned vaddr[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) vaddr[h] = (unsigned)(li * 64 + (((2 * h + hi) ^ ((li >> 2) & 3)) << 4));
-    auto vfrag = [&](int buf, int slot) __attribute__((always_inline)) -> u32x4 {
-        const int h = slot / NT, tt = slot % NT;
-        if constexpr (ABL & 2) return qf[(tt + h) % NKS];
-        return *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(Vs + buf * VTILE) +
-                                                vaddr[h] + tt * 2048);
-    };
-    // the caller guarantees the MFMA chain that wrote sx has retired (mfma_result_fence / slots)
-    auto mask_ragged = [&](f32x16 &sx, int tile) __attribute__((always_inline)) {
-        const int valid = kv_end - (kv_begin + tile * kKvTile);
-        if (valid < kKvTile) {
-            mfma_result_fence(sx);
-            const int vh = valid - 4 * hi;                 // compare against literals: no 16 hoisted row indices
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (crow16(r, 0) >= vh) sx[r] = -INFINITY;
-        }
-    };
-    // Pipeline of one step t (tile t is "current", t+1 "next"), one barrier per step:
-    //   [A] S^T(t+1) = K(t+1).Q^T, a dependent chain of VGPR-form MFMAs, with nothing beside it
-    //       but fragment reads and the DMA issue of K(t+3): VALU work next to a DEPENDENT MFMA
-    //       chain delays the next link (the wave issues in order), next to independent MFMAs it
-    //       is nearly free (tools/probes/mfma_probe.hip)
-    //   fence: all DMA older than this step's K pieces has landed (K(t+2), Vt(t)) + barrier
-    //   [B] O^T += Vt(t).P(t)^T, 32 independent MFMAs  ||  all softmax VALU work of tile t+1
-    //       (exp2, row sum, bf16 pack -> P(t+1) for the next step; row max)  ||  DMA issue of Vt(t+1)
-    // P needs no row max (fixed reference exponent), so the score tile is dead after [B]: one
-    // score tile and two packed P tiles are live, not two score tiles.
-    // K has three buffers (K(t+3) lands while K(t+1) is read and K(t+2) waits), Vt two (Vt(t+1)
-    // is issued behind the barrier that ends every wave's reads of Vt(t-1)); DMA pieces are
-    // issued one at a time between MFMAs, so their scalar set-up hides in the matrix pipe's shadow.
-    // kr / kw: K buffer read in this step / written by this step's DMA (wave-uniform, rotating).
-    // returns true (wave-uniform) when the tile scored in this step does not fit the reference exponent
-    // `fenced`: put the explicit MFMA-result fence behind the score chain.  The steady-state loop
-    // does not need it (reads are placed >= 11 issue slots later and hipcc leaves that code
-    // alone); the tail steps do, because hipcc spills around them and may touch the tile at once.
-    int kr = 1, kw = 0;
-    f32x16 sx;                                             // the score tile
-    // exp2 in place, issued one element before its row-sum add and bf16 pack: a transcendental's result
-    // is never read by the next instruction
-    // (the packed pair goes straight into its word of the P operand: no staging array to keep alive)
-    auto p_elem = [&](int r, u32x4 (&pout)[2]) __attribute__((always_inline)) {
-        asm volatile("v_exp_f32 %0, %0" : "+v"(sx[r]));
-        if (r >= 1) {
-            asm volatile("v_add_f32 %0, %0, %1" : "+v"(l_run) : "v"(sx[r - 1]));   // pinned: hipcc sinks the adds into one chain
-            if (((r - 1) & 1) == 1) pout[((r - 1) >> 1) / 4][((r - 1) >> 1) % 4] = bpin_pack(sx[r - 2], sx[r - 1]);
-        }
-    };
-    auto p_close = [&](u32x4 (&pout)[2]) __attribute__((always_inline)) {      // element 15, >= 1 instruction behind its exp2
-        asm volatile("v_add_f32 %0, %0, %1" : "+v"(l_run) : "v"(sx[15]));
-        pout[1][3] = bpin_pack(sx[14], sx[15]);
-    };
-    auto step = [&](auto has_next, auto fenced, const u32x4 (&pb)[2], u32x4 (&pn)[2], int t) __attribute__((always_inline)) {
-        constexpr bool HAS_NEXT = decltype(has_next)::value;
-        constexpr bool FENCED = decltype(fenced)::value;
-        const int vbuf = t & 1;
-        PIN_O_IN_LOOP(1);
-        if constexpr (HAS_NEXT) {
-            // [A]
-            const int tk = min(t + 3, T - 1);              // past the end: a harmless reload into a free buffer
-            constexpr int KD = NKS < SDPA_WIDE_KD ? NKS : SDPA_WIDE_KD;
-            u32x4 kq[KD];
-#pragma unroll
-            for (int i = 0; i < KD; ++i) kq[i] = kfrag(i);
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                const u32x4 kf = kq[ks % KD];
-                __builtin_amdgcn_sched_barrier(0);
-                if (ks == 0) mfma_bf16_vgpr_first(sx, kf, qf[0]);
-                else mfma_bf16_vgpr(sx, kf, qf[ks]);
-                if (ks + KD < NKS) kq[ks % KD] = kfrag(ks + KD);
-                if (ks % 4 == 0) dma_k_piece(tk, kw, ks / 4);      // NKS / KPW == 4 for every DK
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (FENCED) mfma_result_fence(sx);
-            stage_fence(std::integral_constant<int, KPW>());
-        } else {
-            stage_fence(std::integral_constant<int, 0>());
-        }
-        PIN_O_IN_LOOP(2);
-
-        // [B]
-        if constexpr (HAS_NEXT && (FENCED || SDPA_BF16_MASK_EVERY_STEP)) mask_ragged(sx, t + 1);    // (only a fenced step scores the last tile)
-        constexpr int SLOTS = 2 * NT;                     // P.V MFMAs of this step
-        constexpr int VD = SDPA_WIDE_VD;                   // V fragment prefetch depth
-        // next step reads the next K buffer: advance the fragment addresses in place
-        const int kr_next = kr == 2 ? 0 : kr + 1;
-        const unsigned kstep = (unsigned)((kr_next - kr) * KTILE * 2);
-        u32x4 vq[VD];
-#pragma unroll
-        for (int i = 0; i < VD; ++i) vq[i] = vfrag(vbuf, i);
-#pragma unroll
-        for (int slot = 0; slot < SLOTS; ++slot) {
-            const int tt = slot % NT, h = slot / NT;
-            const u32x4 vf = vq[slot % VD];
-            __builtin_amdgcn_sched_barrier(0);
-            oacc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
-                                                               __builtin_bit_cast(bf16x8, pb[h]),
-                                                               oacc[tt], 0, 0, 0);
-            if (slot + VD < SLOTS) vq[slot % VD] = vfrag(vbuf, slot + VD);
-            if constexpr (HAS_NEXT) {
-                if (slot % 4 == 1) dma_v_piece(t + 1, vbuf ^ 1, slot / 4);       // VPW == 8 pieces over 32 slots
-                // first read of the score tile: >= 11 issue slots (the MFMA->VALU requirement for an
-                // 8-pass MFMA) behind the chain's last link
-                if constexpr (!(ABL & 4)) {
-                    if (slot >= 12 && slot < 28) p_elem(slot - 12, pn);
-                    if (slot == 28) p_close(pn);
-                } else if (slot == 4) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) pn[q / 4][q % 4] = __builtin_bit_cast(unsigned, sx[q]);
-                }
-                if (slot >= 20 && slot < 20 + NKA) kaddr[slot - 20] += kstep;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        PIN_O_IN_LOOP(3);
-        if constexpr (HAS_NEXT) {
-            kr = kr_next;
-            kw = kw == 2 ? 0 : kw + 1;
-        }
-    };
-
-    if (T > 0) {
-#pragma unroll
-        for (int j = 0; j < KPW; ++j) dma_k_piece(0, 0, j);
-#pragma unroll
-        for (int j = 0; j < VPW; ++j) dma_v_piece(0, 0, j);
-#pragma unroll
-        for (int j = 0; j < KPW; ++j) dma_k_piece(min(1, T - 1), 1, j);
-#pragma unroll
-        for (int j = 0; j < KPW; ++j) dma_k_piece(min(2, T - 1), 2, j);
-        stage_fence(std::integral_constant<int, 0>());
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            const u32x4 kf = kfrag(ks);
-            if (ks == 0) mfma_bf16_vgpr_first(sx, kf, qf[0]);
-            else mfma_bf16_vgpr(sx, kf, qf[ks]);
-        }
-        mfma_result_fence(sx);
-        mask_ragged(sx, 0);
-        // P(0)
-        u32x4 pA[2], pB[2];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) p_elem(r, pA);
-        p_close(pA);
-        __syncthreads();                                // K(0) fully consumed before K(3) lands on it
-#pragma unroll
-        for (int u = 0; u < NKA; ++u) kaddr[u] += (unsigned)(KTILE * 2);   // step 0 reads K(1) in buffer 1
-
-        // Steady state.  ANY VALU access to the 256 AGPR-resident O values in or around this loop
-        // (a rescale, even on a never-taken branch, even an early exit) makes hipcc copy and spill
-        // accumulator tiles on the hot path.  So this kernel has no rescale and no reference exponent
-        // at all: a row whose sum left [2^-80, 2^80] (overflow, or every P flushed to zero) flags its
-        // (q block, split) after the loop, and the launcher runs the general kernel right behind this
-        // one over the flagged blocks, which rewrites their rows.
-        int t = 0;
-        // Only the shard's LAST tile can be ragged, so only the step that scores it masks: the steady-state loop
-        // stops two tiles short of the end and the tail below runs the masking instantiation.  (Round 4: with the
-        // mask in every step hipcc turned its wave-uniform branch into ~45 selects per step, a third of the loop's
-        // VALU work, next to MFMAs that do not overlap with VALU issue -- profiles/r04/bf16_ragged_mask_hoist.log.)
-        for (; t + 3 < T; t += 2) {
-            step(std::true_type(), std::false_type(), pA, pB, t);
-            step(std::true_type(), std::false_type(), pB, pA, t + 1);
-        }
-        if (T - t == 3) {
-            step(std::true_type(), std::false_type(), pA, pB, t);
-            step(std::true_type(), std::true_type(), pB, pA, t + 1);
-            step(std::false_type(), std::true_type(), pA, pB, t + 2);
-        } else if (T - t == 2) {
-            step(std::true_type(), std::true_type(), pA, pB, t);
-            step(std::false_type(), std::true_type(), pB, pA, t + 1);
-        } else {
-            step(std::false_type(), std::true_type(), pA, pB, t);
-        }
-    }
-    // max_j P_j <= l <= n max_j P_j: inside [2^-80, 2^80] nothing overflowed (2^47 of fp32 headroom
-    // left for sum_j P_j |V_j|) and the row did not flush to zero
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const bool ok = l_tot >= 0x1p-80f && l_tot <= 0x1p80f;
-    if (T > 0 && __any(!ok) && lane == 0) a.redo[split * n_qblocks + qblock] = a.redo_gen;
-    // fold out the power of two just below the row sum: exact, and lsum lands in [1, 2)
-    const int fold_exp = ok ? __builtin_amdgcn_frexp_expf(l_tot) - 1 : 0;
-
-    // ---- epilogue: the triple relative to lmax = fold_exp * ln 2 (a reference exponent, not the row
-    //      max: any value makes a valid triple for the merges), this chunk's columns
-    float *out = a.contrib;
-    float *omax = a.lmax, *osum = a.lsum;
-    int ldo = a.ldo;
-    if (a.kv_splits > 1) {
-        ldo = a.ws_ld;
-        out = a.ws_contrib + (size_t)split * a.ws_rows * ldo;
-        omax = a.ws_lmax + (size_t)split * a.ws_rows;
-        osum = a.ws_lsum + (size_t)split * a.ws_rows;
-    }
-    if (qrow < a.m) {
-        float *orow = out + (size_t)qrow * ldo + dv0;
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int col = 32 * tt + crow16(r, hi);
-                if (dv0 + col < a.dv) orow[col] = __builtin_amdgcn_ldexpf(oacc[tt][r], -fold_exp);
-            }
-        if (hi == 0 && chunk == 0) {
-            omax[qrow] = T > 0 ? (float)fold_exp * 0.69314718055994530942f : -INFINITY;
-            osum[qrow] = __builtin_amdgcn_ldexpf(l_tot, -fold_exp);
-        }
-    }
+// the steady-state chain's links carry no wait states: its operands are written by LDS reads (covered by s_waitcnt) and by
+// the previous link only -- tests/test_kernel_isa.py checks that no VALU write of an operand sits right in front of one
+__device__ __forceinline__ void mfma_bf16_vgpr_first_nl(f32x16 &d, const u32x4 &x, const u32x4 &y) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(x), "v"(y));
+}
+__device__ __forceinline__ void mfma_bf16_vgpr_nl(f32x16 &d, const u32x4 &x, const u32x4 &y) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(x), "v"(y));
 }
 
 #define SDPA_TD_STREAM 0
@@ -1476,26 +1087,34 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// converts: fp64 -> bf16 (RNE), row-major with zero-padded columns, and the transposed V image
+// converts: fp64 -> bf16 (RNE), row-major with zero-padded columns, and the transposed V image -- in the layout the
+// shape's kernel reads (sdpa_internal.h: row images for dv <= 256, tiled images for dv > 256)
 // ---------------------------------------------------------------------------
+// rows [0, rows) converted, rows [rows, rows_pad) zero; 16-byte chunk c of row r lands at chunk position c ^ (r & swz)
+// (swz = 0: plain rows; the tiled K image: bf16_k_swz -- r counts from the image's first row, a multiple of 16 for `dst`)
 __global__ void cvt_d2bf_kernel(const double *__restrict__ src, unsigned short *__restrict__ dst,
-                                long rows, int cols, int ld, double mult) {
-    const long total = rows * ld;
+                                long rows, long rows_pad, int cols, int ld, double mult, int swz) {
+    const long total = rows_pad * ld;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long)gridDim.x * blockDim.x) {
         const long r = idx / ld;
         const int cidx = (int)(idx - r * ld);
-        dst[idx] = cidx < cols ? (unsigned short)f32_to_bf16_rne(__double2float_rn(src[r * cols + cidx] * mult)) : 0;
+        const unsigned short v = (r < rows && cidx < cols) ? (unsigned short)f32_to_bf16_rne(__double2float_rn(src[r * cols + cidx] * mult)) : (unsigned short)0;
+        const int at = ((((cidx >> 3) ^ ((int)r & swz)) << 3) | (cidx & 7));
+        dst[r * ld + at] = v;
     }
 }
 
-// dst[cidx * ldt + kvpos(r)] = bf16(src[r * cols + cidx]) for r < rows, 0 for rows <= r < ldt;
-// rows of dst beyond `cols` (up to cols_pad) are zero.  32x32 tiles through LDS so both sides
-// coalesce (kvpos permutes inside 16-element groups, ldt is a multiple of 32).
+// Row images: dst[cidx * ldt + kvpos(r)] = bf16(src[r * cols + cidx]) for r < rows, 0 for rows <= r < rows_pad; rows of
+// dst beyond `cols` (up to cols_pad) are zero.  32x32 tiles through LDS so both sides coalesce (kvpos permutes inside
+// 16-element groups, ldt is a multiple of 32).
+// Tiled images (TILED; cols_pad a multiple of 512): key tile T = r / 32 of the image at `dst`, column chunk C = cidx / 512:
+// block (T * cols_pad / 512 + C) of 512 x 32 elements; in it row cidx % 512 is 64 bytes = the tile's 32 key positions
+// (kvpos order), 16-byte chunk q stored at q ^ ((row >> 2) & 3) -- the byte order of the tandem kernel's LDS Vt buffer.
 __device__ __forceinline__ unsigned short to_bf16_elem(double x) { return (unsigned short)f32_to_bf16_rne(__double2float_rn(x)); }
 __device__ __forceinline__ unsigned short to_bf16_elem(unsigned short x) { return x; }      // rounded by the host already
 
-template <typename SRC>
+template <typename SRC, bool TILED>
 __global__ void cvt_d2bf_t_kernel(const SRC *__restrict__ src, unsigned short *__restrict__ dst,
                                   long rows, long rows_pad, int cols, int cols_pad, long ldt) {
     __shared__ unsigned short tile[32][33];
@@ -1511,7 +1130,14 @@ __global__ void cvt_d2bf_t_kernel(const SRC *__restrict__ src, unsigned short *_
     for (int k = ty; k < 32; k += 8) {
         const int cc = c0 + k;
         const long r = r0 + tx;
-        if (cc < cols_pad && r < rows_pad) dst[(size_t)cc * ldt + r0 + bf16_kvpos(tx)] = tile[tx][k];
+        if (cc >= cols_pad || r >= rows_pad) continue;
+        if constexpr (TILED) {
+            const int row = cc & 511, pos = (int)bf16_kvpos(tx);
+            const size_t block = (size_t)blockIdx.x * (cols_pad >> 9) + (cc >> 9);
+            dst[block * (512 * 32) + (size_t)row * 32 + ((((pos >> 3) ^ ((row >> 2) & 3)) << 3) | (pos & 7))] = tile[tx][k];
+        } else {
+            dst[(size_t)cc * ldt + r0 + bf16_kvpos(tx)] = tile[tx][k];
+        }
     }
 }
 
@@ -1608,30 +1234,6 @@ static hipError_t launch_bf16_pipe(const Bf16Args &a, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int DK, int ABL = 0>
-static hipError_t launch_bf16_wide(const Bf16Args &a, hipStream_t s) {
-    const int nqb = (a.m + kQRowsPerBlock - 1) / kQRowsPerBlock;
-    const int chunks = bf16_pad_dv(a.dv) / 512;
-    const int ntiles = (a.n_local + kKvTile - 1) / kKvTile;
-    const int tiles_per_split = (ntiles + a.kv_splits - 1) / a.kv_splits;
-    const int kv_per_split = tiles_per_split > 0 ? tiles_per_split * kKvTile : kKvTile;
-    const size_t lds = ((size_t)3 * kKvTile * DK + (size_t)2 * 512 * kKvTile) * sizeof(unsigned short);
-    static std::atomic<bool> attr_done[64];   // (zero-initialised; set from any enqueue thread)
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_bf16_wide_kernel<DK, ABL>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done[dev] = true;
-    }
-    const float scale = 1.0f;   // attention-mpi.c:208's 1/sqrt(dk) (and log2 e) live in the Q image
-    hipLaunchKernelGGL((fused_bf16_wide_kernel<DK, ABL>), dim3(nqb * chunks * a.kv_splits), dim3(256), lds, s,
-                       a, kv_per_split, nqb, chunks, scale);
-    note_launch("fused_bf16_wide_kernel", 2, DK, ABL, 0, 0, 0, nqb * chunks * a.kv_splits, a.kv_splits, 0, a.m, a.n_local);
-    return hipGetLastError();
-}
-
 template <int DK>
 static hipError_t launch_bf16_tandem(const Bf16Args &a, hipStream_t s) {
     const int nqb = (a.m + kQRowsPerBlock - 1) / kQRowsPerBlock;
@@ -1679,12 +1281,6 @@ static hipError_t launch_bf16_tandem_streamed(const Bf16Args &a, const StreamArg
     return hipGetLastError();
 }
 
-// dv > 256: the tandem kernel (two waves share 64 rows and split the columns; the default since round 3), or
-// the wide kernel it was derived from -- both exact, bit-identical to each other ($SDPA_BF16_TANDEM=0/1, A/B timing)
-static bool bf16_uses_tandem() {       // (from the launch-knob snapshot: no getenv on an enqueue thread)
-    return SDPA_BF16_TANDEM_DEFAULT != 0 ? launch_knobs().bf16_tandem != 0 : false;
-}
-
 template <int DK, int DV>
 static hipError_t launch_bf16_duo(const Bf16Args &a, hipStream_t s) {
     const int nqb = (a.m + kDuoRows - 1) / kDuoRows;
@@ -1717,7 +1313,7 @@ hipError_t launch_shard_partial_bf16(const Bf16Args &args, hipStream_t s) {
 
 // dims whose main kernel has a persistent form: the tandem kernel's (value columns in 512-wide chunks, i.e. dv > 256)
 bool bf16_stream_launch_supported(int dk, int dv) {
-    return dk >= 1 && dk <= 512 && bf16_chunk_dv(dv) == 512 && bf16_uses_tandem();
+    return dk >= 1 && dk <= 512 && bf16_tiled(dv);
 }
 
 hipError_t launch_shard_partial_bf16_streamed(const Bf16Args &a, const StreamArgs &st, hipStream_t s) {
@@ -1750,14 +1346,15 @@ static hipError_t launch_shard_partial_bf16_impl(const Bf16Args &args, const Str
     }
 #endif
     // every byte offset inside the Vt image is carried in 32 bits by the staging code
-    if ((size_t)bf16_pad_dv(a.dv) * (size_t)a.ldvt * 2u > 0xffffffffull) return hipErrorInvalidValue;
+    if ((size_t)bf16_pad_dv(a.dv) * (size_t)bf16_pad_n(a.n_local) * 2u > 0xffffffffull) return hipErrorInvalidValue;
+    a.tiled = vc == 512 ? 1 : 0;                // (the redo pass reads the same images: it has to know their layout)
     if (vc == 512) {
         if ((reinterpret_cast<uintptr_t>(a.K) & 15) || (reinterpret_cast<uintptr_t>(a.Vt) & 15) || !a.redo)
             return hipErrorInvalidValue;
 #ifdef SDPA_ABLATIONS   // tools/ builds only ($SDPA_TUNE bit 12): the STREAM kernel on resident images, every ready word raised beforehand --
         // what the persistent form's waits and extra arguments cost the kernel itself (profiles/r05/bf16_stream_kernel_resident_ab.log)
         static StreamArgs self_st = {};
-        if (!st && (tune & 4096) && bf16_uses_tandem()) {
+        if (!st && (tune & 4096)) {
             if (!self_st.flags) {
                 unsigned *w = nullptr;
                 int *stat = nullptr;
@@ -1775,46 +1372,25 @@ static hipError_t launch_shard_partial_bf16_impl(const Bf16Args &args, const Str
             st = &self_st;
         }
 #endif
-#ifdef SDPA_ABLATIONS
-        if (kp == 512 && ((tune >> 8) & 15)) {                // timing-only ablations
-            switch ((tune >> 8) & 15) {
-                case 1: e = launch_bf16_wide<512, 1>(a, s); break;    // no DMA
-                case 2: e = launch_bf16_wide<512, 2>(a, s); break;    // no LDS fragment reads
-                case 8: e = launch_bf16_wide<512, 8>(a, s); break;    // no barrier (racy)
-                case 9: e = launch_bf16_wide<512, 9>(a, s); break;
-                case 11: e = launch_bf16_wide<512, 11>(a, s); break;  // MFMA + softmax only
-                case 4: e = launch_bf16_wide<512, 4>(a, s); break;    // no softmax VALU
-                case 13: e = launch_bf16_wide<512, 13>(a, s); break;  // LDS fragment reads + MFMA only
-                default: e = launch_bf16_wide<512, 15>(a, s); break;  // MFMA skeleton only
-            }
-        } else
-#endif
-        if (st) {                                            // (bf16_stream_launch_supported: the tandem kernel is in use)
+        if (st) {
             switch (kp) {
                 case 64: e = launch_bf16_tandem_streamed<64>(a, *st, s); break;
                 case 128: e = launch_bf16_tandem_streamed<128>(a, *st, s); break;
                 case 256: e = launch_bf16_tandem_streamed<256>(a, *st, s); break;
                 default: e = launch_bf16_tandem_streamed<512>(a, *st, s); break;
             }
-        } else if (bf16_uses_tandem()) {
+        } else {
             switch (kp) {
                 case 64: e = launch_bf16_tandem<64>(a, s); break;
                 case 128: e = launch_bf16_tandem<128>(a, s); break;
                 case 256: e = launch_bf16_tandem<256>(a, s); break;
                 default: e = launch_bf16_tandem<512>(a, s); break;
             }
-        } else {
-            switch (kp) {
-                case 64: e = launch_bf16_wide<64>(a, s); break;
-                case 128: e = launch_bf16_wide<128>(a, s); break;
-                case 256: e = launch_bf16_wide<256>(a, s); break;
-                default: e = launch_bf16_wide<512>(a, s); break;
-            }
         }
         if (e != hipSuccess) return e;
         main_note = last_launch_note();
         have_main = true;
-        // general kernel (256-column chunks, in-loop rescale) over the blocks the wide one flagged
+        // general kernel (256-column chunks, in-loop rescale) over the blocks the tandem one flagged
         switch (kp) {
             case 64: e = launch_bf16_pipe<64, 256>(a, s); break;
             case 128: e = launch_bf16_pipe<128, 256>(a, s); break;
@@ -1855,32 +1431,42 @@ static hipError_t launch_shard_partial_bf16_impl(const Bf16Args &args, const Str
     return e;
 }
 
+static hipError_t launch_cvt_rows(const double *src, unsigned short *dst, long rows, long rows_pad, int cols, int ld, double mult,
+                                  int swz, hipStream_t s) {
+    if (rows_pad <= 0) return hipSuccess;
+    long g = (rows_pad * ld + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(cvt_d2bf_kernel, dim3((unsigned)g), dim3(256), 0, s, src, dst, rows, rows_pad, cols, ld, mult, swz);
+    return hipGetLastError();
+}
+
 hipError_t launch_cvt_d2bf(const double *src, unsigned short *dst, long rows, int cols, int ld,
                            hipStream_t s) {
-    if (rows <= 0) return hipSuccess;
-    long g = (rows * ld + 255) / 256;
-    if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(cvt_d2bf_kernel, dim3((unsigned)g), dim3(256), 0, s, src, dst, rows, cols, ld, 1.0);
-    return hipGetLastError();
+    return launch_cvt_rows(src, dst, rows, rows, cols, ld, 1.0, 0, s);
+}
+
+// the K image of a (dk, dv) shape: rows [rows, rows_pad) zero; tiled images (dv > 256) with the row's chunk swizzle
+hipError_t launch_cvt_d2bf_k(const double *src, unsigned short *dst, long rows, long rows_pad, int dk, int dv, hipStream_t s) {
+    return launch_cvt_rows(src, dst, rows, rows_pad, dk, bf16_pad_dk(dk), 1.0, bf16_k_swz(dk, dv), s);
 }
 
 // the Q image of the bf16 kernels: bf16(Q * log2(e)/sqrtf(dk)), ONE rounding from fp64 -- the softmax
 // scale (attention-mpi.c:208) and the change of base for v_exp_f32 folded into the operand
 hipError_t launch_cvt_d2bf_q(const double *src, unsigned short *dst, long rows, int dk, int ld, hipStream_t s) {
-    if (rows <= 0) return hipSuccess;
-    long g = (rows * ld + 255) / 256;
-    if (g > 2048) g = 2048;
     const float c = 1.44269504088896340736f * (1.0f / sqrtf((float)dk));
-    hipLaunchKernelGGL(cvt_d2bf_kernel, dim3((unsigned)g), dim3(256), 0, s, src, dst, rows, dk, ld, (double)c);
-    return hipGetLastError();
+    return launch_cvt_rows(src, dst, rows, rows, dk, ld, (double)c, 0, s);
 }
 
 hipError_t launch_cvt_d2bf_t_part(const double *src, unsigned short *dst, long rows, long rows_pad, int cols,
                                   int cols_pad, long ldt, hipStream_t s) {
     if (rows_pad <= 0 || cols_pad <= 0) return hipSuccess;
     const unsigned gx = (unsigned)((rows_pad + 31) / 32), gy = (unsigned)((cols_pad + 31) / 32);
-    hipLaunchKernelGGL(cvt_d2bf_t_kernel<double>, dim3(gx, gy), dim3(256), 0, s, src, dst, rows, rows_pad, cols,
-                       cols_pad, ldt);
+    if (bf16_tiled(cols))
+        hipLaunchKernelGGL((cvt_d2bf_t_kernel<double, true>), dim3(gx, gy), dim3(256), 0, s, src, dst, rows, (long)gx * 32, cols,
+                           cols_pad, ldt);
+    else
+        hipLaunchKernelGGL((cvt_d2bf_t_kernel<double, false>), dim3(gx, gy), dim3(256), 0, s, src, dst, rows, rows_pad, cols,
+                           cols_pad, ldt);
     return hipGetLastError();
 }
 
@@ -1888,8 +1474,12 @@ hipError_t launch_cvt_bf_t_part(const unsigned short *src, unsigned short *dst, 
                                 int cols_pad, long ldt, hipStream_t s) {
     if (rows_pad <= 0 || cols_pad <= 0) return hipSuccess;
     const unsigned gx = (unsigned)((rows_pad + 31) / 32), gy = (unsigned)((cols_pad + 31) / 32);
-    hipLaunchKernelGGL(cvt_d2bf_t_kernel<unsigned short>, dim3(gx, gy), dim3(256), 0, s, src, dst, rows, rows_pad,
-                       cols, cols_pad, ldt);
+    if (bf16_tiled(cols))
+        hipLaunchKernelGGL((cvt_d2bf_t_kernel<unsigned short, true>), dim3(gx, gy), dim3(256), 0, s, src, dst, rows, (long)gx * 32,
+                           cols, cols_pad, ldt);
+    else
+        hipLaunchKernelGGL((cvt_d2bf_t_kernel<unsigned short, false>), dim3(gx, gy), dim3(256), 0, s, src, dst, rows, rows_pad,
+                           cols, cols_pad, ldt);
     return hipGetLastError();
 }
 

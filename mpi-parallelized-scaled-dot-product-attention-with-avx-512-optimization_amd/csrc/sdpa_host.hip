@@ -484,10 +484,11 @@ bool want_bf16(int flags) {
 // shard keys x 2 bytes) inside the 32-bit offsets the staging code carries.  Beyond that the call runs the fp32 path
 // (and says so on stderr once per call) instead of refusing: fp32 is the tighter of the two tolerances, and the
 // reference takes any shape (attention-mpi.c:103-140) -- VERDICT r4 "what's missing" 4.
-bool bf16_for(int flags, int n, int dk, int dv, int ranks) {
+// (qrows: under the Q-row plan every rank holds ALL n keys -- ADVICE r5: the size test has to know the plan)
+bool bf16_for(int flags, int n, int dk, int dv, int ranks, bool qrows) {
     if (!want_bf16(flags)) return false;
     if (dk > 512 || dv > 1024) return false;
-    const long per_rank = ((long)n + ranks - 1) / std::max(1, ranks);
+    const long per_rank = qrows ? (long)n : ((long)n + ranks - 1) / std::max(1, ranks);
     return (double)sdpa::bf16_pad_dv(dv) * (double)sdpa::bf16_pad_n(per_rank) * 2.0 < 4294967296.0;
 }
 
@@ -495,10 +496,10 @@ bool bf16_for(int flags, int n, int dk, int dv, int ranks) {
 void make_plan(Plan &pl, int m, int n, int dk, int dv, int flags, int ranks = 0) {
     pl.m = m; pl.n = n; pl.dk = dk; pl.dv = dv;
     pl.P = ranks > 0 ? ranks : E.n;
-    pl.bf16 = bf16_for(flags, n, dk, dv, pl.P);
     pl.qrows = (flags & SDPA_F_PLAN_QROWS) != 0;
     if (const char *v = getenv("SDPA_PLAN")) pl.qrows = pl.qrows || strcmp(v, "qrows") == 0;
     if (pl.P == 1) pl.qrows = false;
+    pl.bf16 = bf16_for(flags, n, dk, dv, pl.P, pl.qrows);
     pl.merge_allreduce = (flags & SDPA_F_MERGE_ALLREDUCE) != 0;
     if (const char *v = getenv("SDPA_MERGE")) pl.merge_allreduce = pl.merge_allreduce || strcmp(v, "allreduce") == 0;
     const bool force = getenv("SDPA_FORCE_COLLECTIVES") && atoi(getenv("SDPA_FORCE_COLLECTIVES")) != 0;
@@ -717,7 +718,8 @@ int ensure_buffers(const Plan &pl) {
         HIP_TRY(hipSetDevice(rk.dev));
         SDPA_TRY(ensure(rk.k64, (size_t)rp.key_cnt * pl.dk * sizeof(double)));
         SDPA_TRY(ensure(rk.v64, (size_t)rp.key_cnt * pl.dv * sizeof(double)));
-        SDPA_TRY(ensure(rk.kf, (size_t)rp.key_cnt * pl.ldk * pl.kv_elem));
+        // (bf16: whole 32-key tiles of K rows -- the tiled image's last tile is read to its end, sdpa_internal.h)
+        SDPA_TRY(ensure(rk.kf, (size_t)(pl.bf16 ? sdpa::bf16_pad_n(rp.key_cnt) : rp.key_cnt) * pl.ldk * pl.kv_elem));
         if (pl.bf16)
             SDPA_TRY(ensure(rk.vf, (size_t)sdpa::bf16_pad_dv(pl.dv) * sdpa::bf16_pad_n(rp.key_cnt) * sizeof(unsigned short)));
         else
@@ -816,7 +818,7 @@ int launch_fused(const Plan &pl, Rank &rk, const RankPlan &rp, int s, int bs, in
     Bf16Args a = {};
     a.Q = (const unsigned short *)rk.qf[s].p + (size_t)j0 * pl.ldq;  a.ldq = pl.ldq;
     a.K = (const unsigned short *)rk.kf.p + (size_t)k0 * pl.ldk;     a.ldk = pl.ldk;
-    a.Vt = (const unsigned short *)rk.vf.p + k0;                     a.ldvt = sdpa::bf16_pad_n(rp.key_cnt);
+    a.Vt = (const unsigned short *)rk.vf.p + sdpa::bf16_vt_key_offset(k0, pl.dv);   a.ldvt = sdpa::bf16_pad_n(rp.key_cnt);
     a.m = jr; a.n_local = keys; a.dk = pl.dk; a.dv = pl.dv;
     a.kv_splits = splits;
     if (slot0 >= 0 && splits == 1) {
@@ -899,6 +901,11 @@ int stage_half(const Plan &pl, Rank &rk, const RankPlan &rp, const double *src, 
             // them in place -- the copy engine's, like the linear ones (tools/probes/h2d_2d_probe.hip)
             const long ldn = sdpa::bf16_pad_n(rp.key_cnt);
             const unsigned short *img = (const unsigned short *)(HI.v + HI.v_rank_off[g]) + ch.img_off;
+            if (sdpa::bf16_tiled(pl.dv)) {      // tiled image (round 6): the entry's tiles are ONE contiguous block at both ends
+                HIP_TRY(hipMemcpyAsync((unsigned short *)rk.vf.p + sdpa::bf16_vt_key_offset(ch.k0, pl.dv), img,
+                                       (size_t)ch.keys_pad * sdpa::bf16_pad_dv(pl.dv) * sizeof(unsigned short), hipMemcpyHostToDevice, rk.s_cp));
+                return SDPA_OK;
+            }
             HIP_TRY(hipMemcpy2DAsync((unsigned short *)rk.vf.p + ch.k0, (size_t)ldn * sizeof(unsigned short), img,
                                      (size_t)ch.keys_pad * sizeof(unsigned short), (size_t)ch.keys_pad * sizeof(unsigned short),
                                      (size_t)sdpa::bf16_pad_dv(pl.dv), hipMemcpyHostToDevice, rk.s_cp));
@@ -913,7 +920,7 @@ int stage_half(const Plan &pl, Rank &rk, const RankPlan &rp, const double *src, 
         const long ldn = sdpa::bf16_pad_n(rp.key_cnt);
         const bool last = ch.k0 + ch.keys == rp.key_cnt;
         const long pad = last ? ldn - ch.k0 : ch.keys;
-        HIP_TRY(sdpa::launch_cvt_bf_t_part(rows16, (unsigned short *)rk.vf.p + ch.k0, ch.keys, pad, pl.dv,
+        HIP_TRY(sdpa::launch_cvt_bf_t_part(rows16, (unsigned short *)rk.vf.p + sdpa::bf16_vt_key_offset(ch.k0, pl.dv), ch.keys, pad, pl.dv,
                                            sdpa::bf16_pad_dv(pl.dv), ldn, rk.s_in));
         return SDPA_OK;
     }
@@ -923,9 +930,10 @@ int stage_half(const Plan &pl, Rank &rk, const RankPlan &rp, const double *src, 
     HIP_TRY(hipEventRecord(copied, rk.s_cp));
     HIP_TRY(hipStreamWaitEvent(rk.s_in, copied, 0));
     if (!is_v) {
-        if (pl.bf16)
-            HIP_TRY(sdpa::launch_cvt_d2bf(stage, (unsigned short *)rk.kf.p + (size_t)ch.k0 * pl.ldk, ch.keys, pl.dk,
-                                          pl.ldk, rk.s_in));
+        if (pl.bf16)       // (the image of the shape's kernel: tiled for dv > 256, with the last tile's pad rows zeroed)
+            HIP_TRY(sdpa::launch_cvt_d2bf_k(stage, (unsigned short *)rk.kf.p + (size_t)ch.k0 * pl.ldk, ch.keys,
+                                            ch.k0 + ch.keys == rp.key_cnt ? sdpa::bf16_pad_n(rp.key_cnt) - ch.k0 : ch.keys, pl.dk, pl.dv,
+                                            rk.s_in));
         else
             HIP_TRY(sdpa::launch_cvt_d2f(stage, (float *)rk.kf.p + (size_t)ch.k0 * pl.ldk, ch.keys, pl.dk, pl.ldk,
                                          rk.s_in));
@@ -933,7 +941,7 @@ int stage_half(const Plan &pl, Rank &rk, const RankPlan &rp, const double *src, 
         const long ldn = sdpa::bf16_pad_n(rp.key_cnt);
         const bool last = ch.k0 + ch.keys == rp.key_cnt;
         const long pad = last ? ldn - ch.k0 : ch.keys;       // the image's zero tail belongs to the last keys
-        HIP_TRY(sdpa::launch_cvt_d2bf_t_part(stage, (unsigned short *)rk.vf.p + ch.k0, ch.keys, pad, pl.dv,
+        HIP_TRY(sdpa::launch_cvt_d2bf_t_part(stage, (unsigned short *)rk.vf.p + sdpa::bf16_vt_key_offset(ch.k0, pl.dv), ch.keys, pad, pl.dv,
                                              sdpa::bf16_pad_dv(pl.dv), ldn, rk.s_in));
     } else {
         HIP_TRY(sdpa::launch_cvt_d2f(stage, (float *)rk.vf.p + (size_t)ch.k0 * pl.ldv, ch.keys, pl.dv, pl.ldv,
@@ -2118,8 +2126,10 @@ int sdpa_attention_f64(const double *Q, const double *K, const double *V, double
                 const RankPlan &rp = pl.r[g];
                 const Chunk &cc = list_of(g)[ch];
                 const size_t row0 = (size_t)rp.key_off + cc.k0;
-                HI.k_task[g].push_back(E.hc->submit(K + row0 * dk, hk + row0 * pl.ldk * kel, cc.keys, dk,
-                                                     pl.ldk, kind, 1.0));
+                // (bf16, dv > 256: rows of the TILED K image -- chunk swizzle by the row's place in its tile; chunks and entries
+                //  start on tile boundaries of the rank's image, so the task's own row count gives it)
+                HI.k_task[g].push_back(E.hc->submit(K + row0 * dk, hk + row0 * pl.ldk * kel, cc.keys, dk, pl.ldk,
+                                                     pl.bf16 && sdpa::bf16_tiled(dv) ? sdpa::kCvtBf16Swz : kind, 1.0));
                 if (pl.bf16 && HI.streamed[g])        // the entry's columns of the Vt image, as a packed block of the staging
                     HI.v_task[g].push_back(E.hc->submit_t(V + row0 * dv, (unsigned short *)(hv + hv_rank_off[g]) + cc.img_off, cc.keys,
                                                            cc.keys_pad, dv, sdpa::bf16_pad_dv(dv), cc.keys_pad));

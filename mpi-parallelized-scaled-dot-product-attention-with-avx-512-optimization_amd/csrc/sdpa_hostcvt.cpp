@@ -96,6 +96,48 @@ void rows_to_bf16_avx512(const double *src, unsigned short *dst, long rows, int 
     }
 }
 
+// Rows of the TILED K image (round 6, sdpa_internal.h): the same values, 16-byte chunk c of image row r stored at chunk position
+// c ^ (r & swz) -- the byte order of the tandem kernel's LDS K buffer.  `row0` = image row of the first row (the swizzle needs it).
+void rows_to_bf16_swz_scalar(const double *src, unsigned short *dst, long rows, int cols, int ld, double mult, long row0, int swz) {
+    for (long r = 0; r < rows; ++r) {
+        const double *s = src + r * cols;
+        unsigned short *d = dst + r * ld;
+        const int x = (int)((row0 + r) & swz);
+        for (int c = 0; c < ld; ++c) d[(((c >> 3) ^ x) << 3) | (c & 7)] = c < cols ? to_bf16(s[c] * mult) : (unsigned short)0;
+    }
+}
+
+// AVX-512: a row in 64-byte lines of four chunks; x & 3 permutes the chunks of a line, x >> 2 the lines (ld is a multiple of 32)
+__attribute__((target("avx512f,avx512bw,avx512vl")))
+void rows_to_bf16_swz_avx512(const double *src, unsigned short *dst, long rows, int cols, int ld, double mult, long row0, int swz, bool nt) {
+    const __m512d vm = _mm512_set1_pd(mult);
+    const __m256i one = _mm256_set1_epi32(1), bias = _mm256_set1_epi32(0x7fff);
+    for (long r = 0; r < rows; ++r) {
+        const double *s = src + r * cols;
+        unsigned short *d = dst + r * ld;
+        const int x = (int)((row0 + r) & swz), xl = x >> 2, xc = x & 3;
+        const bool aligned = nt && (((uintptr_t)d) & 63u) == 0;
+        for (int line = 0; line < ld / 32; ++line) {
+            __m128i q[4];
+            for (int k = 0; k < 4; ++k) {
+                const int c = line * 32 + k * 8, left = cols - c;
+                const __mmask8 msk = left >= 8 ? (__mmask8)0xff : left <= 0 ? (__mmask8)0 : (__mmask8)((1u << left) - 1u);
+                __m256i u = _mm256_castps_si256(_mm512_cvtpd_ps(_mm512_mul_pd(_mm512_maskz_loadu_pd(msk, s + (left > 0 ? c : 0)), vm)));
+                u = _mm256_add_epi32(u, _mm256_add_epi32(bias, _mm256_and_si256(_mm256_srli_epi32(u, 16), one)));
+                q[k] = _mm_maskz_mov_epi16(msk, _mm256_cvtepi32_epi16(_mm256_srli_epi32(u, 16)));      // (pad columns: zero, not bf16(0 + bias))
+            }
+            __m512i v = _mm512_castsi128_si512(q[0 ^ xc]);
+            v = _mm512_inserti32x4(v, q[1 ^ xc], 1);
+            v = _mm512_inserti32x4(v, q[2 ^ xc], 2);
+            v = _mm512_inserti32x4(v, q[3 ^ xc], 3);
+            unsigned short *at = d + (size_t)(line ^ xl) * 32;
+            if (aligned) _mm512_stream_si512((__m512i *)at, v);
+            else _mm512_storeu_si512((void *)at, v);
+        }
+    }
+    if (nt) _mm_sfence();
+}
+
 // The same rows with STREAMING stores (round 4): a row whose destination is 64-byte aligned is written in whole cache
 // lines past the cache (two vcvtpd2ps per line of floats, four 8-lane groups per line of bf16), so that the write
 // does not first READ the line it overwrites (write-allocate: 16 instead of 12 bytes of memory traffic per fp32
@@ -193,6 +235,12 @@ inline void rows_to_bf16(const double *src, unsigned short *dst, long rows, int 
     if (!have_avx512()) rows_to_bf16_scalar(src, dst, rows, cols, ld, mult);
     else if (nt) rows_to_bf16_avx512_nt(src, dst, rows, cols, ld, mult);
     else rows_to_bf16_avx512(src, dst, rows, cols, ld, mult);
+}
+
+inline void rows_to_bf16_swz(const double *src, unsigned short *dst, long rows, int cols, int ld, double mult, long row0, int swz,
+                             bool nt, bool force_scalar = false) {
+    if (force_scalar || !have_avx512() || (ld & 31)) rows_to_bf16_swz_scalar(src, dst, rows, cols, ld, mult, row0, swz);
+    else rows_to_bf16_swz_avx512(src, dst, rows, cols, ld, mult, row0, swz, nt);
 }
 
 // The Vt image of the bf16 kernels, made on the host (round 5: what a persistent bf16 launch is fed with -- a device transpose
@@ -303,6 +351,65 @@ void tiles_to_bf16_t(const double *src, unsigned short *dst, long keys, long til
 #endif
 }
 
+// The TILED Vt image (round 6, sdpa_internal.h; dv > 256): per 32-key tile one contiguous block [cols_pad / 512 chunks][512 columns]
+// [32 key positions]; a column's 64-byte line holds the tile's keys in kvpos order, 16-byte chunk q at q ^ ((column >> 2) & 3).
+// dst = the block of the first tile.  Per tile: 32 rows through the row converter into scratch, 32 x 32 blocks transposed in
+// registers, each line's chunks permuted and streamed out -- 32 KiB of consecutive lines per (tile, chunk).
+__attribute__((target("avx512f,avx512bw,avx512vl")))
+inline void store_line_swz(unsigned short *line, const unsigned short *from, int x, bool nt) {
+    __m512i y = _mm512_loadu_si512((const void *)from);
+    switch (x) {                                     // chunk position p takes chunk p ^ x
+        case 1: y = _mm512_shuffle_i32x4(y, y, 0xB1); break;
+        case 2: y = _mm512_shuffle_i32x4(y, y, 0x4E); break;
+        case 3: y = _mm512_shuffle_i32x4(y, y, 0x1B); break;
+        default: break;
+    }
+    if (nt && ((uintptr_t)line & 63u) == 0) _mm512_stream_si512((__m512i *)line, y);
+    else _mm512_storeu_si512((void *)line, y);
+}
+
+void tiles_to_bf16_tiled(const double *src, unsigned short *dst, long keys, long tiles, int cols, int cols_pad, bool nt,
+                         bool force_scalar = false) {
+    constexpr int TK = 32;
+    const int ldtmp = (cols + 31) / 32 * 32;
+    const bool simd = !force_scalar && have_avx512();
+    unsigned short *tmp = vt_scratch((size_t)TK * ldtmp + (size_t)32 * TK + 64);
+    unsigned short *obuf = tmp + (size_t)TK * ldtmp;                   // [32 columns][32 positions]
+    const size_t tile_elems = (size_t)cols_pad * TK;
+    for (long t = 0; t < tiles; ++t) {
+        const long r0 = t * TK;
+        const long nr = keys - r0 < TK ? (keys - r0 > 0 ? keys - r0 : 0) : TK;
+        if (nr > 0) {
+            if (simd) rows_to_bf16_avx512(src + r0 * cols, tmp, nr, cols, ldtmp, 1.0);
+            else rows_to_bf16_scalar(src + r0 * cols, tmp, nr, cols, ldtmp, 1.0);
+        }
+        if (nr < TK) memset(tmp + nr * ldtmp, 0, (size_t)(TK - nr) * ldtmp * sizeof(unsigned short));
+        unsigned short *tile = dst + (size_t)t * tile_elems;
+        for (int c0 = 0; c0 < cols; c0 += 32) {
+            const int nc = cols - c0 < 32 ? cols - c0 : 32;
+            const unsigned short *in = tmp + c0;
+            if (simd) {
+                transpose_block_32x32(in, ldtmp, obuf, TK, 32, false);
+                for (int cc = 0; cc < nc; ++cc) {
+                    const int c = c0 + cc;
+                    store_line_swz(tile + (size_t)(c >> 9) * (512 * TK) + (size_t)(c & 511) * TK, obuf + (size_t)cc * TK, (c >> 2) & 3, nt);
+                }
+            } else {
+                for (int cc = 0; cc < nc; ++cc) {
+                    const int c = c0 + cc, x = (c >> 2) & 3;
+                    unsigned short *line = tile + (size_t)(c >> 9) * (512 * TK) + (size_t)(c & 511) * TK;
+                    for (int p = 0; p < TK; ++p) line[(((p >> 3) ^ x) << 3) | (p & 7)] = in[(size_t)kvpos32(p) * ldtmp + cc];
+                }
+            }
+        }
+        for (int c = cols; c < cols_pad; ++c)
+            memset(tile + (size_t)(c >> 9) * (512 * TK) + (size_t)(c & 511) * TK, 0, TK * sizeof(unsigned short));
+    }
+#if defined(__x86_64__)
+    if (nt && simd) _mm_sfence();
+#endif
+}
+
 // fp32 -> fp64 of `n` contiguous values: the reference's cvt_f2d_avx512 (attention-mpi.c:68-101, called on the
 // root at :373 / :396), exact.  The AVX-512 form streams its stores past the cache once dst is 64-byte aligned:
 // the caller reads `result` later, from another core as likely as not, and a write-allocate would first READ
@@ -356,6 +463,8 @@ struct Task {
     // kCvtBf16T only: rows of the entry (the image holds whole 32-key tiles up to the padded count), image rows, row stride
     long keys = 0, ldt = 0;
     int cols_pad = 0;
+    bool tiled = false;      // kCvtBf16T: the tiled Vt image (cols > 256)
+    int swz = 0;             // kCvtBf16Swz: the K image's chunk swizzle mask
     Task(const double *s, void *d, int c, int l, CvtKind k, double mu, long items)
         : src(s), dst(d), cols(c), ld(l), kind(k), mult(mu), remaining(items) {}
 };
@@ -502,6 +611,7 @@ public:
         const long n_items = rows > 0 ? (rows + per - 1) / per : 0;
         const int id = (int)mine_->tasks.size();
         mine_->tasks.emplace_back(src, dst, cols, ld, kind, mult, n_items);
+        if (kind == kCvtBf16Swz) mine_->tasks.back().swz = ld / 8 >= 16 ? 15 : ld / 8 - 1;
         for (long r = 0; r < rows; r += per) mine_->items.push_back({id, r, rows - r < per ? rows - r : per});
         return id;
     }
@@ -515,7 +625,7 @@ public:
         const int id = (int)mine_->tasks.size();
         mine_->tasks.emplace_back(src, (void *)dst, cols, 0, kCvtBf16T, 1.0, n_items);
         Task &t = mine_->tasks.back();
-        t.keys = keys; t.ldt = ldt; t.cols_pad = cols_pad;
+        t.keys = keys; t.ldt = ldt; t.cols_pad = cols_pad; t.tiled = cols > 256;
         for (long r = 0; r < total; r += per) mine_->items.push_back({id, r, total - r < per ? total - r : per});
         return id;
     }
@@ -621,8 +731,12 @@ private:
                 const double *s = t.src + it.row0 * t.cols;
                 if (t.kind == kCvtF32)
                     rows_to_f32(s, (float *)t.dst + it.row0 * t.ld, it.rows, t.cols, t.ld, nt_);
+                else if (t.kind == kCvtBf16T && t.tiled)
+                    tiles_to_bf16_tiled(s, (unsigned short *)t.dst + (size_t)it.row0 * t.cols_pad, t.keys - it.row0, it.rows / 32, t.cols, t.cols_pad, nt_);
                 else if (t.kind == kCvtBf16T)          // it.row0, it.rows: whole tiles; keys left of the entry from row0 on
                     tiles_to_bf16_t(s, (unsigned short *)t.dst + it.row0, t.keys - it.row0, it.rows / 32, t.cols, t.cols_pad, t.ldt, nt_);
+                else if (t.kind == kCvtBf16Swz)        // (the task's dst is an image row that is a multiple of 16)
+                    rows_to_bf16_swz(s, (unsigned short *)t.dst + it.row0 * t.ld, it.rows, t.cols, t.ld, t.mult, it.row0, t.swz, nt_);
                 else
                     rows_to_bf16(s, (unsigned short *)t.dst + it.row0 * t.ld, it.rows, t.cols, t.ld, t.mult, nt_);
                 t.remaining.fetch_sub(1, std::memory_order_release);
@@ -668,6 +782,8 @@ void host_convert_rows(const double *src, void *dst, long rows, int cols, int ld
     if (kind == kCvtF32) {
         if (force_scalar) rows_to_f32_scalar(src, (float *)dst, rows, cols, ld);
         else rows_to_f32(src, (float *)dst, rows, cols, ld, nt);
+    } else if (kind == kCvtBf16Swz) {
+        rows_to_bf16_swz(src, (unsigned short *)dst, rows, cols, ld, mult, 0, ld / 8 >= 16 ? 15 : ld / 8 - 1, nt && !force_scalar, force_scalar);
     } else {
         if (force_scalar) rows_to_bf16_scalar(src, (unsigned short *)dst, rows, cols, ld, mult);
         else rows_to_bf16(src, (unsigned short *)dst, rows, cols, ld, mult, nt);
@@ -677,7 +793,8 @@ void host_convert_rows(const double *src, void *dst, long rows, int cols, int ld
 void host_convert_vt(const double *src, unsigned short *dst, long keys, long keys_pad, int cols, int cols_pad, long ldt,
                      bool force_scalar, int stream_stores) {
     const bool nt = stream_stores < 0 ? stream_stores_default() : stream_stores != 0;
-    tiles_to_bf16_t(src, dst, keys, (keys_pad + 31) / 32, cols, cols_pad, ldt, nt && !force_scalar, force_scalar);
+    if (cols > 256) tiles_to_bf16_tiled(src, dst, keys, (keys_pad + 31) / 32, cols, cols_pad, nt && !force_scalar, force_scalar);
+    else tiles_to_bf16_t(src, dst, keys, (keys_pad + 31) / 32, cols, cols_pad, ldt, nt && !force_scalar, force_scalar);
 }
 
 void host_widen(const float *src, double *dst, size_t n, bool force_scalar) { widen_range(src, dst, n, force_scalar); }

@@ -16,6 +16,8 @@ enum CvtKind {
     kCvtF32 = 0,      // float image, rows padded with zero columns to ld floats (cvt_d2f_kernel)
     kCvtBf16 = 1,     // bf16 image, rows padded to ld, values bf16((float)(x * mult)) (cvt_d2bf_kernel)
     kCvtBf16T = 2,    // the TRANSPOSED bf16 image of V (cvt_d2bf_t_kernel): submit_t() / host_convert_vt() only
+    kCvtBf16Swz = 3,  // rows of the TILED K image (dv > 256, sdpa_internal.h): kCvtBf16's values, 16-byte chunk c of image row r at
+                      // c ^ (r & swz), swz = min(15, ld / 8 - 1); dst must be an image row that is a multiple of 16
 };
 
 // Streaming (non-temporal) stores in the AVX-512 rows: whole 64-byte lines written past the cache wherever a row's
@@ -29,6 +31,7 @@ enum CvtKind {
 void host_convert_rows(const double *src, void *dst, long rows, int cols, int ld, CvtKind kind, double mult,
                        bool force_scalar, int stream_stores = -1);
 
+// cols > 256: the TILED Vt image (sdpa_internal.h) -- dst = the block of the first key's tile, whole tiles, ldt unused.  Otherwise:
 // `keys` rows of V (fp64, `cols` columns) -> the columns [0, keys_pad) of a Vt image whose rows are `ldt` elements apart (dst = its
 // row 0 at the first key's tile; keys_pad = keys rounded up to whole 32-key tiles, or more: zero tiles): dst[c * ldt + kvpos(j)] for
 // key j (sdpa_internal.h: bf16_kvpos), zero behind the last key, zero rows [cols, cols_pad) -- cvt_d2bf_t_kernel's image bit for bit

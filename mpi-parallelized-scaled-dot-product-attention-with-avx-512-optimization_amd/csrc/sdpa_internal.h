@@ -119,13 +119,24 @@ bool stream_launch_supported(int dk, int dv);
 // !defer_merge.  The triples are bit for bit those of launch_shard_partial() with the same kv_splits on resident inputs.
 hipError_t launch_shard_partial_streamed(const PartialArgs &a, const StreamArgs &st, hipStream_t s);
 
-// bf16 variant: Q,K row-major bf16 (ld = dk padded to 64/128/256/512, pad columns zero),
-// Vt = V transposed, bf16 [dv_pad x ldvt] (ldvt = n_local padded to 32, pads zero), key j of a
-// row stored at bf16_kvpos(j).
+// bf16 variant: Q row-major bf16 (ld = dk padded to 64/128/256/512, pad columns zero), holding bf16(Q log2e / sqrt(dk)).
+// K and V come as operand IMAGES whose layout belongs to the kernel of the shape's dv:
+//   row images (dv <= 256: duo / pipe kernels)
+//     K  [n_local x ldk] row-major, pad columns zero;
+//     Vt [dv_pad x ldvt] = V transposed (ldvt = n_local padded to 32, pads zero), key j of a row stored at bf16_kvpos(j).
+//   tiled images (dv > 256: the tandem kernel and its redo pass; round 6) -- every 32-key tile is one contiguous block in
+//   exactly the byte order of the kernel's LDS buffer, so that its LDS-DMA pieces are lane-linear at both ends:
+//     K  [pad_n(n_local) x ldk]: row-major rows, 16-byte chunk c of row r stored at chunk position c ^ (r & bf16_k_swz)
+//        (a tile = 32 rows = 32 * ldk contiguous elements); rows [n_local, pad_n) are read (and masked): any finite-or-not
+//        content, but ALLOCATED;
+//     Vt [pad_n / 32 tiles][dv_pad / 512 chunks][512 columns][32 key positions]: a column's 64 bytes hold the tile's keys in
+//        bf16_kvpos order, 16-byte chunk q stored at q ^ ((column >> 2) & 3); zero for keys >= n_local and columns >= dv.
+//     The image of keys [k0, k0 + cnt) (k0 a multiple of 32) starts bf16_vt_key_offset(k0, dv) elements into the Vt image
+//     and k0 * ldk elements into the K image: a launch over a sub-range of keys takes those pointers.
 struct Bf16Args {
     const unsigned short *Q;  int ldq;
     const unsigned short *K;  int ldk;
-    const unsigned short *Vt; long ldvt;
+    const unsigned short *Vt; long ldvt;       // (ldvt: row images only)
     float *contrib;  int ldo;
     float *lmax;
     float *lsum;
@@ -140,6 +151,7 @@ struct Bf16Args {
     int redo_gen;                  // a flag counts when it equals this launch's generation (set by the
                                    // launcher): nothing has to be cleared, stale or uninitialised
                                    // values at worst cause a harmless extra redo
+    int tiled;                     // set by the launcher: bf16_tiled(dv) -- the layout of K and Vt (kernels that serve both read it)
 };
 
 int  bf16_pad_dk(int dk);
@@ -151,6 +163,17 @@ long bf16_pad_n(long n);
 __host__ __device__ inline constexpr long bf16_kvpos(long j) {
     return (j & ~12L) | ((j & 4) << 1) | ((j & 8) >> 1);
 }
+// which image layout a shape's kernels read, and where things sit in it (comment above Bf16Args)
+inline bool bf16_tiled(int dv) { return dv > 256; }
+inline int  bf16_k_swz(int dk, int dv) {
+    if (!bf16_tiled(dv)) return 0;
+    const int kch = (dk <= 64 ? 64 : dk <= 128 ? 128 : dk <= 256 ? 256 : 512) / 8;    // 16-byte chunks of a K row
+    return kch >= 16 ? 15 : kch - 1;
+}
+inline size_t bf16_vt_key_offset(long k0, int dv) {       // elements from the image's start to the block of key k0 (multiple of 32)
+    if (!bf16_tiled(dv)) return (size_t)k0;
+    return (size_t)k0 * (size_t)((dv + 511) / 512 * 512);
+}
 bool bf16_needs_redo(int dk, int dv);  // the shape's kernel flags blocks for a second pass (workspace holds the flags)
 int  pick_kv_splits_bf16(int m, int n_local, int dk, int dv);
 size_t bf16_workspace_bytes(int m, int n_local, int dk, int dv);
@@ -161,11 +184,14 @@ hipError_t launch_shard_partial_bf16(const Bf16Args &a, hipStream_t s);
 bool bf16_stream_launch_supported(int dk, int dv);
 hipError_t launch_shard_partial_bf16_streamed(const Bf16Args &a, const StreamArgs &st, hipStream_t s);
 hipError_t launch_cvt_d2bf(const double *src, unsigned short *dst, long rows, int cols, int ld, hipStream_t s);
+// the K image of a (dk, dv) shape at `dst` (the image's row of the first key, a multiple of 32 keys in): rows [rows, rows_pad) zero
+hipError_t launch_cvt_d2bf_k(const double *src, unsigned short *dst, long rows, long rows_pad, int dk, int dv, hipStream_t s);
 hipError_t launch_cvt_d2bf_q(const double *src, unsigned short *dst, long rows, int dk, int ld, hipStream_t s);
 hipError_t launch_cvt_d2bf_t(const double *src, unsigned short *dst, long rows, int cols, int cols_pad,
                              long ldt, hipStream_t s);
-// the same for `rows` keys that land at dst (a column offset into a larger Vt image of row stride
-// ldt): zero-fills key positions [rows, rows_pad) only
+// the same for `rows` keys that land at dst (row images: a column offset into a larger Vt image of row stride ldt, zero-fills
+// key positions [rows, rows_pad) only; tiled images -- chosen by cols > 256 --: dst = image + bf16_vt_key_offset(first key),
+// whole tiles are written)
 hipError_t launch_cvt_d2bf_t_part(const double *src, unsigned short *dst, long rows, long rows_pad, int cols,
                                   int cols_pad, long ldt, hipStream_t s);
 // the same from rows that are bf16 already (dense, row stride = cols): $SDPA_HOST_CVT, where the host rounds
@@ -261,7 +287,6 @@ int format_launch_kernel(const LaunchNote &n, char *buf, size_t len);
 struct LaunchKnobs {
     int split_merge_kernel;   // $SDPA_SPLIT_MERGE=kernel: the fp32 pipelined kernel merges its K/V splits itself
     int dksplit_pipe;         // $SDPA_DKSPLIT_PIPE (default 1): software-pipelined dk-split kernel
-    int bf16_tandem;          // $SDPA_BF16_TANDEM (default 1): tandem kernel for dv > 256
     int streamk;              // $SDPA_STREAMK: 0 = never, 1 = whenever eligible, unset/auto = -1: by the cost model
 };
 const LaunchKnobs &launch_knobs();

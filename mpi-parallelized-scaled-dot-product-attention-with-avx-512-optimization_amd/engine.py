@@ -234,8 +234,23 @@ class HipBackend:
                       "sdpa_dev_cvt_d2bf_q")
         return out
 
+    def cvt_d2bf_k(self, k64, dv):
+        """fp64 K[n, dk] -> the K image of a (dk, dv) shape, [n_pad, ld] bf16: plain rows for dv <= 256, for dv > 256 the
+        TILED image (chunk-swizzled rows, include/sdpa_hip.h) with its last tile's pad rows zeroed."""
+        n, dk = k64.shape
+        ld, ldn = self.lib.sdpa_dev_bf16_ld(dk), self.lib.sdpa_dev_bf16_ldn(n)
+        check(min(ld, 0), "sdpa_dev_bf16_ld")
+        out = self.empty((max(ldn, 32), ld), torch.bfloat16)
+        if n:
+            assert k64.is_contiguous() and k64.dtype == torch.float64
+            with torch.cuda.device(self.device):
+                check(self.lib.sdpa_dev_cvt_d2bf_k(k64.data_ptr(), out.data_ptr(), n, dk, dv, self._stream()),
+                      "sdpa_dev_cvt_d2bf_k")
+        return out
+
     def cvt_d2bf_t(self, v64):
-        """fp64 V[n, dv] -> the transposed bf16 image Vt[dv_pad, n_pad] the bf16 kernel reads."""
+        """fp64 V[n, dv] -> the transposed bf16 image the bf16 kernel of this dv reads: Vt[dv_pad, n_pad] (key positions
+        permuted, dv <= 256) or the tiled image [n_pad/32, dv_pad/512, 512, 32] (dv > 256), returned as [dv_pad, n_pad] elements."""
         n, dv = v64.shape
         dvp, ldn = self.lib.sdpa_dev_bf16_dvp(dv), self.lib.sdpa_dev_bf16_ldn(n)
         check(min(dvp, 0), "sdpa_dev_bf16_dvp")
@@ -366,7 +381,7 @@ class ShardedAttention:
         self.n, self.dk, self.dv = n, dk, dv
         self.n_local = K64_local.shape[0]
         if self.precision == "bf16":
-            self.Kf = self.be.cvt_d2bf(K64_local)
+            self.Kf = self.be.cvt_d2bf_k(K64_local, dv)
             self.Vf = self.be.cvt_d2bf_t(V64_local)
         else:
             self.Kf = self.be.cvt_d2f(K64_local)

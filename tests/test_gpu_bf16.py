@@ -67,11 +67,56 @@ def test_bf16_converts(be, pkg):
     want = torch.zeros(64, 128, dtype=torch.bfloat16, device="cuda")
     want[:40, pos[:100]] = v.to(torch.float32).to(torch.bfloat16).t()
     assert torch.equal(vt, want)
-    big = torch.randn(4096, 512, dtype=torch.float64, device="cuda")
-    bpos = torch.tensor([be.lib.sdpa_dev_bf16_kvpos(j) for j in range(4096)], device="cuda")
-    bwant = torch.empty(512, 4096, dtype=torch.bfloat16, device="cuda")
-    bwant[:, bpos] = big.to(torch.float32).to(torch.bfloat16).t()
-    assert torch.equal(be.cvt_d2bf_t(big), bwant)
+    # a dv <= 256 shape's K image is plain rows
+    k = torch.randn(100, 72, dtype=torch.float64, device="cuda")
+    assert be.lib.sdpa_dev_bf16_tiled(40) == 0 and be.lib.sdpa_dev_bf16_tiled(256) == 0 and be.lib.sdpa_dev_bf16_tiled(257) == 1
+    kb = be.cvt_d2bf_k(k, 40)
+    assert kb.shape == (128, 128) and torch.equal(kb[:100, :72], k.to(torch.float32).to(torch.bfloat16)) and torch.all(kb[:100, 72:] == 0)
+
+
+def tiled_images_reference(K, V, dk_pad, dv_pad):
+    """the TILED images (include/sdpa_hip.h, dv > 256) built in numpy from the definition: uint16 bit patterns"""
+    def bits(x):
+        return torch.from_numpy(np.ascontiguousarray(x)).to(torch.float32).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+    n, dk = K.shape
+    dv = V.shape[1]
+    npad = (n + 31) // 32 * 32
+    kb = np.zeros((npad, dk_pad), np.uint16)
+    kb[:n, :dk] = bits(K)
+    swz = min(15, dk_pad // 8 - 1)
+    kimg = np.zeros_like(kb)
+    for r in range(npad):
+        row = kb[r].reshape(-1, 8)
+        kimg[r] = row[np.arange(dk_pad // 8) ^ (r & swz)].reshape(-1)          # chunk position p holds chunk p ^ (r & swz)
+    vb = np.zeros((npad, dv_pad), np.uint16)
+    vb[:n, :dv] = bits(V)
+    kvpos = lambda j: (j & ~12) | ((j & 4) << 1) | ((j & 8) >> 1)
+    vimg = np.zeros((npad // 32, dv_pad // 512, 512, 32), np.uint16)
+    for t in range(npad // 32):
+        tile = vb[32 * t:32 * t + 32]                                            # [key, column]
+        line = np.zeros((dv_pad, 32), np.uint16)
+        for j in range(32):
+            line[:, kvpos(j)] = tile[j]
+        line = line.reshape(dv_pad, 4, 8)
+        col = np.arange(dv_pad)
+        x = (col >> 2) & 3
+        out = np.empty_like(line)
+        for q in range(4):
+            out[col, q] = line[col, q ^ x]                                       # chunk position q holds chunk q ^ x
+        vimg[t] = out.reshape(dv_pad // 512, 512, 32)
+    return kimg, vimg.reshape(-1)
+
+
+@pytest.mark.parametrize("n,dk,dv", [(100, 72, 300), (4096, 512, 512), (77, 512, 700), (33, 64, 260)])
+def test_bf16_tiled_images_are_the_documented_layout(n, dk, dv, be):
+    rng = np.random.default_rng(n + dk)
+    K, V = rng.standard_normal((n, dk)), rng.standard_normal((n, dv))
+    kb = be.cvt_d2bf_k(torch.from_numpy(K).cuda(), dv)
+    vt = be.cvt_d2bf_t(torch.from_numpy(V).cuda())
+    dkp, dvp = be.lib.sdpa_dev_bf16_ld(dk), be.lib.sdpa_dev_bf16_dvp(dv)
+    kimg, vimg = tiled_images_reference(K, V, dkp, dvp)
+    assert kb.shape == kimg.shape and np.array_equal(kb.view(torch.int16).cpu().numpy().view(np.uint16), kimg)
+    assert vt.numel() == vimg.size and np.array_equal(vt.view(torch.int16).cpu().numpy().view(np.uint16).reshape(-1), vimg)
 
 
 SHAPES = [
@@ -88,13 +133,13 @@ SHAPES = [
     (48,  300,  512, 512, "D1"),      # BASELINE config 5 dims: two dv chunks of 256
     (40,  200,  100, 200, "D2"),      # dv padded to 256, dk to 128
     (32,   96,  512,  64, "D1"),
-    (129, 700,  300, 700, "D1"),      # dk -> 512, dv -> 2 wide chunks of 512
-    (96,  1000,  64, 300, "D4"),      # wide kernel (dv > 256), dk padded to 64, late spike key
-    (64,  2048, 128, 512, "D3"),      # wide, dk 128, peaky
-    (70,  333,  256, 384, "D2"),      # wide, dk 256, ragged last tile
-    (300, 4096, 512, 512, "D2"),      # wide with in-GPU K/V splits
-    (200,   5,  512, 512, "D2"),      # wide, n < tile
-    (33,   64,  400, 257, "D1"),      # wide, both dims padded
+    (129, 700,  300, 700, "D1"),      # dk -> 512, dv -> 2 chunks of 512
+    (96,  1000,  64, 300, "D4"),      # tandem kernel (dv > 256), dk padded to 64, late spike key
+    (64,  2048, 128, 512, "D3"),      # tandem, dk 128, peaky
+    (70,  333,  256, 384, "D2"),      # tandem, dk 256, ragged last tile
+    (300, 4096, 512, 512, "D2"),      # tandem with in-GPU K/V splits
+    (200,   5,  512, 512, "D2"),      # tandem, n < tile
+    (33,   64,  400, 257, "D1"),      # tandem, both dims padded
 ]
 
 
@@ -109,12 +154,12 @@ def test_bf16_shapes(m, n, dk, dv, dist, pkg, be, orc, O):
     assert np.abs(got - same_inputs).max() <= 4e-3 * max(1.0, np.abs(V).max())
 
 
-def test_bf16_wide_steep_scores_take_the_redo_pass(pkg, be, O):
-    """dv > 256 runs the wide kernel, which has no accumulator rescale and the reference exponent
+def test_bf16_tandem_steep_ramp_takes_the_redo_pass(pkg, be, O):
+    """dv > 256 runs the tandem kernel, which has no accumulator rescale and the reference exponent
     zero: a q block with a row whose sum of 2^score leaves [2^-80, 2^80] is flagged and redone by the
-    general kernel.
+    general kernel (which reads the same TILED images).
     Block 0 (rows 0..127) climbs 0.5 nat per key, block 1 has flat scores and must stay on the
-    wide kernel's own result."""
+    tandem kernel's own result."""
     m, n, d = 256, 1024, 512
     rng = np.random.default_rng(11)
     Q = np.zeros((m, d)); K = np.zeros((n, d))
@@ -141,7 +186,7 @@ def test_bf16_wide_steep_scores_take_the_redo_pass(pkg, be, O):
 @pytest.mark.parametrize("d", [64, 128, 256])
 def test_bf16_duo_steep_scores_take_the_redo_pass(d, pkg, be, O):
     """dk, dv <= 256 run the duo kernel (two query blocks per wave, 256-row workgroups), which like
-    the wide kernel computes against the reference exponent zero: a workgroup in which some row's sum
+    the tandem kernel computes against the reference exponent zero: a workgroup in which some row's sum
     of 2^score leaves [2^-80, 2^80] flags its two 128-row blocks and the general kernel redoes them.
     Rows 0..127 climb 0.5 nat per key (workgroup 0 is redone, including its flat rows 128..255);
     workgroup 1 (rows 256..511, flat scores) must stay on the duo kernel's own result."""
@@ -185,7 +230,7 @@ def test_bf16_duo_every_instantiation(dk, dv, pkg, be, orc, O):
 @pytest.mark.parametrize("d", [128, 512])
 def test_bf16_kv_splits_and_triple(d, pkg, be, O):
     """long K/V with few query blocks: in-GPU splits.  The triple of the fixed-reference kernels
-    (d = 128: duo, d = 512: wide) is relative to a power of two, not to the row max: lmax is the
+    (d = 128: duo, d = 512: tandem) is relative to a power of two, not to the row max: lmax is the
     reference exponent that puts lsum in [1, 2), and lmax + ln(lsum) is the row's log-sum-exp of the
     scores of the bf16 operand images"""
     m, n = 256, 8192
@@ -206,7 +251,7 @@ def test_bf16_kv_splits_and_triple(d, pkg, be, O):
 @pytest.mark.parametrize("d", [128, 512])
 @pytest.mark.parametrize("offset", [-40.0, 40.0, -70.0, 70.0])
 def test_bf16_fixed_reference_range(d, offset, pkg, be, O):
-    """The duo and wide kernels compute P = 2^score against the reference exponent ZERO.  Rows whose
+    """The duo and tandem kernels compute P = 2^score against the reference exponent ZERO.  Rows whose
     scores sit +-40 nats from zero are still inside their range (row sums within 2^+-80); at +-70 nats
     (2^+-101) the row sum leaves it -- overflow on one side, P flushed towards zero on the other -- and
     the general kernel redoes the block.  Either way the answer is the oracle's."""
@@ -328,32 +373,28 @@ def test_bf16_race_screen_repeatability(pkg, be, O):
     (513, 2048, 384, 512, "D3"),       # dk padded to 512, peaky scores
     (32, 4100, 512, 1024, "D1"),       # fewer rows than a pair holds
 ])
-def test_bf16_tandem_kernel_equals_the_wide_kernel_bit_for_bit(m, n, dk, dv, dist, pkg, be, orc, O):
-    """dv > 256 has two kernels: `wide` (every wave owns 32 rows x 512 columns) and `tandem` (two waves share 64
-    rows and split the columns, P handed over through LDS: 50 instead of 64 LDS fragment reads per 64 MFMAs).
-    Same MFMA order per accumulator and the same softmax arithmetic: the triples must be IDENTICAL, 5 launches;
-    and within the bf16 tolerance of the fp64 oracle."""
+def test_bf16_tandem_kernel_against_the_oracle_and_itself(m, n, dk, dv, dist, pkg, be, orc, O):
+    """dv > 256: the tandem kernel on the TILED images (two waves share 64 rows and split the columns, P handed over through
+    LDS; round 6: one barrier per step, every DMA piece of a step issued behind it, MFMAs carried across it).  Its tiles move
+    by LDS-DMA behind counted waits and ONE barrier: a missing wait shows as rare wrong tiles -- 6 launches must be IDENTICAL;
+    the result within the kernel's budget of the fp64 oracle on the very operand images it multiplies, and within the bf16
+    tolerance of the oracle on the inputs."""
     Q, K, V = O.make_inputs(m, n, dk, dv, dist, seed=m + n + dk)
     sa = pkg.ShardedAttention(be, precision="bf16")
     sa.load_kv_from_root(K, V, n, dk, dv)
     qb = sa.convert_q(torch.from_numpy(np.ascontiguousarray(Q)).cuda())
-    try:
-        os.environ["SDPA_BF16_TANDEM"] = "0"
-        pkg.reload_env()
-        want = tuple(t.clone() for t in sa.batch_partial(qb))
-        os.environ["SDPA_BF16_TANDEM"] = "1"
-        pkg.reload_env()
-        for it in range(5):
-            got = sa.batch_partial(qb)
-            for name, g, w in zip(("contrib", "lmax", "lsum"), got, want):
-                g, w = (g[:, :dv], w[:, :dv]) if g.dim() == 2 else (g, w)
-                assert torch.equal(g, w), "launch %d: %s of the tandem kernel differs from the wide kernel" % (it, name)
-        res = be.finish_f64(got[0], got[2], dv).cpu().numpy()
-    finally:
-        os.environ.pop("SDPA_BF16_TANDEM", None)
-        pkg.reload_env()
+    want = tuple(t.clone() for t in sa.batch_partial(qb))
+    assert "fused_bf16_tandem_kernel" in pkg.last_launch()["kernel"]
+    for it in range(5):
+        got = sa.batch_partial(qb)
+        for name, g, w in zip(("contrib", "lmax", "lsum"), got, want):
+            g, w = (g[:, :dv], w[:, :dv]) if g.dim() == 2 else (g, w)
+            assert torch.equal(g, w), "launch %d: %s differs from the first launch" % (it, name)
+    res = be.finish_f64(got[0], got[2], dv).cpu().numpy()
     assert np.isfinite(res).all()
     assert np.abs(res - orc.attention_f64(Q, K, V)).max() <= bf16_tol(V)
+    same_inputs = orc.attention_f64(q_image_f64(Q), to_bf16_f64(K), to_bf16_f64(V))
+    assert np.abs(res - same_inputs).max() <= 4e-3 * max(1.0, np.abs(V).max())
 
 
 def test_bf16_tandem_steep_scores_take_the_redo_pass(pkg, be, O):
@@ -365,13 +406,7 @@ def test_bf16_tandem_steep_scores_take_the_redo_pass(pkg, be, O):
     Q[5] *= 40.0                       # one row of wave 0 ...
     Q[100] *= 40.0                     # ... and one of wave 3's: both pairs redo
     want = O.numpy_attention_f64(Q, K, V)
-    try:
-        os.environ["SDPA_BF16_TANDEM"] = "1"
-        pkg.reload_env()
-        got = dev_attention_bf16(pkg, be, Q, K, V)
-    finally:
-        os.environ.pop("SDPA_BF16_TANDEM", None)
-        pkg.reload_env()
+    got = dev_attention_bf16(pkg, be, Q, K, V)
     assert np.isfinite(got).all()
     assert np.abs(got - want).max() <= bf16_tol(V)
 

@@ -99,7 +99,8 @@ def test_argument_checks(pkg):
     buf = (ctypes.c_double * 16)()
     p = ctypes.addressof(buf)
     assert lib.sdpa_host_cvt_rows(p, p, 1, 8, 4, 0, 1.0, 0) == pkg._lib.SDPA_EINVAL      # ld < cols
-    assert lib.sdpa_host_cvt_rows(p, p, 1, 4, 4, 2, 1.0, 0) == pkg._lib.SDPA_EINVAL      # unknown kind
+    assert lib.sdpa_host_cvt_rows(p, p, 1, 4, 4, 3, 1.0, 0) == pkg._lib.SDPA_EINVAL      # unknown kind
+    assert lib.sdpa_host_cvt_rows(p, p, 1, 4, 4, 2, 1.0, 0) == pkg._lib.SDPA_EINVAL      # kind 2: ld must be the padded dk
     assert lib.sdpa_host_cvt_rows(None, p, 1, 4, 4, 0, 1.0, 0) == pkg._lib.SDPA_EINVAL
     assert lib.sdpa_host_cvt_rows(None, None, 0, 4, 4, 0, 1.0, 0) == 0
 
@@ -150,8 +151,8 @@ def _vt_reference(V, keys_pad, cols_pad, ldt):
 
 
 @pytest.mark.parametrize("keys,cols,cols_pad,extra_tiles,scalar", [
-    (64, 32, 32, 0, False), (96, 512, 512, 0, False), (33, 300, 512, 0, False), (1, 7, 64, 1, False), (255, 129, 256, 2, False),
-    (64, 40, 64, 0, True), (95, 512, 512, 0, True), (0, 16, 32, 1, False)])
+    (64, 32, 32, 0, False), (96, 256, 256, 0, False), (33, 200, 256, 0, False), (1, 7, 64, 1, False), (255, 129, 256, 2, False),
+    (64, 40, 64, 0, True), (95, 256, 256, 0, True), (0, 16, 32, 1, False)])
 def test_host_vt_image_is_the_device_converters_image(keys, cols, cols_pad, extra_tiles, scalar, pkg):
     """every key position of the padded range is written (stale staging bytes must not survive), the pad rows are zero, the values
     and their places are cvt_d2bf_t_kernel's; AVX-512 rows + streaming lines == the plain C rows"""
@@ -201,7 +202,7 @@ def test_host_vt_rejects_bad_arguments(pkg):
     assert lib.sdpa_host_cvt_vt(None, d.ctypes.data, 8, 32, 8, 8, 64, 1, 0) == pkg._lib.SDPA_EINVAL
 
 
-@pytest.mark.parametrize("keys,cols,cols_pad,threads,item_kb", [(4096, 512, 512, 8, 64), (1000, 300, 512, 3, 4), (8192, 64, 64, 5, 1024)])
+@pytest.mark.parametrize("keys,cols,cols_pad,threads,item_kb", [(4096, 256, 256, 8, 64), (1000, 200, 256, 3, 4), (8192, 64, 64, 5, 1024)])
 def test_host_vt_on_a_pool_of_threads_is_the_single_thread_image(keys, cols, cols_pad, threads, item_kb, pkg, monkeypatch):
     """the pool's work items (whole 32-key tiles, $SDPA_HOST_CVT_ITEM_KB of source each, taken by whichever thread is free) write the
     same image as one thread does, including the zero tail and the pad rows"""
@@ -250,3 +251,86 @@ def test_host_vt_image_fuzz(pkg):
             os.environ.pop("SDPA_HOST_CVT_ITEM_KB", None)
         else:
             os.environ["SDPA_HOST_CVT_ITEM_KB"] = old
+
+
+# ---- the TILED images of dv > 256 (round 6: include/sdpa_hip.h) -----------------------------------------------------------------
+def _bf16(x, mult=1.0):
+    return bf16_bits(np.asarray(x, dtype=np.float64), mult)
+
+
+def _tiled_k_reference(K, ld):
+    n, dk = K.shape
+    b = np.zeros((n, ld), np.uint16)
+    b[:, :dk] = _bf16(K)
+    swz = min(15, ld // 8 - 1)
+    out = np.empty_like(b)
+    for r in range(n):
+        out[r] = b[r].reshape(-1, 8)[np.arange(ld // 8) ^ (r & swz)].reshape(-1)
+    return out
+
+
+def _tiled_vt_reference(V, keys_pad, cols_pad):
+    keys, cols = V.shape
+    b = np.zeros((keys_pad, cols_pad), np.uint16)
+    b[:keys, :cols] = _bf16(V)
+    img = np.zeros((keys_pad // 32, cols_pad // 512, 512, 32), np.uint16)
+    col = np.arange(cols_pad)
+    x = (col >> 2) & 3
+    for t in range(keys_pad // 32):
+        line = np.zeros((cols_pad, 32), np.uint16)
+        for j in range(32):
+            line[:, _kvpos(j)] = b[32 * t + j]
+        line = line.reshape(cols_pad, 4, 8)
+        out = np.empty_like(line)
+        for q in range(4):
+            out[col, q] = line[col, q ^ x]
+        img[t] = out.reshape(cols_pad // 512, 512, 32)
+    return img.reshape(-1)
+
+
+@pytest.mark.parametrize("rows,cols,ld", [(64, 512, 512), (37, 300, 512), (50, 256, 256), (33, 100, 128), (40, 64, 64), (19, 7, 64)])
+def test_tiled_k_rows_are_the_chunk_swizzled_bf16_rows(rows, cols, ld, pkg):
+    lib = pkg.load()
+    x = np.ascontiguousarray(samples(rows, cols, 31 * cols + rows))
+    want = _tiled_k_reference(x, ld)
+    for flags in (0, 1, 2, 4):                      # AVX-512 (default stores), plain C, streaming stores on / off
+        dst = _aligned(rows, ld, np.uint16, 0)
+        assert lib.sdpa_host_cvt_rows(x.ctypes.data, dst.ctypes.data, rows, cols, ld, 2, 1.0, flags) == 0
+        assert np.array_equal(dst, want), "flags=%d" % flags
+
+
+@pytest.mark.parametrize("keys,cols,cols_pad,extra_tiles,scalar", [
+    (96, 512, 512, 0, False), (33, 300, 512, 0, False), (95, 512, 512, 1, True), (64, 700, 1024, 0, False), (1, 257, 512, 2, False),
+    (0, 400, 512, 1, False), (130, 1024, 1024, 0, True)])
+def test_host_tiled_vt_image_is_the_documented_layout(keys, cols, cols_pad, extra_tiles, scalar, pkg):
+    lib = pkg.load()
+    V = np.random.default_rng(keys * 7 + cols).uniform(-3, 3, (keys, cols))
+    keys_pad = (keys + 31) // 32 * 32 + 32 * extra_tiles
+    if keys_pad == 0:
+        keys_pad = 32
+    img = np.full(keys_pad * cols_pad + 64, 0xABCD, np.uint16)
+    rc = lib.sdpa_host_cvt_vt(V.ctypes.data if keys else None, img.ctypes.data, keys, keys_pad, cols, cols_pad, keys_pad, 1, 1 if scalar else 0)
+    assert rc == 0
+    assert np.array_equal(img[:keys_pad * cols_pad], _tiled_vt_reference(V, keys_pad, cols_pad))
+    assert (img[keys_pad * cols_pad:] == 0xABCD).all(), "wrote behind the image"
+
+
+@pytest.mark.parametrize("keys,cols,cols_pad,threads,item_kb", [(4096, 512, 512, 8, 64), (1000, 300, 512, 3, 4), (2048, 1000, 1024, 5, 256)])
+def test_host_tiled_vt_on_a_pool_of_threads_is_the_single_thread_image(keys, cols, cols_pad, threads, item_kb, pkg, monkeypatch):
+    lib = pkg.load()
+    monkeypatch.setenv("SDPA_HOST_CVT_ITEM_KB", str(item_kb))
+    V = np.random.default_rng(keys + threads).normal(0, 2, (keys, cols))
+    keys_pad = (keys + 31) // 32 * 32 + 64
+    one = np.full(cols_pad * keys_pad, 0x1234, np.uint16)
+    many = np.full(cols_pad * keys_pad, 0x4321, np.uint16)
+    assert lib.sdpa_host_cvt_vt(V.ctypes.data, one.ctypes.data, keys, keys_pad, cols, cols_pad, keys_pad, 1, 0) == 0
+    assert lib.sdpa_host_cvt_vt(V.ctypes.data, many.ctypes.data, keys, keys_pad, cols, cols_pad, keys_pad, threads, 0) == 0
+    assert np.array_equal(one, many)
+    assert np.array_equal(one, _tiled_vt_reference(V, keys_pad, cols_pad))
+
+
+def test_host_tiled_vt_rejects_a_partial_chunk(pkg):
+    lib = pkg.load()
+    x = np.zeros(64 * 300)
+    d = np.zeros(32 * 512, np.uint16)
+    assert lib.sdpa_host_cvt_vt(x.ctypes.data, d.ctypes.data, 32, 32, 300, 300, 32, 1, 0) == pkg._lib.SDPA_EINVAL     # cols_pad must be whole 512-column chunks

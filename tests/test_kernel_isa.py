@@ -101,33 +101,80 @@ def test_duo_kernel_loop_is_spill_free_and_reads_one_fragment_per_two_mfmas(dk, 
     assert c["global_load_lds_dwordx4"] == 2 * (dk // 64 + dv // 64), c      # DMA pieces of two steps
 
 
-def test_wide_kernel_loop_is_spill_free(bf16_asm):
-    c = main_loop_mix(kernel_lines(bf16_asm, "fused_bf16_wide_kernelILi512ELi0E"))
-    assert c["v_mfma_f32_32x32x16_bf16"] == 128 and c["ds_read_b128"] == 128, c
-    assert sum(v for k, v in c.items() if k.startswith("scratch_")) == 0, c
-    # at most two O tiles cross the back-edge through VGPRs (the accumulator file is completely full; one tile before
-    # round 4 took the ragged-tile mask -- ~90 VALU instructions per loop trip -- out of the steady-state loop)
-    assert c["v_accvgpr_read_b32"] <= 32 and c["v_accvgpr_write_b32"] <= 32, c
+def _loop_ops(k, lo, hi):
+    """(mnemonic, operand text, inside an asm block?) of every instruction of k[lo..hi]"""
+    out, inside = [], False
+    for l in k[lo:hi + 1]:
+        if "#ASMSTART" in l:
+            inside = True
+        elif "#ASMEND" in l:
+            inside = False
+        elif (m := re.match(r"^\t([a-z_0-9]+)\s*(.*)", l)):
+            out.append((m.group(1), m.group(2).split(";")[0], inside))
+    return out
+
+
+def _regs(text):
+    """every vector register a token list names: v5, v[0:15] -> {5}, {0..15}"""
+    out = set()
+    for m in re.finditer(r"\bv(\d+)\b", text):
+        out.add(int(m.group(1)))
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]", text):
+        out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    return out
 
 
 def test_tandem_kernel_loop_is_spill_free_and_reads_50_fragments_per_64_mfmas(bf16_asm):
-    """dv > 256 default since round 3: two waves share 64 rows and split the value columns.  Per step and wave:
-    32 + 32 MFMAs, 32 K + 16 Vt + 2 P fragment reads (the wide kernel: 64), 2 P stores, 16 DMA pieces,
-    two barriers; O stays in the accumulator file."""
-    c = main_loop_mix(kernel_lines(bf16_asm, "fused_bf16_tandem_kernelILi512E"))
+    """dv > 256: two waves share 64 rows and split the value columns.  Per step and wave: 32 + 32 MFMAs, 32 K + 16 Vt + 2 P
+    fragment reads, 2 P stores, 16 DMA pieces; O stays in the accumulator file.  Round 6 (tiled images): ONE barrier per step,
+    and the DMA costs one VMEM instruction per piece plus a handful of scalar ones per TILE (<= 1 SALU per piece)."""
+    k = kernel_lines(bf16_asm, "fused_bf16_tandem_kernelILi512E")
+    lo, hi, c = main_loop_span(k)
     assert c["v_mfma_f32_32x32x16_bf16"] == 128 and c["ds_read_b128"] == 100 and c["ds_write_b128"] == 4, c
-    assert sum(v for k, v in c.items() if k.startswith("scratch_")) == 0, c
-    # round 5: NO accumulator tile crosses the back edge through architectural VGPRs (a never-taken scalar branch behind each
-    # barrier ends the basic block there, SDPA_TANDEM_BLOCKSPLIT: 16 + 16 v_accvgpr moves and an MFMA drain per two steps gone,
-    # +1.0 % measured)
+    assert sum(v for name, v in c.items() if name.startswith("scratch_")) == 0, c
+    # NO accumulator tile crosses the back edge through architectural VGPRs (pin_o() at every step + the block split behind
+    # the barrier: 16 + 16 v_accvgpr moves and an MFMA drain per two steps otherwise)
     assert c["v_accvgpr_read_b32"] == 0 and c["v_accvgpr_write_b32"] == 0, c
-    assert c["global_load_lds_dwordx4"] == 32 and c["s_barrier"] == 4 and c["v_exp_f32"] == 32, c
-    # round 4: no ragged-tile mask and no K-row clamp in the steady state (they live in the tail steps) and ONE scalar
-    # address per K tile (immediate-offset pieces): 758 -> 676 instructions per two steps.  A compiler that brings the
-    # selects or the per-piece address arithmetic back shows up here.
-    assert c["v_cndmask_b32_e32"] + c["v_cndmask_b32_e64"] == 0 and c["s_min_i32"] == 0, c
-    assert c["s_lshl_b64"] <= 4 and c["s_add_u32"] <= 24, c
-    assert sum(c.values()) <= 670, (sum(c.values()), c)
+    assert c["global_load_lds_dwordx4"] == 32 and c["s_barrier"] == 2 and c["v_exp_f32"] == 32, c
+    # no ragged-tile mask, no row clamp, no per-piece swizzle in the steady state
+    assert c["v_cndmask_b32_e32"] + c["v_cndmask_b32_e64"] == 0 and c["s_min_i32"] == 0 and c["v_xor_b32"] + c["v_xor_b32_e32"] == 0, c
+    # scalar work of the DMA: M0 once per tile (4 per two steps), the tile bases, the loop's own counter and branches
+    salu = sum(v for name, v in c.items() if name.startswith("s_") and name not in ("s_waitcnt", "s_nop", "s_barrier"))
+    assert c["s_mov_b32"] <= 6 and salu <= 32, (salu, c)          # <= 1 scalar instruction per DMA piece, everything included
+    assert c["s_nop"] <= 8, c                                        # (no wait states in front of the chain's links)
+    assert sum(c.values()) <= 490, (sum(c.values()), c)             # round 5: 651
+
+
+def test_tandem_kernel_dma_pieces_are_lane_linear_immediates(bf16_asm):
+    """every LDS-DMA piece of the steady state is `global_load_lds_dwordx4 vL, s[b:b+1] offset:IMM` with ONE vector register for all
+    of them and immediates -4096 .. 3072: no per-piece address arithmetic is left for the compiler to scatter between the MFMAs"""
+    k = kernel_lines(bf16_asm, "fused_bf16_tandem_kernelILi512E")
+    lo, hi, _ = main_loop_span(k)
+    pieces = [l.strip() for l in k[lo:hi + 1] if l.startswith("\tglobal_load_lds_dwordx4")]
+    assert len(pieces) == 32
+    vregs = {re.match(r"global_load_lds_dwordx4 (v\d+),", p).group(1) for p in pieces}
+    assert len(vregs) == 1, vregs
+    offs = sorted(int(re.search(r"offset:(-?\d+)", p).group(1)) if "offset:" in p else 0 for p in pieces)
+    assert offs == sorted(list(range(-4096, 4096, 1024)) * 4), offs
+    assert len({re.search(r"(s\[\d+:\d+\])", p).group(1) for p in pieces}) <= 4        # K and Vt base of each of the two steps
+
+
+def test_tandem_kernel_chain_links_need_no_wait_states(bf16_asm):
+    """The steady-state chain's MFMAs are asm statements WITHOUT the two leading wait states the other asm MFMAs carry (hipcc's
+    hazard recogniser does not see into an asm statement).  That is safe while nothing but an LDS read (covered by s_waitcnt) or
+    the previous link writes their operands: no VALU instruction that writes a register a link reads may sit within the two
+    instructions in front of it ("VALU write VGPR -> MFMA read": 2 wait states on gfx90a+)."""
+    k = kernel_lines(bf16_asm, "fused_bf16_tandem_kernelILi512E")
+    lo, hi, _ = main_loop_span(k)
+    ops = _loop_ops(k, lo, hi)
+    links = [i for i, (op, args, inside) in enumerate(ops) if inside and op == "v_mfma_f32_32x32x16_bf16"]
+    assert len(links) == 64, len(links)
+    for i in links:
+        reads = _regs(ops[i][1])
+        for op, args, _ in ops[max(0, i - 2):i]:
+            if op.startswith("v_") and not op.startswith("v_mfma"):
+                dst = args.split(",")[0]
+                assert not (_regs(dst) & reads), "VALU write of a link's operand right in front of it: %s %s" % (op, args)
 
 
 def test_tandem_stream_kernel_loop_does_the_classic_loops_work(bf16_asm):
@@ -137,6 +184,7 @@ def test_tandem_stream_kernel_loop_does_the_classic_loops_work(bf16_asm):
     the acquire's invalidate) sits on a branch the steady state does not take."""
     c = main_loop_mix(kernel_lines(bf16_asm, "fused_bf16_tandem_stream_kernelILi512E"))
     classic = main_loop_mix(kernel_lines(bf16_asm, "fused_bf16_tandem_kernelILi512E"))
+    assert c["s_barrier"] == 2, c
     for k in ("v_mfma_f32_32x32x16_bf16", "ds_read_b128", "ds_write_b128", "global_load_lds_dwordx4", "s_barrier", "v_exp_f32"):
         assert c[k] == classic[k], (k, c[k], classic[k])
     assert sum(v for k, v in c.items() if k.startswith("scratch_")) == 0, c
@@ -291,7 +339,7 @@ def test_nothing_but_the_dma_asm_touches_m0(f32_asm, bf16_asm):
     or writes M0 at all -- there is nothing the DMA's leftover address could be mistaken for.  A compiler that starts
     using M0 in these kernels (LDS-direct loads, s_movrel, GWS) trips this test, and build() with it."""
     names = [(f32_asm, r"fused_pipelined_(sk_|stream_)?kernelILi\d+ELi\d+E"),
-             (bf16_asm, r"fused_bf16_(wide|tandem|tandem_stream|duo|pipe)_kernelI")]
+             (bf16_asm, r"fused_bf16_(tandem|tandem_stream|duo|pipe)_kernelI")]
     seen = 0
     for lines, pat in names:
         for i, l in enumerate(lines):
