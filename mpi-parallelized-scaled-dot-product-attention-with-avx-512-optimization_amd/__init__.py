@@ -12,8 +12,8 @@ The directory name contains hyphens (it is the name the task prescribes), so imp
 from . import _lib
 from ._lib import SdpaError, header_symbols, load, reload_env
 from .engine import (DEFAULT_Q_BATCH, HipBackend, ShardedAttention, attention, attention_mpi, attention_qrows, init,
-                     last_launch, last_timing, owner_count, owner_disp, plan, round4, shutdown)
+                     last_launch, last_timing, owner_count, owner_disp, plan, prepare, round4, shutdown)
 
 __all__ = ["SdpaError", "header_symbols", "load", "reload_env", "HipBackend", "ShardedAttention", "attention",
-           "attention_mpi", "attention_qrows", "init", "last_launch", "last_timing", "owner_count", "owner_disp", "plan", "round4", "shutdown",
+           "attention_mpi", "attention_qrows", "init", "last_launch", "last_timing", "owner_count", "owner_disp", "plan", "prepare", "round4", "shutdown",
            "DEFAULT_Q_BATCH", "_lib"]

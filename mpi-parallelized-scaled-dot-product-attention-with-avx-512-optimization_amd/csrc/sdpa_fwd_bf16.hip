@@ -1317,7 +1317,7 @@ bool bf16_stream_launch_supported(int dk, int dv) {
 }
 
 hipError_t launch_shard_partial_bf16_streamed(const Bf16Args &a, const StreamArgs &st, hipStream_t s) {
-    if (!bf16_stream_launch_supported(a.dk, a.dv) || !st.flags || !st.status || st.n_chunks < 1 ||
+    if (!bf16_stream_launch_supported(a.dk, a.dv) || !st.flags || !st.status || !st.abort || st.n_chunks < 1 ||
         st.n_chunks > kStreamMaxChunks || a.n_local <= 0)
         return hipErrorInvalidValue;
     return launch_shard_partial_bf16_impl(a, &st, s);
@@ -1362,7 +1362,7 @@ static hipError_t launch_shard_partial_bf16_impl(const Bf16Args &args, const Str
                 if (hipMalloc((void **)&w, words * sizeof(unsigned)) != hipSuccess || hipMalloc((void **)&stat, 64) != hipSuccess) return hipErrorOutOfMemory;
                 (void)hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(w), 0x5eed0001u, words);
                 (void)hipMemset(stat, 0, 64);
-                self_st.flags = w; self_st.gen = 0x5eed0001u; self_st.status = stat;
+                self_st.flags = w; self_st.gen = 0x5eed0001u; self_st.status = stat; self_st.abort = reinterpret_cast<unsigned *>(stat) + 4;
                 self_st.timeout_ticks = 100000000ull;
             }
             const int ntiles_ = (a.n_local + kKvTile - 1) / kKvTile;

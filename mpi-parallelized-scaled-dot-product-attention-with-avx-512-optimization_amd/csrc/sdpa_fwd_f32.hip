@@ -735,7 +735,7 @@ hipError_t launch_shard_partial_streamed(const PartialArgs &a_in, const StreamAr
     const bool dense = a.ldq == a.ldk && (kp == 64 || kp == 128) && kp >= a.dk && (vp == 64 || vp == 128) && vp >= a.dv &&
                        a.ldo >= vp && a.ldo % 4 == 0 && (a.kv_splits <= 1 || (a.ws_contrib && a.ws_ld >= vp)) &&
                        (reinterpret_cast<uintptr_t>(a.K) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.V) & 15) == 0;
-    if (!dense || !st.flags || !st.status || st.n_chunks < 1 || st.n_chunks > kStreamMaxChunks || a.n_local <= 0)
+    if (!dense || !st.flags || !st.status || !st.abort || st.n_chunks < 1 || st.n_chunks > kStreamMaxChunks || a.n_local <= 0)
         return hipErrorInvalidValue;
     if (kp == 128 && vp == 128) return launch_streamed<128, 128>(a, st, s);
     if (kp == 64 && vp == 64) return launch_streamed<64, 64>(a, st, s);

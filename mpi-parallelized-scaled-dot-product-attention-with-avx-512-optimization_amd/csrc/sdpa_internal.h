@@ -111,7 +111,8 @@ struct StreamArgs {
                                           // (strictly increasing; the last one covers the longest split)
     int q_piece_blocks;                   // query blocks per Q row piece (0 = Q is resident before the launch)
     unsigned long long timeout_ticks;     // wall_clock64 ticks (100 MHz) one wait may last
-    int *status;                          // device-visible word, set to 1 when a wait timed out (results are garbage then)
+    int *status;                          // device-visible word, set to 1 + the word's index when a wait timed out (results are garbage then)
+    unsigned *abort;                      // device word: == gen once a wait of this launch has timed out (the others stop waiting)
 };
 // dims the stream form exists for: dense images 64 / 128 wide on both sides (every BASELINE fp32 shape with d <= 128)
 bool stream_launch_supported(int dk, int dv);

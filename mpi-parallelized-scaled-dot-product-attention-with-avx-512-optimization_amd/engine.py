@@ -98,6 +98,15 @@ def attention(Q, K, V, flags=0, precision=None, plan=None, merge=None):
     return out
 
 
+def prepare(m, n, dk, dv, flags=0, precision=None):
+    """sdpa_prepare(): buffers at their real sizes, the clock warm-up and one small call through the same code path -- which is
+    also the start-up probe of the streamed launch (a runtime on which it cannot be fed is found out here and the engine keeps
+    the launch-per-chunk schedule)."""
+    if precision == "bf16":
+        flags |= _lib.SDPA_F_BF16
+    check(_lib.load().sdpa_prepare(m, n, dk, dv, flags), "sdpa_prepare")
+
+
 def plan(m, n, dk, dv, flags=0, ranks=1):
     """The schedule sdpa_attention_f64 would run (sdpa_plan_describe): needs no GPU."""
     import ctypes

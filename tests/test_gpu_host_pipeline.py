@@ -5,6 +5,8 @@ communicator (SDPA_FORCE_COLLECTIVES=1).
 
 Tolerance: max|got - fp64 oracle| <= 5e-5 * max(1, max|V|) for fp32
 compute, 1e-2 * max(1, max|V|) for the bf16 path; NaN/Inf anywhere fails."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -44,7 +46,7 @@ def engine(pkg, monkeypatch):
                   "SDPA_KV_CHUNK_MAX", "SDPA_ROW_PIECES", "SDPA_PIECE_MIN_ROWS", "SDPA_PLAN", "SDPA_MERGE", "SDPA_PRECISION",
                   "SDPA_EGRESS", "SDPA_ENQUEUE_THREADS", "SDPA_PROGRESSIVE_PIN", "SDPA_HOST_CVT", "SDPA_HOST_CVT_THREADS",
                   "SDPA_COMM_CUS", "SDPA_HOST_WIDEN", "SDPA_HOST_REGISTER", "SDPA_STREAMED", "SDPA_STREAM_CHUNK_MIN",
-                  "SDPA_STREAM_TIMEOUT_MS", "SDPA_STREAM_DROP_WORD", "SDPA_HOST_CVT_PIN"):
+                  "SDPA_STREAM_TIMEOUT_MS", "SDPA_STREAM_PROBE_MS", "SDPA_DEBUG", "SDPA_HOST_CVT_PIN"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, str(v))
@@ -602,20 +604,75 @@ def test_streamed_launch_from_page_locked_caller_arrays_and_on_loopback_ranks(en
     check(got2[rows], O.numpy_attention_f64(Q, K, V, rows), V, "2 loopback ranks, streamed shards")
 
 
-def test_streamed_launch_times_out_instead_of_hanging(engine, O):
-    """A ready word that never comes (here: dropped on purpose) must end the launch -- bounded by $SDPA_STREAM_TIMEOUT_MS
-    -- with an error from the call, not hang the GPU: every wait in the kernel watches the wall clock."""
+def test_streamed_launch_that_loses_a_ready_word_falls_back_to_the_chunked_schedule(engine, O):
+    """A ready word that never comes (here: dropped on purpose, $SDPA_DEBUG=stream_drop_word) ends the launch -- every wait in the
+    kernel watches the wall clock, and after the first timeout the launch's abort word ends all the others at once: ONE timeout for the
+    call, not one per wave chain -- and the call is RE-RUN on the launch-per-chunk schedule: the caller gets the chunked schedule's result
+    bit for bit and a line on stderr, never an error (the reference's attention() has no failure mode, attention-mpi.c:191-407).  The
+    engine keeps that schedule from then on (no second timeout); a new engine probes again."""
     import time
     Q, K, V = O.make_inputs(8192, 32768, 128, 128, "D1", seed=5)               # two K/V groups (config 2 is ONE group)
-    pkg = engine(SDPA_STREAM_TIMEOUT_MS=200, SDPA_STREAM_DROP_WORD=2)          # the second K/V group is never announced
+    pkg = engine(SDPA_STREAMED=0)
+    want = pkg.attention(Q, K, V)
+    pkg = engine(SDPA_STREAM_TIMEOUT_MS=200, SDPA_DEBUG="stream_drop_word=2")  # the second K/V group is never announced
     assert len(pkg.plan(8192, 32768, 128, 128, 0, 1)["r"][0]["stream"]["end_tile"]) == 2
     t0 = time.perf_counter()
-    with pytest.raises(pkg.SdpaError):
-        pkg.attention(Q, K, V)
-    assert time.perf_counter() - t0 < 5.0
+    got = pkg.attention(Q, K, V)
+    assert time.perf_counter() - t0 < 2.0, "one timeout (200 ms) + the chunked re-run"
+    t = pkg.last_timing()
+    assert t["streamed"] == 0 and t["fused_launches"] > 1, t
+    assert np.array_equal(got, want)
+    t0 = time.perf_counter()
+    assert np.array_equal(pkg.attention(Q, K, V), want)                        # sticky: no timeout is sat out again
+    assert time.perf_counter() - t0 < 0.15 and pkg.last_timing()["streamed"] == 0
+    assert pkg.plan(8192, 32768, 128, 128, 0, 1)["r"][0]["stream"]["on"] == 0
     pkg = engine()
-    got = pkg.attention(Q, K, V)                                               # and the engine is usable afterwards
+    got = pkg.attention(Q, K, V)                                               # a new engine streams again
     assert pkg.last_timing()["streamed"] == 1 and np.isfinite(got).all()
+
+
+def test_prepare_probes_the_streamed_launch_and_disables_it_when_it_cannot_be_fed(engine, O):
+    """sdpa_prepare()'s warm-up call IS the start-up probe: a streamed 8192 x 8192 call with a short wait bound.  When its words do not
+    arrive ($SDPA_DEBUG drops group 0's) prepare still succeeds, quickly, says so once on stderr, and the timed call that follows runs
+    the launch-per-chunk schedule -- correct, with no timeout inside it."""
+    import time
+    m, n, d = 8192, 32768, 128
+    Q, K, V = O.make_inputs(m, n, d, d, "D2", seed=6)
+    pkg = engine(SDPA_STREAMED=0)
+    want = pkg.attention(Q, K, V)
+    pkg = engine(SDPA_DEBUG="stream_drop_word=1", SDPA_PREPARE_WARM_MS=5)
+    t0 = time.perf_counter()
+    pkg.prepare(m, n, d, d)
+    assert time.perf_counter() - t0 < 3.0
+    t0 = time.perf_counter()
+    got = pkg.attention(Q, K, V)
+    dt = time.perf_counter() - t0
+    assert pkg.last_timing()["streamed"] == 0 and dt < 0.15, (pkg.last_timing(), dt)
+    assert np.array_equal(got, want)
+    pkg = engine(SDPA_PREPARE_WARM_MS=5)                                       # the healthy case: the probe passes, the call streams
+    pkg.prepare(m, n, d, d)
+    got = pkg.attention(Q, K, V)
+    assert pkg.last_timing()["streamed"] == 1
+    rows = np.arange(0, m, 257)
+    check(got[rows], O.numpy_attention_f64(Q, K, V, rows), V, "streamed after a passed probe")
+
+
+def test_cli_prints_correct_when_the_streamed_probe_fails(O, tmp_path):
+    """the one-shot CLI (sdpa_prepare + ONE timed call) on a runtime that cannot feed the streamed launch: `Correct!`, exit 0, the
+    fallback announced on stderr"""
+    import subprocess
+    from conftest import PKG, ROOT
+    cli = os.path.join(ROOT, PKG, "bin", "attention-hip")
+    m, n, d = 8192, 16384, 128
+    Q, K, V = O.make_inputs(m, n, d, d, "D1", seed=8)
+    path = str(tmp_path / "probe.bin")
+    O.write_case(path, Q, K, V, O.numpy_attention_f64(Q, K, V))
+    r = subprocess.run([cli, path], capture_output=True, text=True, env=dict(os.environ, SDPA_VERBOSE="1", SDPA_DEBUG="stream_drop_word=1"))
+    assert r.returncode == 0 and r.stdout.startswith("Correct!\nElapsed time: "), (r.stdout, r.stderr)
+    assert "launch-per-chunk schedule" in r.stderr, r.stderr
+    r = subprocess.run([cli, path], capture_output=True, text=True, env=dict(os.environ, SDPA_VERBOSE="1", HSA_ENABLE_SDMA="0"))
+    assert r.returncode == 0 and r.stdout.startswith("Correct!\nElapsed time: "), (r.stdout, r.stderr)
+    assert "one launch per K/V chunk" in r.stderr and "streamed (one persistent launch)" not in r.stderr, r.stderr      # no copy engines: never tried
 
 
 # ------------------------------------------------- ... and its bf16 form (the tandem kernel's shapes: dv > 256) ------------------------------
@@ -664,8 +721,8 @@ def test_streamed_bf16_first_batch_is_the_device_level_launch_bit_for_bit(m, n, 
 
 def test_streamed_bf16_calls_back_to_back_on_different_inputs_and_the_timeout(engine, O):
     """two input sets alternating in one engine (the images of a call land in the SAME device buffers as the previous call's while the
-    launch is resident): every call equals its own set's first result bit for bit; and a ready word that never comes ends the call
-    with an error inside $SDPA_STREAM_TIMEOUT_MS, after which the engine still works"""
+    launch is resident): every call equals its own set's first result bit for bit; and a ready word that never comes ends the launch
+    inside $SDPA_STREAM_TIMEOUT_MS and the call falls back to the launch-per-chunk schedule"""
     import time
     m, n, d = 8192, 16384, 512
     sets = [O.make_inputs(m, n, d, d, dist, seed=seed) for dist, seed in (("D1", 21), ("D2", 22))]
@@ -683,12 +740,14 @@ def test_streamed_bf16_calls_back_to_back_on_different_inputs_and_the_timeout(en
             got = pkg.attention(Q, K, V, precision="bf16")
             assert np.array_equal(got, want), "round %d: %d values differ (max %.3e)" % (rep, (got != want).sum(), np.abs(got - want).max())
     Q, K, V = sets[0]
-    pkg = engine(SDPA_STREAM_TIMEOUT_MS=200, SDPA_STREAM_DROP_WORD=2)
+    pkg = engine(SDPA_STREAMED=0)
+    chunked = pkg.attention(Q, K, V, precision="bf16")
+    pkg = engine(SDPA_STREAM_TIMEOUT_MS=200, SDPA_DEBUG="stream_drop_word=2")
     assert len(pkg.plan(m, n, d, d, 2, 1)["r"][0]["stream"]["end_tile"]) >= 2
     t0 = time.perf_counter()
-    with pytest.raises(pkg.SdpaError):
-        pkg.attention(Q, K, V, precision="bf16")
-    assert time.perf_counter() - t0 < 5.0
+    got = pkg.attention(Q, K, V, precision="bf16")          # falls back: the chunked schedule's result, no error
+    assert time.perf_counter() - t0 < 2.0
+    assert pkg.last_timing()["streamed"] == 0 and np.array_equal(got, chunked)
     pkg = engine()
     got = pkg.attention(Q, K, V, precision="bf16")
     assert pkg.last_timing()["streamed"] == 1 and np.array_equal(got, first[0])
