@@ -44,6 +44,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <string>
+#include <sched.h>
 #include <thread>
 #include <vector>
 
@@ -1691,10 +1692,81 @@ int host_cvt_mode() {
     return atoi(v) > 0 ? 1 : 0;
 }
 
+// CPUs this process can really keep busy: its affinity mask cut down to the container's CPU quota (cgroup v2 cpu.max, v1
+// cpu.cfs_quota_us / cpu.cfs_period_us).  std::thread::hardware_concurrency() says 256 on a GPU box whose container may use
+// 16 cores' worth of CPU time.  $SDPA_HOST_CORES overrides (tests pin the model with it).
+int effective_cores() {
+    if (const char *v = getenv("SDPA_HOST_CORES"))
+        if (*v && atoi(v) > 0) return atoi(v);
+    static const int cores = [] {
+        int n = (int)std::thread::hardware_concurrency();
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) n = CPU_COUNT(&set);
+        double quota = 0.0;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[64] = {0};
+            long period = 0;
+            if (fscanf(f, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) quota = atof(q) / (double)period;
+            fclose(f);
+        } else {
+            long q = -1, period = 0;
+            if (FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(fq, "%ld", &q) != 1) q = -1; fclose(fq); }
+            if (FILE *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(fp, "%ld", &period) != 1) period = 0; fclose(fp); }
+            if (q > 0 && period > 0) quota = (double)q / (double)period;
+        }
+        if (quota >= 1.0 && quota < n) n = (int)(quota + 0.5);
+        return n < 1 ? 1 : n;
+    }();
+    return cores;
+}
+
+// two threads per usable core (the rows are half load, half convert/store: 32 threads on a 16-core quota measured ~100 GB/s of
+// fp64 source), at most 128
 int host_convert_thread_count() {
-    const int hw = (int)std::thread::hardware_concurrency();
-    const int dflt = std::max(1, std::min(32, hw > 4 ? hw - 2 : 1));
+    const int cores = effective_cores();
+    const int dflt = cores > 4 ? std::min(128, 2 * cores) : std::max(1, cores - 1);
     return env_int("SDPA_HOST_CVT_THREADS", dflt);
+}
+
+// ---- the feed model (round 6): where the fp64 -> operand converts of a call should run, for P ranks -----------
+// ONE converter pool serves every rank of the process, each rank has its OWN PCIe link and its own kernels:
+//   t_host   = every rank's inputs (K, V once; Q once -- the K/V plan's ranks read the same rows) / the pool's rate
+//   t_link   = ONE rank's fp64 inputs (its K/V shard + every Q row it scores) / 55 GB/s -- what device converts pull over the link
+//   t_kernel = one rank's fused kernels over the whole call
+// Host converts (and with them the streamed first batch) pay while the pool is not what everybody waits for.  At P = 1 the rules
+// of rounds 3-5 stand.  At P > 1 page-locked arrays go to the device converts + the launch-per-chunk schedule once
+// t_host > 1.1 max(t_kernel, t_link).  Measured (profiles/r06/feed_model_p8.log): on the GPU boxes' host the pool is NOT what P = 8
+// waits for at the BASELINE shapes -- config 3: 570 MB in 2.9-3.6 ms against 4.2 ms of kernel per rank; the metric shape: 0.9-1.1 ms
+// against 1.06 ms of kernel and 0.92 ms of link -- so they keep host converts and the streamed launches; a host with a slower pool
+// (fewer usable cores) or a shape with less kernel per byte flips to the device converts.  Pageable arrays keep the pool whatever P is (a pageable source makes the
+// runtime stage through ITS bounce buffers on the enqueueing thread: slower than the pool at any P) -- the pool itself is sized
+// by the cores the process may really use.  sdpa_plan_describe() prints the three times and both decisions.
+struct FeedModel {
+    int cores = 0, threads = 0;
+    double pool_Bps = 0.0, t_host = 0.0, t_link = 0.0, t_kernel = 0.0;
+    bool host_ok = false, streamable = false;
+};
+FeedModel feed_model(const Plan &pl) {
+    FeedModel f;
+    f.cores = effective_cores();
+    f.threads = host_convert_thread_count();
+    f.host_ok = f.cores >= 16 && f.threads >= 8;
+    // 5.0-6.4 GB/s of fp64 source per busy thread, measured with 8 loopback ranks' worth of work on the pool (config 3: 570 MB in
+    // 2.9-3.6 ms = 160-194 GB/s over the span with 32 threads; metric shape 168 MB in 0.90-1.09 ms; config 4 268 MB in 1.34-1.74 ms:
+    // profiles/r06/feed_model_p8.log), up to what the host's memory delivers to streaming readers.  (The boxes' 16-core cgroup quota
+    // is CPU TIME per 100 ms period -- 1.6 CPU-seconds: a 3 ms burst of 32 threads uses 0.1 of it and is not throttled; the quota
+    // sizes the pool, it does not slow a call down.)
+    f.pool_Bps = std::min(240e9, std::max(1, f.threads) * 5.3e9);
+    const double P = std::max(1, pl.P);
+    const double m_rank = pl.qrows ? (double)pl.m / P : (double)pl.m;
+    const double keys_rank = pl.qrows ? (double)pl.n : (double)pl.n / P;
+    f.t_host = ((double)pl.n * (pl.dk + pl.dv) + (double)pl.m * pl.dk) * 8.0 / f.pool_Bps;
+    f.t_link = (keys_rank * (pl.dk + pl.dv) + m_rank * pl.dk) * 8.0 / 55e9;           // fp64 over PCIe Gen5 x16, as measured
+    const double rate = pl.bf16 ? 1.0e15 : (pl.dk <= 256 ? 1.3e14 : 1.0e14);
+    f.t_kernel = 2.0 * m_rank * keys_rank * (pl.dk + pl.dv) / rate;
+    for (const RankPlan &rp : pl.r) f.streamable = f.streamable || rp.stream.on;
+    return f;
 }
 
 // `pageable`: the caller's input arrays are neither page-locked already nor about to be registered -- the device converts
@@ -1705,25 +1777,21 @@ bool want_host_cvt(const Plan &pl, bool pageable) {
     if (mode != 2) return mode == 1;
     const double elems = (double)pl.m * pl.dk + (double)pl.n * pl.dk + (double)pl.n * pl.dv;
     if (elems < 1e6) return false;                                   // latency bound either way
-    const bool host_ok = (int)std::thread::hardware_concurrency() >= 16 && host_convert_thread_count() >= 8;
-    if (pageable) return host_ok;
-    // page-locked caller arrays: the streamed first batch (StreamPlan) can only be fed by the copy engine -- a device
-    // convert kernel could not run beside the persistent launch -- and the host converts cost the call nothing where
-    // the kernels cover the transfer (metric shape 9.0 vs 9.1-9.2 ms, profiles/r04/hostlevel_all_configs.log)
-    for (const RankPlan &rp : pl.r)
-        if (rp.stream.on && host_ok) return true;
-    if (pl.P != 1) return false;
-    const double t_link = elems * 8.0 / 55e9;                        // fp64 over PCIe Gen5 x16, as measured
-    const double rate = pl.bf16 ? 1.0e15 : (pl.dk <= 256 ? 1.3e14 : 1.0e14);
-    const double t_kernel = 2.0 * pl.m * (double)pl.n * (pl.dk + pl.dv) / rate;
-    // ... and only where the HOST can do it faster than the link would have carried the fp64 bytes: the
-    // convert threads read 8 B and write 2-4 B per element at ~3 GB/s of source per thread, ~100 GB/s for the whole
-    // pool on the box this was measured on (profiles/r03/host_convert_numa_probe.log); a host with few hardware
-    // threads keeps the device converts
-    const int threads = host_convert_thread_count();
-    if ((int)std::thread::hardware_concurrency() < 16 || threads < 8) return false;
-    const double t_host = elems * 8.0 / std::min(100e9, threads * 3.2e9);
-    return t_link > 1.4 * t_kernel && t_host < t_link;
+    const FeedModel f = feed_model(pl);
+    if (pageable) return f.host_ok;
+    if (pl.P == 1) {
+        // page-locked caller arrays: the streamed first batch (StreamPlan) can only be fed by the copy engine -- a device
+        // convert kernel could not run beside the persistent launch -- and the host converts cost the call nothing where
+        // the kernels cover the transfer (metric shape 9.0 vs 9.1-9.2 ms, profiles/r04/hostlevel_all_configs.log)
+        if (f.streamable && f.host_ok) return true;
+        // ... otherwise only where the HOST can do it faster than the link would have carried the fp64 bytes
+        if (!f.host_ok) return false;
+        return f.t_link > 1.4 * f.t_kernel && f.t_host < f.t_link;
+    }
+    // P > 1, page-locked: the streamed launches with host converts while ONE pool keeps up with P ranks, else every rank pulls
+    // its fp64 shard over its own link and converts on the device (launch per chunk)
+    if (!f.streamable || !f.host_ok) return false;
+    return f.t_host <= 1.1 * std::max(f.t_kernel, f.t_link);
 }
 
 // ---- where the result is widened to fp64 ($SDPA_HOST_WIDEN) ---------------------------------------------
@@ -1749,7 +1817,7 @@ bool want_host_widen(const Plan &pl, bool pageable_result = true) {
     if (mode != 2) return mode == 1;
     if ((double)pl.m * pl.dv < 256.0 * 1024.0) return false;
     if (pageable_result) return true;
-    return (int)std::thread::hardware_concurrency() >= 16 && host_convert_thread_count() >= 8;
+    return effective_cores() >= 16 && host_convert_thread_count() >= 8;
 }
 
 // the converter pool is created on first use (32 threads, $SDPA_HOST_CVT_THREADS)
@@ -2477,7 +2545,15 @@ int sdpa_plan_describe(int m, int n, int dk, int dv, int flags, int ranks, char 
         }
         o += "]}}";
     }
-    o += "]}";
+    {
+        // the feed model of this plan: the three times (ms) and where the converts run for pageable / page-locked caller arrays
+        const FeedModel f = feed_model(pl);
+        snprintf(t, sizeof t, "], \"feed\": {\"cores\": %d, \"pool_threads\": %d, \"pool_GBps\": %.1f, \"t_host_ms\": %.3f, "
+                 "\"t_link_ms\": %.3f, \"t_kernel_ms\": %.3f, \"pageable\": \"%s\", \"page_locked\": \"%s\"}}",
+                 f.cores, f.threads, f.pool_Bps / 1e9, f.t_host * 1e3, f.t_link * 1e3, f.t_kernel * 1e3,
+                 want_host_cvt(pl, true) ? "host" : "device", want_host_cvt(pl, false) ? "host" : "device");
+        o += t;
+    }
     if (o.size() + 1 > len) return SDPA_EINVAL;
     memcpy(buf, o.c_str(), o.size() + 1);
     return SDPA_OK;

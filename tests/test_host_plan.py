@@ -226,3 +226,68 @@ def test_streamed_first_batch_plan_on_the_baseline_shapes(pkg, monkeypatch):
         assert pkg.plan(m, n, d, d, flags, 1)["r"][0]["stream"]["on"] == 0, (m, n, d, flags)
     monkeypatch.setenv("SDPA_STREAMED", "0")
     assert pkg.plan(32768, 65536, 128, 128, 0, 1)["r"][0]["stream"]["on"] == 0
+
+
+# ---- the feed model (round 6): where the fp64 -> operand converts run, for P ranks sharing ONE host -------------
+CONFIG3, METRIC, CONFIG4 = (32768, 262144, 128, 128), (32768, 65536, 128, 128), (131072, 65536, 128, 128)
+
+
+@pytest.mark.parametrize("shape,ranks,page_locked", [
+    # ONE pool serves every rank; each rank has its own PCIe link and its own kernels.  Host converts (and with them the streamed
+    # first batch) while the pool keeps up, device converts + launch per chunk once t_host > 1.1 max(t_kernel, t_link)
+    (CONFIG3, 1, "host"), (CONFIG3, 2, "host"), (CONFIG3, 8, "host"),       # P = 8: 570 MB through the pool in 3.4 ms (measured 2.9-3.6) under 4.2 ms of kernel per rank
+    (METRIC, 1, "host"), (METRIC, 2, "host"), (METRIC, 8, "host"),          # P = 8: 1.0 ms of pool (measured 0.9-1.1) beside 1.06 ms of kernel, 0.9 ms of link
+    (CONFIG4, 1, "host"), (CONFIG4, 2, "host"), (CONFIG4, 8, "device"),     # P = 8: four 1-ms batches leave 16 CUs to the comm streams --
+                                                                            # stream-K grids have no streamed form: device converts, as before
+])
+def test_feed_model_choice_for_the_baseline_shapes(shape, ranks, page_locked, pkg, monkeypatch):
+    """pinned for the GPU boxes' host as the library sees it: a 16-core CPU quota ($SDPA_HOST_CORES stands in for cgroup cpu.max here),
+    32 pool threads, ~170 GB/s of fp64 source (measured: profiles/r06/feed_model_p8.log).  Pageable caller arrays keep the pool at every P (device converts would pull them
+    through the runtime's bounce buffers on the enqueueing threads); page-locked ones follow the model."""
+    monkeypatch.setenv("SDPA_HOST_CORES", "16")
+    for k in ("SDPA_HOST_CVT", "SDPA_HOST_CVT_THREADS", "SDPA_STREAMED"):
+        monkeypatch.delenv(k, raising=False)
+    m, n, dk, dv = shape
+    f = pkg.plan(m, n, dk, dv, 0, ranks)["feed"]
+    assert f["cores"] == 16 and f["pool_threads"] == 32 and abs(f["pool_GBps"] - 169.6) < 0.5, f
+    assert f["pageable"] == "host" and f["page_locked"] == page_locked, f
+    # the three times are the documented arithmetic
+    total = (n * (dk + dv) + m * dk) * 8.0
+    per_rank = (n / ranks * (dk + dv) + m * dk) * 8.0
+    assert abs(f["t_host_ms"] - total / 169.6e9 * 1e3) < 0.01 * f["t_host_ms"] + 0.002, f
+    assert abs(f["t_link_ms"] - per_rank / 55e9 * 1e3) < 0.01 * f["t_link_ms"] + 0.002, f
+    assert abs(f["t_kernel_ms"] - 2.0 * m * (n / ranks) * (dk + dv) / 1.3e14 * 1e3) < 0.01 * f["t_kernel_ms"] + 0.002, f
+
+
+def test_feed_model_follows_the_hosts_real_core_count(pkg, monkeypatch):
+    """the pool is sized by the CPUs the process may really use (affinity mask cut down to the cgroup quota), two threads per core, at
+    most 128; a small host keeps the device converts; a big one lifts the pool's rate and with it the P = 8 decision"""
+    for k in ("SDPA_HOST_CVT", "SDPA_HOST_CVT_THREADS", "SDPA_STREAMED"):
+        monkeypatch.delenv(k, raising=False)
+    m, n, dk, dv = CONFIG3
+    monkeypatch.setenv("SDPA_HOST_CORES", "8")
+    f = pkg.plan(m, n, dk, dv, 0, 1)["feed"]
+    assert f["pool_threads"] == 16 and f["pageable"] == "device" and f["page_locked"] == "device", f
+    monkeypatch.setenv("SDPA_HOST_CORES", "128")
+    f = pkg.plan(m, n, dk, dv, 0, 8)["feed"]
+    assert f["pool_threads"] == 128 and f["pool_GBps"] == 240.0 and f["page_locked"] == "host", f      # 2.4 ms of pool under 4.2 ms of kernel
+    # a pool that cannot keep up with eight ranks: page-locked arrays go to the device converts (every rank pulls its fp64 shard over
+    # its own link, launch per chunk), pageable ones stay with the pool
+    monkeypatch.setenv("SDPA_HOST_CORES", "16")
+    monkeypatch.setenv("SDPA_HOST_CVT_THREADS", "16")
+    f = pkg.plan(m, n, dk, dv, 0, 8)["feed"]
+    assert f["t_host_ms"] > 1.1 * max(f["t_kernel_ms"], f["t_link_ms"]) and f["page_locked"] == "device" and f["pageable"] == "host", f
+    assert pkg.plan(m, n, dk, dv, 0, 2)["feed"]["page_locked"] == "host"                               # ... but keeps up with two
+    monkeypatch.delenv("SDPA_HOST_CVT_THREADS")
+    monkeypatch.setenv("SDPA_HOST_CVT_THREADS", "12")
+    assert pkg.plan(m, n, dk, dv, 0, 8)["feed"]["pool_threads"] == 12
+    monkeypatch.delenv("SDPA_HOST_CORES")
+    monkeypatch.delenv("SDPA_HOST_CVT_THREADS")
+    f = pkg.plan(m, n, dk, dv, 0, 1)["feed"]                                                          # whatever this machine is: consistent
+    import os
+    assert 1 <= f["cores"] <= (os.cpu_count() or 1) and f["pool_threads"] >= 1, f
+    # the knob still overrides the model
+    monkeypatch.setenv("SDPA_HOST_CVT", "1")
+    assert pkg.plan(m, n, dk, dv, 0, 8)["feed"]["page_locked"] == "host"
+    monkeypatch.setenv("SDPA_HOST_CVT", "0")
+    assert pkg.plan(m, n, dk, dv, 0, 8)["feed"]["pageable"] == "device"
