@@ -110,7 +110,22 @@ def cpu_baseline(m, n, d, budget_rows=8192):
     except Exception:
         phys = 0
     avail = len(os.sched_getaffinity(0))
-    cores = max(1, min(avail, phys if phys > 0 else avail, 256))
+    # what this process may really keep busy: the affinity mask and the physical cores cut down to the container's CPU quota
+    # (cgroup v2 cpu.max / v1 cpu.cfs_quota_us).  The GPU boxes show 256 CPUs of a 2 x 64-core host and grant 16 cores'
+    # worth of CPU time: "the reference on 128 cores" would be 128 ranks time-slicing 16.
+    quota = None
+    try:
+        if os.path.exists("/sys/fs/cgroup/cpu.max"):
+            q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            quota = None if q == "max" else float(q) / float(period)
+        else:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = q / period if q > 0 and period > 0 else None
+    except (OSError, ValueError):
+        quota = None
+    host_cores = max(1, min(avail, phys if phys > 0 else avail, 256))
+    cores = max(1, min(host_cores, int(quota + 0.5) if quota and quota >= 1 else host_cores))
     if os.path.exists(exe) and os.path.exists(mpiexec) and "avx512f" in cpuinfo:
         try:
             ans = np.concatenate([O.numpy_attention_f64(Q[i:i + 256], K, V) for i in range(0, rows, 256)])
@@ -131,11 +146,12 @@ def cpu_baseline(m, n, d, budget_rows=8192):
                 probe_path = os.path.join(td, "probe.bin")
                 O.write_case(probe_path, Q[:probe_rows], K, V, ans[:probe_rows])
                 tried = {}
-                for r in sorted({cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8)}, reverse=True):
+                # (around the cores this process may use: the quota, half, a quarter, and twice it -- MPICH's shared-memory
+                #  ranks spin while they wait, so oversubscribing the quota is expected to lose; it is measured, not assumed)
+                for r in sorted({cores, max(1, cores // 2), max(1, cores // 4), min(host_cores, 2 * cores)}, reverse=True):
                     tried[r] = probe_rows / (run_ref(exe, probe_path, r) * 1e-6)
                 best_ranks = max(tried, key=tried.get)
                 best = min(run_ref(exe, path, best_ranks) for _ in range(2))
-                all_cores_us = best if best_ranks == cores else run_ref(exe, path, cores)
                 # the documented build line has no -O flag (README.md:131): time that binary too,
                 # on a quarter of the sample
                 doc = None
@@ -153,8 +169,7 @@ def cpu_baseline(m, n, d, budget_rows=8192):
                         sample=sample, tflops=flop / (best * 1e-6) / 1e12, cpu=model,
                         build="attention-mpi.c unmodified, mpicc -O3 + AVX-512 flags, MPICH ch3:nemesis, "
                               "its own Elapsed time (best of 2) at the best of the probed rank counts",
-                        physical_cores=cores,
-                        all_physical_cores={"ranks": cores, "value": rows / (all_cores_us * 1e-6), "unit": "Q-rows/s"},
+                        effective_cores=cores, cpu_quota_cores=quota, cpus_in_affinity_mask=avail, physical_cores_of_the_host=phys or None,
                         rank_probe={"rows": probe_rows, "q_rows_per_s": {str(k): v for k, v in sorted(tried.items())}},
                         documented_flags=doc)
         except Exception as e:  # noqa: BLE001
@@ -165,7 +180,8 @@ def cpu_baseline(m, n, d, budget_rows=8192):
     orc.shard_partial_f32(Qf, Kf, Vf)
     dt = time.perf_counter() - t0
     return dict(value=rows / dt, unit="Q-rows/s", cores=orc.threads(), kind="port", sample=sample,
-                tflops=flop / dt / 1e12, cpu=model, build="oracle/sdpa_oracle.c, gcc -O2 -fopenmp")
+                tflops=flop / dt / 1e12, cpu=model, build="oracle/sdpa_oracle.c, gcc -O2 -fopenmp",
+                effective_cores=cores, cpu_quota_cores=quota, cpus_in_affinity_mask=avail, physical_cores_of_the_host=phys or None)
 
 
 # the translation units (and their shared headers) that define the fused kernels of one precision
@@ -312,6 +328,54 @@ def boundary_timing(pkg, m, n, d, precision, reps=5, warm=3, pinned_leg=True, in
     finally:
         for ptr in bufs:
             lib.sdpa_host_free(ptr)
+    return out
+
+
+def cli_one_shot(dev, names=("headline", "config2"), runs=3):
+    """The reference's literal use and timed region (attention.c:179-189): `prog <file>` as a fresh process, ONE timed attention()
+    call.  Forks PKG/bin/attention-hip `runs` times on a generated file per workload (inputs drawn here; the file's answer block is
+    an fp64 torch restatement of attention.c:20-75 computed on this GPU -- independent of the library's kernels) and reports the
+    program's own `Elapsed time` (min / median), COLD: every run pays engine creation and sdpa_prepare() outside its timer and one
+    un-warmed call inside it.  `Correct!` is asserted."""
+    exe = os.path.join(ROOT, PKG, "bin", "attention-hip")
+    if not os.path.exists(exe):
+        return {"error": "bin/attention-hip not built"}
+    out = {"what": "PKG/bin/attention-hip <file>, a fresh process per run: the program's own 'Elapsed time' around its ONE attention() "
+                   "call (host fp64 in/out, PCIe inclusive, page-locked arrays from its reader); %d runs per workload" % runs}
+    for name in names:
+        w = WORKLOADS[name]
+        m, n, d = w["m"], w["n"], w["d"]
+        try:
+            g = torch.Generator(device=dev)
+            g.manual_seed(4242)
+            Q, K, V = (torch.rand(s, generator=g, device=dev, dtype=torch.float64) * 2 - 1 for s in ((m, d), (n, d), (n, d)))
+            ans = torch.empty((m, d), dtype=torch.float64, device=dev)
+            for i in range(0, m, 4096):          # fp64 three-pass softmax, a block of rows at a time (4096 x n scores = 2 GiB at n = 65536)
+                sc = (Q[i:i + 4096] @ K.T) / float(np.sqrt(d))
+                sc = torch.exp(sc - sc.max(dim=1, keepdim=True).values)
+                ans[i:i + 4096] = (sc / sc.sum(dim=1, keepdim=True)) @ V
+                del sc
+            with tempfile.TemporaryDirectory(dir="/tmp") as td:
+                path = os.path.join(td, name + ".bin")
+                with open(path, "wb") as f:       # the reference's file format, attention.c:92-99 / :139-140
+                    f.write(np.asarray([m, n, d, d], dtype="<i4").tobytes())
+                    for t in (Q, K, V, ans):
+                        f.write(t.cpu().numpy().astype("<f8").tobytes())
+                del Q, K, V, ans
+                torch.cuda.empty_cache()
+                us, stages = [], None
+                for _ in range(runs):
+                    r = subprocess.run([exe, path], capture_output=True, text=True, timeout=300, env=dict(os.environ, SDPA_VERBOSE="1"))
+                    mt = re.match(r"Correct!\nElapsed time: ([0-9.]+) us\n$", r.stdout)
+                    if r.returncode != 0 or not mt:
+                        raise RuntimeError("rc %d, stdout %r, stderr tail %r" % (r.returncode, r.stdout[:80], r.stderr[-300:]))
+                    us.append(float(mt.group(1)))
+                    stages = [l for l in r.stderr.split("\n") if "head" in l and "tail" in l][-1:] or stages
+            out[name] = {"workload": "%s: m=%d n=%d dk=dv=%d" % (name, m, n, d), "elapsed_ms": [round(x / 1e3, 3) for x in us],
+                         "min_ms": min(us) / 1e3, "median_ms": float(np.median(us)) / 1e3, "correct": True,
+                         "q_rows_per_s_median": m / (float(np.median(us)) * 1e-6), "stages_last_run": stages[0].strip() if stages else None}
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
 
 
@@ -908,6 +972,7 @@ def main():
     ap.add_argument("--no-configs", action="store_true",
                     help="N = 1: skip the record of the other BASELINE configs (config 2, 4, 5 in bf16 and in fp32) that follows")
     ap.add_argument("--no-c-host", action="store_true", help="N > 1: skip the C-host probe (one process, SDPA_GPUS = N)")
+    ap.add_argument("--no-cli", action="store_true", help="N = 1: skip the cold one-shot runs of bin/attention-hip")
     ap.add_argument("--host", default="py", choices=["py", "c"],
                     help="py = one process per GPU, torch.distributed over RCCL (the contract's launch); c = time the C "
                          "host's own schedule: ONE process, sdpa_attention_f64 with page-locked host fp64 in/out on --gpus N "
@@ -1152,6 +1217,21 @@ def main():
                 line["boundary"] = boundary_timing(pkg, m, n, d, args.precision)
             except Exception as e:  # noqa: BLE001
                 line["boundary"] = {"error": str(e)}
+        # the one-shot CLI, cold: what a user of the reference's command line sees
+        if (world == 1 and not qrows and args.emulate_ranks <= 1 and not force_dist and not args.no_boundary and not args.no_cli
+                and args.workload == "headline" and args.precision == "f32"):
+            try:
+                job.release()
+                del be
+                torch.cuda.empty_cache()
+                line["cli_one_shot"] = cli_one_shot(dev)
+            except Exception as e:  # noqa: BLE001
+                line["cli_one_shot"] = {"error": str(e)}
+        # where the host-level call of this problem would run its converts at THIS N (the feed model, sdpa_plan_describe)
+        try:
+            line["feed_model"] = pkg.plan(m, n, d, d, 2 if args.precision == "bf16" else 0, max(world, 1))["feed"]
+        except Exception as e:  # noqa: BLE001
+            line["feed_model"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(m, n, d)
         else:

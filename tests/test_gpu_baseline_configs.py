@@ -121,3 +121,39 @@ def test_config5_dims_fp32_dksplit(pkg, be, O):
     rows = np.sort(np.random.default_rng(9).choice(m, 64, replace=False))
     rows[0], rows[-1] = 0, m - 1
     check_rows(got[torch.from_numpy(rows).cuda()].cpu().numpy(), Q, K, V, rows, O, fp32_tol(V), "config 5 dims, fp32")
+
+
+# ---- whole-array parity against the REFERENCE'S OWN program ------------------------------------------------
+@pytest.mark.parametrize("name,m,n,d", [("config 2", 8192, 8192, 128), ("metric shape", 32768, 65536, 128)])
+def test_whole_result_against_the_reference_mpi_program(name, m, n, d, pkg, O, tmp_path):
+    """Every value of sdpa_attention_f64's result -- all m x dv of them, not a row subset -- against the raw result of the reference's
+    attention() (attention-mpi.c:191-407) run here under mpiexec through oracle/_ref/attention-mpi-dump (the reference file compiled
+    unmodified, only its main() replaced so that the result array can be written out).  Two fp32 pipelines with different summation
+    orders: 4e-6 * max(1, max|V|), NaN/Inf anywhere fails.  Skipped where the reference build is absent."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "oracle", "_ref", "attention-mpi-dump")
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if not (os.path.exists(exe) and os.path.exists(mpiexec)):
+        pytest.skip("oracle/_ref/attention-mpi-dump (the reference build) is not here")
+    Q, K, V = inputs(m, n, d, 71)
+    case = str(tmp_path / "case.bin")
+    O.write_case(case, Q, K, V, np.zeros((m, d)))
+    out = str(tmp_path / "ref.f32")
+    quota = 16
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = len(os.sched_getaffinity(0)) if q == "max" else max(1, int(float(q) / float(period)))
+    except (OSError, ValueError):
+        quota = len(os.sched_getaffinity(0))
+    ranks = max(1, min(16, quota, len(os.sched_getaffinity(0))))
+    r = subprocess.run([mpiexec, "-n", str(ranks), exe, case, out], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-800:]
+    ref = np.fromfile(out, dtype=np.float32).reshape(m, d).astype(np.float64)
+    got = pkg.attention(Q, K, V)
+    assert got.shape == ref.shape and np.isfinite(got).all() and np.isfinite(ref).all()
+    tol = 4e-6 * max(1.0, float(np.abs(V).max()))
+    err = np.abs(got - ref).max()
+    print("%s: all %d x %d values against the reference's MPI program at %d ranks: max|delta| %.3e (tol %.1e)" % (name, m, d, ranks, err, tol))
+    assert err <= tol

@@ -52,3 +52,11 @@ def test_bench_line_at_n1_carries_every_baseline_config():
     assert j["boundary"]["streamed"] == 1 and j["boundary"]["fused_launches"] == 1
     assert j["boundary"]["last_kernel"] == "sdpa::fused_pipelined_stream_kernel<128,128>"
     assert cfg["config2"]["boundary"]["streamed"] == 1 and cfg["config5_f32"]["boundary"]["streamed"] == 0
+    # round 6: the cold one-shot CLI runs (the reference's literal use, attention.c:179-189) and the host feed model ride along
+    cli = j["cli_one_shot"]
+    for k in ("headline", "config2"):
+        assert "error" not in cli[k], (k, cli[k])
+        assert cli[k]["correct"] is True and len(cli[k]["elapsed_ms"]) == 3 and cli[k]["min_ms"] <= cli[k]["median_ms"], cli[k]
+    assert cli["headline"]["median_ms"] < 3.0 * j["boundary"]["ms"] and "head" in (cli["headline"]["stages_last_run"] or "")
+    fm = j["feed_model"]
+    assert fm["pageable"] in ("host", "device") and fm["t_host_ms"] > 0 and fm["t_kernel_ms"] > fm["t_link_ms"] > 0, fm
