@@ -420,6 +420,11 @@ struct Chunk {
 // sdpa_dev_shard_partial_f32 on the resident shard, bit for bit.
 struct StreamPlan {
     bool on = false;
+    // Round 6 (built, measured, OFF by default -- make_plan says why): TWO launches of half the batch's rows
+    // each, back to back on the compute stream, each with the split count that fills the chip for ITS rows (twice the one-launch
+    // count).  The first half's merge, finish and device-to-host copy then run under the second half's MFMAs instead of behind the
+    // one launch -- with one launch nothing leaves early: all its workgroups are resident for its whole length and retire together.
+    int halves = 1, rows_per_launch = 0;
     int splits = 1, tiles_per_split = 0;
     std::vector<int> end_tile;          // per group
     std::vector<Chunk> entries;         // staging units in arrival order (group major, split minor)
@@ -661,11 +666,40 @@ void make_plan(Plan &pl, int m, int n, int dk, int dv, int flags, int ranks = 0)
         if (stream_knob && (!pl.bf16 || bf16_streamable) && !no_pipe && (pl.bf16 || sdpa::stream_launch_supported(dk, dv)) && rows0 > 0 &&
             rp.key_cnt >= 2 * scmin) {
             sdpa::F32Plan fp = {};
-            if (pl.bf16) {
-                fp.splits = sdpa::pick_kv_splits_bf16(rows0, rp.key_cnt, dk, dv);
-                fp.streamk = 0;
-            } else {
-                fp = sdpa::plan_f32_launch(rows0, rp.key_cnt, dk, dv, pl.cus);
+            auto plan_rows = [&](int rows) {
+                sdpa::F32Plan q = {};
+                if (pl.bf16) {
+                    q.splits = sdpa::pick_kv_splits_bf16(rows, rp.key_cnt, dk, dv);
+                    q.streamk = 0;
+                } else {
+                    q = sdpa::plan_f32_launch(rows, rp.key_cnt, dk, dv, pl.cus);
+                }
+                return q;
+            };
+            fp = plan_rows(rows0);
+            // two half-row launches where the rank sends its rows home itself, the row pieces pair up, each half still fills the
+            // chip within the streamed form's 8 splits, and a launch is long enough to hide a half's egress under (>= ~1.5 ms)
+            int halves = 1, rows_launch = rows0;
+            {
+                const int pieces0 = rows_piece0 > 0 ? (rows0 + rows_piece0 - 1) / rows_piece0 : 1;
+                const double rate = pl.bf16 ? 1.0e15 : (dk <= 256 ? 1.3e14 : 1.0e14);
+                const double t_launch = 2.0 * rows0 * (double)rp.key_cnt * (dk + dv) / rate;
+                // OFF by default -- a measured negative result (profiles/r06/two_wave_egress_ab.log, same box): the tail shrinks as
+                // intended (headline 0.50 -> 0.32 ms, config 5 in bf16 1.50 -> 0.89) but the launches lose more than that: twice the
+                // split slabs and a second ramp at the headline (kernels 8.22 -> 8.42 ms, call 9.01 -> 9.04), and where the call is LINK
+                // bound the first half cannot end before the last K/V group has landed, so the second half's MFMAs come BEHIND the
+                // transfer instead of under it (config 5 bf16: kernels 4.5 -> 5.7 ms, call 6.10 -> 6.73; config 3: 32.0 -> 32.8).
+                // $SDPA_DEBUG=two_wave=1 runs it (tests/test_gpu_host_pipeline.py keeps it bit-identical to the device-level halves).
+                const bool knob = debug_int("two_wave", 0) != 0;
+                if (knob && !pl.collectives && first_is_last && pieces0 >= 2 && pieces0 % 2 == 0 && rows0 % rows_piece0 == 0 && t_launch >= 3.0e-3) {
+                    const int half = pieces0 / 2 * rows_piece0;
+                    const sdpa::F32Plan h = plan_rows(half);
+                    if (!h.streamk && h.splits <= 8 && rows0 == 2 * half) {
+                        halves = 2;
+                        rows_launch = half;
+                        fp = h;
+                    }
+                }
             }
             const long nqb = (rows0 + sdpa::kQRowsPerBlock - 1) / sdpa::kQRowsPerBlock;
             // (at most 8 splits: every group crosses PCIe as `splits` row ranges of K and of V, and below ~256 KiB a
@@ -673,6 +707,8 @@ void make_plan(Plan &pl, int m, int n, int dk, int dv, int flags, int ranks = 0)
             (void)nqb;   // (a grid of more than one round is fine: later rounds find their words raised)
             if (!fp.streamk && fp.splits <= 8) {
                 StreamPlan &sp = rp.stream;
+                sp.halves = halves;
+                sp.rows_per_launch = rows_launch;
                 sp.splits = fp.splits;
                 const int ntiles = (rp.key_cnt + sdpa::kKvTile - 1) / sdpa::kKvTile;
                 sp.tiles_per_split = (ntiles + sp.splits - 1) / sp.splits;
@@ -725,7 +761,8 @@ void make_plan(Plan &pl, int m, int n, int dk, int dv, int flags, int ranks = 0)
                         }
                     }
                     sp.on = true;
-                    if (!pl.bf16) rp.ws_bytes = std::max(rp.ws_bytes, sdpa::workspace_bytes_for(rows0, dv, sp.splits));
+                    if (!pl.bf16) rp.ws_bytes = std::max(rp.ws_bytes, sdpa::workspace_bytes_for(rows_launch, dv, sp.splits));
+                    else rp.ws_bytes = std::max(rp.ws_bytes, launch_ws_bytes(pl, rows_launch, rp.key_cnt));
                     // (bf16: the launch's own scratch -- launch_ws_bytes(rows0, key_cnt) above -- holds its splits and redo flags)
                 }
             }
@@ -1288,27 +1325,12 @@ int rank_batch0_streamed(Call &c, int g) {
     for (int i = 0; i < sdpa::kStreamFlagStride; ++i) rk.h_gen[i] = c.stream_gen;     // (64 KiB: a few microseconds)
     *rk.h_status = 0;
 
-    // ---- 1. the launch
-    PartialArgs a = {};
-    a.Q = (const float *)rk.qf[s].p; a.ldq = pl.ldq;
-    a.K = (const float *)rk.kf.p;    a.ldk = pl.ldk;
-    a.V = (const float *)rk.vf.p;    a.ldv = pl.ldv;
-    a.m = bs; a.n_local = rp.key_cnt; a.dk = pl.dk; a.dv = pl.dv;
-    a.kv_splits = sp.splits;
-    a.cus = pl.cus;
-    a.contrib = (float *)rk.contrib[s].p; a.ldo = pl.ldo;
-    a.lmax = (float *)rk.stat[s].p;
-    a.lsum = (float *)rk.stat[s].p + bs;
-    if (a.kv_splits > 1) sdpa::carve_workspace(a, rk.ws.p, pl.ldo);
-    sdpa::StreamArgs st = {};
-    st.flags = rk.sflags;
-    st.gen = c.stream_gen;
-    st.n_chunks = (int)sp.end_tile.size();
-    for (int i = 0; i < st.n_chunks; ++i) st.chunk_end[i] = sp.end_tile[i];
-    st.q_piece_blocks = std::max(1, (pr + sdpa::kQRowsPerBlock - 1) / sdpa::kQRowsPerBlock);
-    st.timeout_ticks = c.stream_timeout_ticks;
-    st.status = rk.h_status;
-    st.abort = rk.sflags + (size_t)(sdpa::kStreamMaxChunks + sdpa::kStreamMaxPieces) * sdpa::kStreamFlagStride;
+    // ---- 1. the launch(es): ONE over the batch's rows, or (StreamPlan::halves == 2) one per half -- the second right behind the
+    //      first half's merge and finish kernels on the compute stream, so that the first half's rows cross PCIe and are widened
+    //      while the second half computes.  Both follow the same K/V groups; a half waits for ITS Q row pieces.
+    const int halves = sp.halves == 2 && finisher && pieces % 2 == 0 && sp.rows_per_launch * 2 == bs ? 2 : 1;
+    const int rows_launch = halves == 2 ? sp.rows_per_launch : bs;
+    const int pieces_launch = pieces / halves;
     auto bracket = [&]() -> int {              // timing event on rank 0's compute stream
         if (g != 0) return SDPA_OK;
         if ((int)root.ev_k.size() <= c.n_brackets) {
@@ -1319,27 +1341,53 @@ int rank_batch0_streamed(Call &c, int g) {
         HIP_TRY(hipEventRecord(root.ev_k[c.n_brackets++], root.s_run));
         return SDPA_OK;
     };
-    SDPA_TRY(bracket());
-    if (pl.bf16) {
-        Bf16Args b = {};
-        b.Q = (const unsigned short *)rk.qf[s].p;  b.ldq = pl.ldq;
-        b.K = (const unsigned short *)rk.kf.p;     b.ldk = pl.ldk;
-        b.Vt = (const unsigned short *)rk.vf.p;    b.ldvt = sdpa::bf16_pad_n(rp.key_cnt);
-        b.m = bs; b.n_local = rp.key_cnt; b.dk = pl.dk; b.dv = pl.dv;
-        b.kv_splits = sp.splits;
-        b.contrib = (float *)rk.contrib[s].p; b.ldo = pl.ldo;
-        b.lmax = (float *)rk.stat[s].p;
-        b.lsum = (float *)rk.stat[s].p + bs;
-        sdpa::bf16_carve_workspace(b, rk.ws.p, pl.ldo);
-        HIP_TRY(sdpa::launch_shard_partial_bf16_streamed(b, st, rk.s_run));
-    } else {
-        HIP_TRY(sdpa::launch_shard_partial_streamed(a, st, rk.s_run));
-    }
-    SDPA_TRY(bracket());
+    sdpa::StreamArgs st = {};
+    st.flags = rk.sflags;
+    st.gen = c.stream_gen;
+    st.n_chunks = (int)sp.end_tile.size();
+    for (int i = 0; i < st.n_chunks; ++i) st.chunk_end[i] = sp.end_tile[i];
+    st.q_piece_blocks = std::max(1, (pr + sdpa::kQRowsPerBlock - 1) / sdpa::kQRowsPerBlock);
+    st.timeout_ticks = c.stream_timeout_ticks;
+    st.status = rk.h_status;
+    st.abort = rk.sflags + (size_t)(sdpa::kStreamMaxChunks + sdpa::kStreamMaxPieces) * sdpa::kStreamFlagStride;
+    auto launch_half = [&](int h) -> int {
+        const size_t r0 = (size_t)h * rows_launch;
+        st.q_piece0 = h * pieces_launch;
+        SDPA_TRY(bracket());
+        if (pl.bf16) {
+            Bf16Args b = {};
+            b.Q = (const unsigned short *)rk.qf[s].p + r0 * pl.ldq;  b.ldq = pl.ldq;
+            b.K = (const unsigned short *)rk.kf.p;     b.ldk = pl.ldk;
+            b.Vt = (const unsigned short *)rk.vf.p;    b.ldvt = sdpa::bf16_pad_n(rp.key_cnt);
+            b.m = rows_launch; b.n_local = rp.key_cnt; b.dk = pl.dk; b.dv = pl.dv;
+            b.kv_splits = sp.splits;
+            b.contrib = (float *)rk.contrib[s].p + r0 * pl.ldo; b.ldo = pl.ldo;
+            b.lmax = (float *)rk.stat[s].p + r0;
+            b.lsum = (float *)rk.stat[s].p + bs + r0;
+            sdpa::bf16_carve_workspace(b, rk.ws.p, pl.ldo);
+            HIP_TRY(sdpa::launch_shard_partial_bf16_streamed(b, st, rk.s_run));
+        } else {
+            PartialArgs a = {};
+            a.Q = (const float *)rk.qf[s].p + r0 * pl.ldq; a.ldq = pl.ldq;
+            a.K = (const float *)rk.kf.p;    a.ldk = pl.ldk;
+            a.V = (const float *)rk.vf.p;    a.ldv = pl.ldv;
+            a.m = rows_launch; a.n_local = rp.key_cnt; a.dk = pl.dk; a.dv = pl.dv;
+            a.kv_splits = sp.splits;
+            a.cus = pl.cus;
+            a.contrib = (float *)rk.contrib[s].p + r0 * pl.ldo; a.ldo = pl.ldo;
+            a.lmax = (float *)rk.stat[s].p + r0;
+            a.lsum = (float *)rk.stat[s].p + bs + r0;
+            if (a.kv_splits > 1) sdpa::carve_workspace(a, rk.ws.p, pl.ldo);
+            HIP_TRY(sdpa::launch_shard_partial_streamed(a, st, rk.s_run));
+        }
+        SDPA_TRY(bracket());
+        return SDPA_OK;
+    };
+    SDPA_TRY(launch_half(0));
     if (c.first_kernel_us[g] == 0.0) c.first_kernel_us[g] = now_us() - c.t_enter;
     if (g == 0) {
         c.last_splits = sp.splits;
-        c.last_rows = bs;
+        c.last_rows = rows_launch;
         c.last_keys = rp.key_cnt;
         c.last_note = sdpa::last_launch_note();
     }
@@ -1374,10 +1422,21 @@ int rank_batch0_streamed(Call &c, int g) {
     HIP_TRY(hipEventRecord(rk.ev_q[s], rk.s_cp));
     if (g == 0) HIP_TRY(hipEventRecord(rk.ev_kv_done, rk.s_cp));
 
+    if (halves == 2) {
+        // the first half's rows: finished on the compute stream BEHIND its launch and IN FRONT of the second one (a finish kernel
+        // could not become resident beside a launch that owns the chip), shipped on the egress stream under the second launch.
+        // Enqueued only NOW, behind every copy of the call: the egress stream's wait for the finish kernel is a packet in a
+        // hardware queue the copy stream may share (5 streams, 4 queues) -- in front of the copies it would hold back the very
+        // bytes the first launch is waiting for.  The first launch cannot end before its last group has been enqueued, so the
+        // second one is never late.
+        for (int j = 0; j < pieces_launch; ++j) SDPA_TRY(finish_rows(c, g, s, bs, i0, j, j * pr, std::min(pr, bs - j * pr)));
+        SDPA_TRY(launch_half(1));
+    }
+
     // ---- 3. its rows: merged by the launcher's split-merge pass; a rank that finishes its own rows sends them home
     //      in row pieces (finish + D2H of piece j under the host's widening of piece j-1)
     if (finisher)
-        for (int j = 0; j < pieces; ++j) SDPA_TRY(finish_rows(c, g, s, bs, i0, j, j * pr, std::min(pr, bs - j * pr)));
+        for (int j = halves == 2 ? pieces_launch : 0; j < pieces; ++j) SDPA_TRY(finish_rows(c, g, s, bs, i0, j, j * pr, std::min(pr, bs - j * pr)));
     HIP_TRY(hipEventRecord(rk.ev_run[s], rk.s_run));
     if (finisher) HIP_TRY(hipEventRecord(rk.ev_out[s], rk.s_out));
     return SDPA_OK;
@@ -2530,8 +2589,8 @@ int sdpa_plan_describe(int m, int n, int dk, int dv, int flags, int ranks, char 
         // the streamed form of the first batch, where the shape allows it (taken when the call runs host converts):
         // splits of the ONE launch, tiles per split, the tile each group ends at, and the row ranges [first key, keys,
         // group] in the order they cross PCIe
-        snprintf(t, sizeof t, "], \"stream\": {\"on\": %d, \"splits\": %d, \"tiles_per_split\": %d, \"end_tile\": [",
-                 rp.stream.on ? 1 : 0, rp.stream.splits, rp.stream.tiles_per_split);
+        snprintf(t, sizeof t, "], \"stream\": {\"on\": %d, \"halves\": %d, \"rows_per_launch\": %d, \"splits\": %d, \"tiles_per_split\": %d, \"end_tile\": [",
+                 rp.stream.on ? 1 : 0, rp.stream.halves, rp.stream.rows_per_launch, rp.stream.splits, rp.stream.tiles_per_split);
         o += t;
         for (size_t c = 0; c < rp.stream.end_tile.size(); ++c) {
             snprintf(t, sizeof t, "%s%d", c ? ", " : "", rp.stream.end_tile[c]);

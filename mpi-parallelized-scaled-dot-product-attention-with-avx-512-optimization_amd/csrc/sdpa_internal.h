@@ -110,6 +110,7 @@ struct StreamArgs {
     int chunk_end[kStreamMaxChunks];      // tiles of a split's K/V range that are on the device once chunk c has landed
                                           // (strictly increasing; the last one covers the longest split)
     int q_piece_blocks;                   // query blocks per Q row piece (0 = Q is resident before the launch)
+    int q_piece0;                         // ... and the piece the launch's first query block belongs to (a launch over the second half of a batch)
     unsigned long long timeout_ticks;     // wall_clock64 ticks (100 MHz) one wait may last
     int *status;                          // device-visible word, set to 1 + the word's index when a wait timed out (results are garbage then)
     unsigned *abort;                      // device word: == gen once a wait of this launch has timed out (the others stop waiting)

@@ -487,19 +487,31 @@ def test_convert_placement_is_chosen_per_problem(engine, orc, O):
 
 
 # ------------------------------------------------- the streamed first batch (round 5): ONE persistent launch that follows its inputs -----
+def stream_halves(pkg, m, n, dk, dv, precision="f32"):
+    """how many launches the streamed first batch of this problem is (sdpa_plan_describe): 1, or 2 half-row launches (round 6)"""
+    sp = pkg.plan(m, n, dk, dv, 2 if precision == "bf16" else 0, 1)["r"][0]["stream"]
+    return (sp["halves"], sp["rows_per_launch"]) if sp["on"] else (1, 0)
+
+
 def device_level(pkg, Q, K, V, batch, precision="f32"):
     """the device-level path on resident inputs, batch after batch: converts, ONE fused launch per batch on the whole
-    shard (sdpa_dev_shard_partial_f32 / _bf16), finish -- what the streamed launch must reproduce bit for bit"""
+    shard (sdpa_dev_shard_partial_f32 / _bf16), finish -- what the streamed launch must reproduce bit for bit.  Where the
+    host runs the first batch as TWO half-row launches (round 6: the first half's rows leave under the second half's MFMAs),
+    so does this: the same device-level launch per half."""
     be = pkg.HipBackend("cuda:0")
     sa = pkg.ShardedAttention(be, precision=precision)
     n, dk = K.shape
     dv = V.shape[1]
     sa.load_kv_shard_f64(torch.from_numpy(K).cuda(), torch.from_numpy(V).cuda(), n, dk, dv)
+    halves, rows_launch = stream_halves(pkg, Q.shape[0], n, dk, dv, precision)
     out = []
     for i0 in range(0, Q.shape[0], batch):
-        qf = sa.convert_q(torch.from_numpy(Q[i0:i0 + batch]).cuda())
-        contrib, lmax, lsum = sa.batch_partial(qf)
-        out.append(be.finish_f64(contrib, lsum, dv).cpu().numpy())
+        rows = min(batch, Q.shape[0] - i0)
+        step = rows_launch if (i0 == 0 and halves == 2) else rows
+        for j0 in range(i0, i0 + rows, step):
+            qf = sa.convert_q(torch.from_numpy(Q[j0:j0 + step]).cuda())
+            contrib, lmax, lsum = sa.batch_partial(qf)
+            out.append(be.finish_f64(contrib, lsum, dv).cpu().numpy())
     return np.concatenate(out)
 
 
@@ -527,7 +539,7 @@ def test_streamed_first_batch_is_the_device_level_launch_bit_for_bit(m, n, dk, d
     assert t["streamed"] == 1 and t["host_convert_threads"] > 0, t
     assert "fused_pipelined" in t["last_kernel"], t["last_kernel"]
     if m <= batch:
-        assert t["fused_launches"] == 1 and t["last_kernel"].startswith("sdpa::fused_pipelined_stream_kernel<"), t
+        assert t["fused_launches"] == stream_halves(pkg, m, n, dk, dv)[0] and t["last_kernel"].startswith("sdpa::fused_pipelined_stream_kernel<"), t
     want = device_level(pkg, Q, K, V, batch)
     assert np.array_equal(got, want), "streamed launch differs from the device-level launch in %d values (max %.3e)" % (
         (got != want).sum(), np.abs(got - want).max())
@@ -602,6 +614,33 @@ def test_streamed_launch_from_page_locked_caller_arrays_and_on_loopback_ranks(en
     assert t["streamed"] == 1 and t["n_gpus"] == 2, t
     rows = np.arange(0, m, 171)
     check(got2[rows], O.numpy_attention_f64(Q, K, V, rows), V, "2 loopback ranks, streamed shards")
+
+
+@pytest.mark.parametrize("m,n,d,prec", [(32768, 65536, 128, "f32"), (32768, 65536, 512, "bf16")])
+def test_streamed_batch_in_two_half_row_launches_hides_the_first_halfs_egress(m, n, d, prec, engine, O):
+    """Round 6, behind $SDPA_DEBUG=two_wave=1: a one-batch call whose launch is long enough runs its streamed batch
+    as TWO launches of half the rows each (each with the split count that fills the chip for its rows); the first half's merge and
+    finish kernels sit between them on the compute stream and its rows cross PCIe and are widened under the second half's MFMAs.
+    Bit-identical to the device-level launches of the two halves; the default one launch differs only by the summation order of its
+    fewer splits (within the path's tolerance).  Built, measured, off by default: the tail shrinks, the launches lose more."""
+    precision = None if prec == "f32" else "bf16"
+    Q, K, V = O.make_inputs(m, n, d, d, "D1", seed=m + d)
+    pkg = engine()
+    assert stream_halves(pkg, m, n, d, d, prec)[0] == 1              # off by default: it did not pay (profiles/r06/two_wave_egress_ab.log)
+    pkg = engine(SDPA_DEBUG="two_wave=1")
+    assert stream_halves(pkg, m, n, d, d, prec)[0] == 2
+    got = pkg.attention(Q, K, V, precision=precision)
+    t = pkg.last_timing()
+    assert t["streamed"] == 1 and t["fused_launches"] == 2, t
+    assert np.array_equal(got, device_level(pkg, Q, K, V, 32768, precision=prec))
+    assert np.array_equal(pkg.attention(Q, K, V, precision=precision), got)
+    tol = fp32_tol(V) if prec == "f32" else bf16_tol(V)
+    rows = np.arange(0, m, 331)
+    check(got[rows], O.numpy_attention_f64(Q, K, V, rows), V, "two half-row launches", tol)
+    pkg = engine()
+    one = pkg.attention(Q, K, V, precision=precision)
+    assert pkg.last_timing()["streamed"] == 1 and pkg.last_timing()["fused_launches"] == 1
+    assert np.abs(one - got).max() <= 2 * tol
 
 
 def test_streamed_launch_that_loses_a_ready_word_falls_back_to_the_chunked_schedule(engine, O):
@@ -703,7 +742,7 @@ def test_streamed_bf16_first_batch_is_the_device_level_launch_bit_for_bit(m, n, 
     assert t["streamed"] == 1 and t["host_convert_threads"] > 0, t
     assert "fused_bf16_tandem" in t["last_kernel"], t["last_kernel"]
     if m <= batch:
-        assert t["fused_launches"] == 1 and t["last_kernel"].startswith("sdpa::fused_bf16_tandem_stream_kernel<"), t
+        assert t["fused_launches"] == stream_halves(pkg, m, n, dk, dv, "bf16")[0] and t["last_kernel"].startswith("sdpa::fused_bf16_tandem_stream_kernel<"), t
     want = device_level(pkg, Q, K, V, batch, precision="bf16")
     assert np.array_equal(got, want), "streamed bf16 launch differs from the device-level launch in %d values (max %.3e)" % (
         (got != want).sum(), np.abs(got - want).max())
