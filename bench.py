@@ -593,12 +593,27 @@ class Job:
         # next batch is the next step's.  All K steps' work, including the last reduce and
         # writeback, completes inside the timed region (flush() before the closing fence).
         sa, m, B, d = self.sa, self.m, self.B, self.d
-        sa.load_kv_shard_f64(self.K64, self.V64, self.n, d, d)             # attention-mpi.c:224-225
+        one_launch = self.nb == 1 and self.dist is None and self.precision == "f32"     # K, V and the one Q batch: ONE convert launch (round 6)
+        if one_launch:
+            qf0 = sa.load_kv_shard_and_q_f64(self.K64, self.V64, self.Q64[:min(m, B)], self.n, d, d)   # :224-225, :303
+        else:
+            sa.load_kv_shard_f64(self.K64, self.V64, self.n, d, d)         # attention-mpi.c:224-225
         for b in range(self.nb):
-            qf = sa.convert_q(self.Q64[b * B:min(m, (b + 1) * B)])         # :303,:325
+            qf = qf0 if one_launch else sa.convert_q(self.Q64[b * B:min(m, (b + 1) * B)])         # :303,:325
             if record:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
+            if self.dist is None and self.precision == "f32":
+                # one rank: no merge over ranks -- the batch's rows are finished by the launch's own merge pass (round 6:
+                # sdpa_dev_shard_attention_f64, merge of the in-GPU splits + step 5 + the fp64 writeback in ONE kernel; the
+                # bracket below therefore holds the fused kernel AND that finish)
+                self.finish_previous()
+                res = sa.batch_attention_f64(qf)                           # :333-338, :358-362, :373
+                if record:
+                    e1.record()
+                    self.kernel_events.append((e0, e1, qf.shape[0]))
+                self.carry["res"] = [res]                                  # (as below: the step keeps its last batch's rows)
+                continue
             contrib, lmax, lsum = sa.batch_partial(qf)                     # :333-338
             if record:
                 e1.record()

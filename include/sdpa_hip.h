@@ -319,6 +319,10 @@ SDPA_API int sdpa_dev_dense_ld(int d);
  * Replaces cvt_d2f_avx512 (attention-mpi.c:31-64).                           */
 SDPA_API int sdpa_dev_cvt_d2f(const double *src, float *dst, long rows, int cols,
                               int ld, void *stream);
+/* The same for up to three matrices in ONE launch (ABI 6: a short call's K, V and Q -- three launches' gaps are 3 % of config 2's
+ * step): arrays of `count` sources / destinations / rows / cols / lds; every image is sdpa_dev_cvt_d2f's bit for bit.           */
+SDPA_API int sdpa_dev_cvt_d2f_batch(int count, const double *const *src, float *const *dst, const long *rows, const int *cols,
+                                    const int *ld, void *stream);
 /* fp32 -> fp64 (exact).  Replaces cvt_f2d_avx512 (:68-101).                   */
 SDPA_API int sdpa_dev_cvt_f2d(const float *src, int ld, double *dst, long rows,
                               int cols, void *stream);
@@ -342,6 +346,16 @@ SDPA_API int sdpa_dev_shard_partial_f32(const float *Qf, int ldq, const float *K
                                         float *lmax, float *lsum, int m, int n_local,
                                         int dk, int dv, void *workspace, size_t workspace_bytes,
                                         void *stream);
+
+/* The single-shard call (ABI 6): the stage above followed by merge step 5 with gsum = lsum and the fp64 writeback
+ * (attention-mpi.c:358-362, :373) -- result[m x dv] dense fp64 -- with that finish fused into the merge of the in-GPU K/V splits where
+ * the launch has splits: one pass over the partial triples instead of three kernels.  contrib / lmax / lsum are scratch of the sizes
+ * sdpa_dev_shard_partial_f32 takes (lmax / lsum receive the merged statistics); the rows are bit for bit what
+ * sdpa_dev_shard_partial_f32 + sdpa_dev_finish_f64 produce.                                                                         */
+SDPA_API int sdpa_dev_shard_attention_f64(const float *Qf, int ldq, const float *Kf, int ldk, const float *Vf, int ldv,
+                                          float *contrib, int ldo, float *lmax, float *lsum, double *result, int m,
+                                          int n_local, int dk, int dv, void *workspace, size_t workspace_bytes,
+                                          void *stream);
 
 /* Merge step 3 (attention-mpi.c:346-351): corr = expf(lmax - gmax);
  * lsum *= corr; contrib row *= corr.                                          */

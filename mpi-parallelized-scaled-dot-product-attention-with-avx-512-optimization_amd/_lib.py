@@ -83,6 +83,11 @@ _PROTOS = {
                                             _c_void_p, _c_int, _c_void_p, _c_void_p,
                                             _c_int, _c_int, _c_int, _c_int,
                                             _c_void_p, _c_size_t, _c_void_p]),
+    "sdpa_dev_cvt_d2f_batch": (_c_int, [_c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "sdpa_dev_shard_attention_f64": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int,
+                                              _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p,
+                                              _c_int, _c_int, _c_int, _c_int,
+                                              _c_void_p, _c_size_t, _c_void_p]),
     "sdpa_dev_merge_rescale": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p,
                                         _c_int, _c_int, _c_void_p]),
     "sdpa_dev_merge_normalise": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p]),

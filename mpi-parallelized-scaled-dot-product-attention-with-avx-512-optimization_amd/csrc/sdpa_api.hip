@@ -198,6 +198,18 @@ int sdpa_dev_cvt_d2f(const double *src, float *dst, long rows, int cols, int ld,
     return SDPA_OK;
 }
 
+int sdpa_dev_cvt_d2f_batch(int count, const double *const *src, float *const *dst, const long *rows, const int *cols, const int *ld,
+                           void *stream) {
+    if (count < 1 || count > 3 || !src || !dst || !rows || !cols || !ld) return SDPA_EINVAL;
+    for (int k = 0; k < count; ++k) {
+        if (rows[k] < 0 || cols[k] <= 0 || check_ld(ld[k], cols[k])) return SDPA_EINVAL;
+        if (rows[k] > 0 && (!src[k] || !dst[k] || misaligned16(src[k]) || misaligned16(dst[k]))) return SDPA_EINVAL;
+    }
+    SDPA_TRY(require_device());
+    HIP_TRY(sdpa::launch_cvt_d2f_batch(count, src, dst, rows, cols, ld, (hipStream_t)stream));
+    return SDPA_OK;
+}
+
 int sdpa_dev_cvt_f2d(const float *src, int ld, double *dst, long rows, int cols, void *stream) {
     if (rows < 0 || cols <= 0 || ld < cols) return SDPA_EINVAL;
     if (rows == 0) return SDPA_OK;
@@ -248,6 +260,41 @@ int sdpa_dev_shard_partial_f32(const float *Qf, int ldq, const float *Kf, int ld
         sdpa::carve_workspace(a, workspace, sdpa::dense_ld(dv));
     }
     HIP_TRY(sdpa::launch_shard_partial(a, (hipStream_t)stream));
+    return SDPA_OK;
+}
+
+// The single-shard call: sdpa_dev_shard_partial_f32 + merge step 5 with gsum = lsum + the fp64 writeback, with the finish FUSED into
+// the merge of the in-GPU splits where the launch has splits (one pass over the slabs instead of split_merge, normalise and f2d)
+int sdpa_dev_shard_attention_f64(const float *Qf, int ldq, const float *Kf, int ldk, const float *Vf, int ldv, float *contrib,
+                                 int ldo, float *lmax, float *lsum, double *result, int m, int n_local, int dk, int dv,
+                                 void *workspace, size_t workspace_bytes, void *stream) {
+    if (m <= 0 || n_local < 0 || dk <= 0 || dv <= 0) return SDPA_EINVAL;
+    if (!Qf || !contrib || !lmax || !lsum || !result) return SDPA_EINVAL;
+    if (n_local > 0 && (!Kf || !Vf)) return SDPA_EINVAL;
+    if (check_ld(ldq, dk) || check_ld(ldk, dk) || check_ld(ldv, dv) || check_ld(ldo, dv)) return SDPA_EINVAL;
+    if (misaligned16(Qf) || misaligned16(Kf) || misaligned16(Vf) || misaligned16(contrib)) return SDPA_EINVAL;
+    SDPA_TRY(require_device());
+    PartialArgs a = {};
+    a.Q = Qf; a.ldq = ldq; a.K = Kf; a.ldk = ldk; a.V = Vf; a.ldv = ldv;
+    a.contrib = contrib; a.ldo = ldo; a.lmax = lmax; a.lsum = lsum;
+    a.m = m; a.n_local = n_local; a.dk = dk; a.dv = dv;
+    a.kv_splits = sdpa::pick_kv_splits(m, n_local, dk, dv, sdpa::stream_cus((hipStream_t)stream));
+    if (a.kv_splits > 1 && workspace && workspace_bytes < sdpa::workspace_bytes_for(m, dv, a.kv_splits) &&
+        workspace_bytes >= sdpa::workspace_bytes(m, n_local, dk, dv))
+        while (a.kv_splits > 1 && workspace_bytes < sdpa::workspace_bytes_for(m, dv, a.kv_splits)) --a.kv_splits;
+    if (a.kv_splits > 1) {
+        if (!workspace || workspace_bytes < sdpa::workspace_bytes_for(m, dv, a.kv_splits)) return SDPA_EINVAL;
+        if (misaligned16(workspace)) return SDPA_EINVAL;
+        sdpa::carve_workspace(a, workspace, sdpa::dense_ld(dv));
+        a.defer_merge = 1;                                        // the splits stay in their slabs ...
+        HIP_TRY(sdpa::launch_shard_partial(a, (hipStream_t)stream));
+        a.defer_merge = 0;
+        const sdpa::FinishTarget f = {result, nullptr};           // ... and ONE pass merges, normalises and widens them
+        HIP_TRY(sdpa::launch_split_merge_finish(a, f, (hipStream_t)stream));
+    } else {
+        HIP_TRY(sdpa::launch_shard_partial(a, (hipStream_t)stream));
+        HIP_TRY(sdpa::launch_finish_f64(contrib, ldo, lsum, result, m, dv, (hipStream_t)stream));
+    }
     return SDPA_OK;
 }
 

@@ -48,6 +48,39 @@ __global__ void cvt_d2f_kernel(const double *__restrict__ src, float *__restrict
     }
 }
 
+// Up to three such conversions in ONE launch (round 6: a short call's K, V and Q images -- config 2's step spends three launches and
+// their gaps on 12 MB of converts): the work items of the matrices back to back, each converted exactly as cvt_d2f_kernel does.
+struct CvtBatch {
+    const double *src[3];
+    float *dst[3];
+    long rows[3];
+    int cols[3], ld[3];
+    long first[4];          // first work item (one float4 of an image row) of each matrix; [3] = the total
+};
+__global__ void cvt_d2f_batch_kernel(CvtBatch b) {
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < b.first[3]; idx += (long)gridDim.x * blockDim.x) {
+        const int k = idx >= b.first[2] ? 2 : idx >= b.first[1] ? 1 : 0;
+        const long i = idx - b.first[k];
+        const int cols = b.cols[k], c4n = b.ld[k] / 4;
+        const double *src = b.src[k];
+        float4 o;
+        if (cols == b.ld[k]) {
+            const double2 x = reinterpret_cast<const double2 *>(src)[2 * i];
+            const double2 y = reinterpret_cast<const double2 *>(src)[2 * i + 1];
+            o = make_float4(__double2float_rn(x.x), __double2float_rn(x.y), __double2float_rn(y.x), __double2float_rn(y.y));
+        } else {
+            const long r = i / c4n;
+            const int c = (int)(i - r * c4n) * 4;
+            const double *s = src + r * cols + c;
+            o.x = c + 0 < cols ? __double2float_rn(s[0]) : 0.f;
+            o.y = c + 1 < cols ? __double2float_rn(s[1]) : 0.f;
+            o.z = c + 2 < cols ? __double2float_rn(s[2]) : 0.f;
+            o.w = c + 3 < cols ? __double2float_rn(s[3]) : 0.f;
+        }
+        reinterpret_cast<float4 *>(b.dst[k])[i] = o;
+    }
+}
+
 // dst[r*cols + c] = (double)src[r*ld + c]
 __global__ void cvt_f2d_kernel(const float *__restrict__ src, int ld, double *__restrict__ dst,
                                long rows, int cols) {
@@ -172,6 +205,26 @@ hipError_t launch_cvt_d2f(const double *src, float *dst, long rows, int cols, in
     if (rows <= 0) return hipSuccess;
     const long work = rows * (ld / 4);
     hipLaunchKernelGGL(cvt_d2f_kernel, dim3(stream_grid(work)), dim3(256), 0, s, src, dst, rows, cols, ld);
+    return hipGetLastError();
+}
+
+hipError_t launch_cvt_d2f_batch(int count, const double *const *src, float *const *dst, const long *rows, const int *cols, const int *ld,
+                                hipStream_t s) {
+    if (count < 1 || count > 3) return hipErrorInvalidValue;
+    CvtBatch b = {};
+    long at = 0;
+    for (int k = 0; k < 3; ++k) {
+        b.first[k] = at;
+        if (k < count && rows[k] > 0) {
+            b.src[k] = src[k]; b.dst[k] = dst[k]; b.rows[k] = rows[k]; b.cols[k] = cols[k]; b.ld[k] = ld[k];
+            at += rows[k] * (ld[k] / 4);
+        } else {
+            b.cols[k] = 4; b.ld[k] = 4;
+        }
+    }
+    b.first[3] = at;
+    if (at <= 0) return hipSuccess;
+    hipLaunchKernelGGL(cvt_d2f_batch_kernel, dim3(stream_grid(at)), dim3(256), 0, s, b);
     return hipGetLastError();
 }
 

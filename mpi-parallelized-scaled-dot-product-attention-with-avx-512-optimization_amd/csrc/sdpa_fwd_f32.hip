@@ -390,6 +390,43 @@ __global__ void split_merge_kernel(PartialArgs a) {
     }
 }
 
+// The same merge with the single-shard FINISH fused in (round 6): merge step 5 with gsum = the merged lsum (attention-mpi.c:358-362)
+// and the writeback (:373) -- the rows leave normalised and dense, as fp64 (out64) or as the fp32 the host widens (out32).  One pass
+// over the slabs instead of three kernels (split_merge, normalise / finish, f2d) and two 4-MB round trips through contrib.
+// Same sums in the same order and the same fp32 product x * (1 / tot) as finish_f64_kernel / finish_f32_kernel: the rows are the
+// separate kernels' bit for bit.
+__global__ void split_merge_finish_kernel(PartialArgs a, FinishTarget f) {
+    const int c4n = (a.dv + 3) / 4;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)a.m * c4n) return;
+    const int row = (int)(idx / c4n), c4 = (int)(idx % c4n);
+    float gm = -INFINITY;
+    for (int s = 0; s < a.kv_splits; ++s) gm = fmaxf(gm, a.ws_lmax[(size_t)s * a.ws_rows + row]);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float tot = 0.f;
+    for (int s = 0; s < a.kv_splits; ++s) {
+        const float lm = a.ws_lmax[(size_t)s * a.ws_rows + row];
+        const float w = (lm == -INFINITY) ? 0.f : expf(lm - gm);
+        tot = fmaf(w, a.ws_lsum[(size_t)s * a.ws_rows + row], tot);
+        const float4 o = *reinterpret_cast<const float4 *>(a.ws_contrib + ((size_t)s * a.ws_rows + row) * a.ws_ld + 4 * c4);
+        acc.x = fmaf(w, o.x, acc.x); acc.y = fmaf(w, o.y, acc.y);
+        acc.z = fmaf(w, o.z, acc.z); acc.w = fmaf(w, o.w, acc.w);
+    }
+    const float inv = (tot == 0.f) ? 0.f : 1.0f / tot;
+    const float v[4] = {acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv};
+    const size_t at = (size_t)row * a.dv + 4 * c4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (4 * c4 + i < a.dv) {
+            if (f.out64) f.out64[at + i] = (double)v[i];
+            if (f.out32) f.out32[at + i] = v[i];
+        }
+    if (c4 == 0 && a.lmax) {          // (the statistics, for callers that look at them)
+        a.lmax[row] = gm;
+        a.lsum[row] = tot;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Any-shape kernel (dk or dv > 128): one wave per query row, lanes across key
 // rows for the dot products and across value columns for the accumulate.  A
@@ -601,6 +638,15 @@ hipError_t launch_split_merge(const PartialArgs &a_in, hipStream_t s) {
     if (a.ws_rows <= 0) a.ws_rows = a.m;
     const long work = (long)a.m * ((a.dv + 3) / 4);
     hipLaunchKernelGGL(split_merge_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_merge_finish(const PartialArgs &a_in, const FinishTarget &f, hipStream_t s) {
+    PartialArgs a = a_in;
+    if (a.ws_rows <= 0) a.ws_rows = a.m;
+    if (!f.out64 && !f.out32) return hipErrorInvalidValue;
+    const long work = (long)a.m * ((a.dv + 3) / 4);
+    hipLaunchKernelGGL(split_merge_finish_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, a, f);
     return hipGetLastError();
 }
 

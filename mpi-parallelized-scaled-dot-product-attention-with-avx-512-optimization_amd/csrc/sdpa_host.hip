@@ -1281,16 +1281,22 @@ bool plan_progressive_pins(Call &c) {
 
 // Rows [j0, j0+jr) of the batch in slot s are complete in contrib[s]/stat[s]: step 5 with gsum = lsum fused with the
 // writeback (attention-mpi.c:358-362, :373), then they go home -- as fp32 rows that the host widens, or as fp64 rows.
-int finish_rows(Call &c, int g, int s, int bs, size_t i0, int ev, int j0, int jr) {
+// `finished`: the dense rows are in out64[s] already (the launch's fused merge + finish pass wrote them): only the copy home is left.
+int finish_rows(Call &c, int g, int s, int bs, size_t i0, int ev, int j0, int jr, bool finished = false) {
     const Plan &pl = c.pl;
     Rank &rk = E.r[g];
     const int dv = c.dv;
     need_pin(c, 3);                  // behind the enqueue of (nearly) all of the batch's kernels
-    if (c.widen)
+    if (c.widen) {
+        if (finished)
+            return ship_rows_f32(c, rk, i0 + j0, jr, (const float *)rk.out64[s].p + (size_t)j0 * dv, dv, nullptr,
+                                 (float *)rk.out64[s].p + (size_t)j0 * dv, rk.s_run, rk.ev_sub[s][ev], rk.s_out);
         return ship_rows_f32(c, rk, i0 + j0, jr, (const float *)rk.contrib[s].p + (size_t)j0 * pl.ldo, pl.ldo,
                              (const float *)rk.stat[s].p + bs + j0, (float *)rk.out64[s].p + (size_t)j0 * dv,
                              rk.s_run, rk.ev_sub[s][ev], rk.s_out);
-    HIP_TRY(sdpa::launch_finish_f64((const float *)rk.contrib[s].p + (size_t)j0 * pl.ldo, pl.ldo,
+    }
+    if (!finished)
+        HIP_TRY(sdpa::launch_finish_f64((const float *)rk.contrib[s].p + (size_t)j0 * pl.ldo, pl.ldo,
                                     (const float *)rk.stat[s].p + bs + j0,
                                     (double *)rk.out64[s].p + (size_t)j0 * dv, jr, dv, rk.s_run));
     HIP_TRY(hipEventRecord(rk.ev_sub[s][ev], rk.s_run));
@@ -1350,6 +1356,15 @@ int rank_batch0_streamed(Call &c, int g) {
     st.timeout_ticks = c.stream_timeout_ticks;
     st.status = rk.h_status;
     st.abort = rk.sflags + (size_t)(sdpa::kStreamMaxChunks + sdpa::kStreamMaxPieces) * sdpa::kStreamFlagStride;
+    // a rank that finishes its own rows: the launch's merge pass also normalises and writes the dense rows that go home (round 6:
+    // split_merge_finish_kernel -- the finish kernels of the row pieces and a round trip through contrib are gone)
+    const bool fused_finish = finisher && sp.splits > 1;
+    auto fin_of = [&](size_t r0) -> sdpa::FinishTarget {
+        sdpa::FinishTarget f = {nullptr, nullptr};
+        if (c.widen) f.out32 = (float *)rk.out64[s].p + r0 * c.dv;
+        else f.out64 = (double *)rk.out64[s].p + r0 * c.dv;
+        return f;
+    };
     auto launch_half = [&](int h) -> int {
         const size_t r0 = (size_t)h * rows_launch;
         st.q_piece0 = h * pieces_launch;
@@ -1365,7 +1380,14 @@ int rank_batch0_streamed(Call &c, int g) {
             b.lmax = (float *)rk.stat[s].p + r0;
             b.lsum = (float *)rk.stat[s].p + bs + r0;
             sdpa::bf16_carve_workspace(b, rk.ws.p, pl.ldo);
+            b.defer_merge = fused_finish ? 1 : 0;
             HIP_TRY(sdpa::launch_shard_partial_bf16_streamed(b, st, rk.s_run));
+            if (fused_finish) {
+                PartialArgs p = {};
+                p.lmax = b.lmax; p.lsum = b.lsum; p.m = b.m; p.dv = b.dv; p.kv_splits = b.kv_splits;
+                p.ws_contrib = b.ws_contrib; p.ws_ld = b.ws_ld; p.ws_lmax = b.ws_lmax; p.ws_lsum = b.ws_lsum; p.ws_rows = b.m;
+                HIP_TRY(sdpa::launch_split_merge_finish(p, fin_of(r0), rk.s_run));
+            }
         } else {
             PartialArgs a = {};
             a.Q = (const float *)rk.qf[s].p + r0 * pl.ldq; a.ldq = pl.ldq;
@@ -1378,7 +1400,12 @@ int rank_batch0_streamed(Call &c, int g) {
             a.lmax = (float *)rk.stat[s].p + r0;
             a.lsum = (float *)rk.stat[s].p + bs + r0;
             if (a.kv_splits > 1) sdpa::carve_workspace(a, rk.ws.p, pl.ldo);
+            a.defer_merge = fused_finish ? 1 : 0;
             HIP_TRY(sdpa::launch_shard_partial_streamed(a, st, rk.s_run));
+            if (fused_finish) {
+                a.defer_merge = 0;
+                HIP_TRY(sdpa::launch_split_merge_finish(a, fin_of(r0), rk.s_run));
+            }
         }
         SDPA_TRY(bracket());
         return SDPA_OK;
@@ -1429,14 +1456,15 @@ int rank_batch0_streamed(Call &c, int g) {
         // hardware queue the copy stream may share (5 streams, 4 queues) -- in front of the copies it would hold back the very
         // bytes the first launch is waiting for.  The first launch cannot end before its last group has been enqueued, so the
         // second one is never late.
-        for (int j = 0; j < pieces_launch; ++j) SDPA_TRY(finish_rows(c, g, s, bs, i0, j, j * pr, std::min(pr, bs - j * pr)));
+        for (int j = 0; j < pieces_launch; ++j) SDPA_TRY(finish_rows(c, g, s, bs, i0, j, j * pr, std::min(pr, bs - j * pr), fused_finish));
         SDPA_TRY(launch_half(1));
     }
 
     // ---- 3. its rows: merged by the launcher's split-merge pass; a rank that finishes its own rows sends them home
     //      in row pieces (finish + D2H of piece j under the host's widening of piece j-1)
     if (finisher)
-        for (int j = halves == 2 ? pieces_launch : 0; j < pieces; ++j) SDPA_TRY(finish_rows(c, g, s, bs, i0, j, j * pr, std::min(pr, bs - j * pr)));
+        for (int j = halves == 2 ? pieces_launch : 0; j < pieces; ++j)
+            SDPA_TRY(finish_rows(c, g, s, bs, i0, j, j * pr, std::min(pr, bs - j * pr), fused_finish));
     HIP_TRY(hipEventRecord(rk.ev_run[s], rk.s_run));
     if (finisher) HIP_TRY(hipEventRecord(rk.ev_out[s], rk.s_out));
     return SDPA_OK;

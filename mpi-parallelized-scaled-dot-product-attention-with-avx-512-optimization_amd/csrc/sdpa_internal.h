@@ -200,6 +200,13 @@ hipError_t launch_cvt_d2bf_t_part(const double *src, unsigned short *dst, long r
 hipError_t launch_cvt_bf_t_part(const unsigned short *src, unsigned short *dst, long rows, long rows_pad, int cols,
                                 int cols_pad, long ldt, hipStream_t s);
 hipError_t launch_split_merge(const PartialArgs &a, hipStream_t s);
+// ... with the single-shard finish fused in (round 6): the merged rows leave normalised and dense [m x dv], as fp64 and / or fp32
+// (split_merge_finish_kernel, sdpa_fwd_f32.hip); a.lmax / a.lsum (optional) receive the merged statistics, a.contrib is not written
+struct FinishTarget {
+    double *out64;
+    float *out32;
+};
+hipError_t launch_split_merge_finish(const PartialArgs &a, const FinishTarget &f, hipStream_t s);
 // The runtime loads a translation unit's device code object when one of its kernels is first used -- an upload that needs the GPU and
 // so WAITS for a resident persistent launch: the split merge enqueued right behind the first streamed bf16 launch of a process blocked
 // its enqueuing thread for the launch's whole timeout, in FRONT of the copies the launch was waiting for (round 5, call 22).  The engine
@@ -306,6 +313,9 @@ int dksplit_rows(int dk);
 hipError_t launch_shard_partial(const PartialArgs &a, hipStream_t s);
 
 hipError_t launch_cvt_d2f(const double *src, float *dst, long rows, int cols, int ld, hipStream_t s);
+// up to three fp64 -> fp32 images in one launch (each exactly launch_cvt_d2f's)
+hipError_t launch_cvt_d2f_batch(int count, const double *const *src, float *const *dst, const long *rows, const int *cols, const int *ld,
+                                hipStream_t s);
 hipError_t launch_cvt_f2d(const float *src, int ld, double *dst, long rows, int cols, hipStream_t s);
 hipError_t launch_merge_rescale(float *contrib, int ldo, float *lsum, const float *lmax,
                                 const float *gmax, int m, int dv, hipStream_t s);

@@ -186,6 +186,19 @@ class HipBackend:
                       "sdpa_dev_cvt_d2f")
         return out
 
+    def cvt_d2f_batch(self, xs):
+        """up to three cvt_d2f's in ONE launch (sdpa_dev_cvt_d2f_batch): a list of [rows, cols] f64 -> the list of their images"""
+        import ctypes
+        k = len(xs)
+        assert 1 <= k <= 3 and all(x.is_contiguous() and x.dtype == torch.float64 for x in xs)
+        outs = [self.empty((x.shape[0], dense_ld(x.shape[1])), torch.float32) for x in xs]
+        P, L, I = ctypes.c_void_p * k, ctypes.c_long * k, ctypes.c_int * k
+        with torch.cuda.device(self.device):
+            check(self.lib.sdpa_dev_cvt_d2f_batch(k, P(*[x.data_ptr() for x in xs]), P(*[o.data_ptr() for o in outs]),
+                                                  L(*[x.shape[0] for x in xs]), I(*[x.shape[1] for x in xs]),
+                                                  I(*[o.shape[1] for o in outs]), self._stream()), "sdpa_dev_cvt_d2f_batch")
+        return outs
+
     def cvt_f2d(self, x32, cols):
         """cvt_f2d_avx512 (attention-mpi.c:68-101)."""
         rows, ld = x32.shape
@@ -214,6 +227,26 @@ class HipBackend:
                 lmax.data_ptr(), lsum.data_ptr(), m, n_local, dk, dv,
                 self._ws.data_ptr() if need else None, need, self._stream()), "sdpa_dev_shard_partial_f32")
         return contrib, lmax, lsum
+
+    def shard_attention_f64(self, Qf, Kf, Vf, dk, dv):
+        """The single-shard call (sdpa_dev_shard_attention_f64): shard_partial + merge step 5 with gsum = lsum + the fp64
+        writeback (attention-mpi.c:358-362, :373), the finish fused into the merge of the in-GPU splits.  -> result [m, dv] fp64."""
+        m = Qf.shape[0]
+        n_local = Kf.shape[0]
+        ldo = max(round4(dv), Vf.shape[1])
+        contrib = self.empty((m, ldo), torch.float32)
+        stats = self.empty((2, m), torch.float32)
+        out = self.empty((m, dv), torch.float64)
+        need = self.lib.sdpa_dev_workspace_bytes(m, n_local, dk, dv)
+        if need and (self._ws is None or self._ws.numel() < need):
+            self._ws = self.empty((need,), torch.uint8)
+        with torch.cuda.device(self.device):
+            check(self.lib.sdpa_dev_shard_attention_f64(
+                Qf.data_ptr(), Qf.shape[1], Kf.data_ptr() if n_local else None, Kf.shape[1],
+                Vf.data_ptr() if n_local else None, Vf.shape[1], contrib.data_ptr(), ldo,
+                stats[0].data_ptr(), stats[1].data_ptr(), out.data_ptr(), m, n_local, dk, dv,
+                self._ws.data_ptr() if need else None, need, self._stream()), "sdpa_dev_shard_attention_f64")
+        return out
 
     # ---- bf16-input MFMA variant (BASELINE config 5) -------------------------------------
     def cvt_d2bf(self, x64, ld=None):
@@ -396,6 +429,16 @@ class ShardedAttention:
             self.Kf = self.be.cvt_d2f(K64_local)
             self.Vf = self.be.cvt_d2f(V64_local)
 
+    def load_kv_shard_and_q_f64(self, K64_local, V64_local, Q64, n, dk, dv):
+        """load_kv_shard_f64 + convert_q of a call's ONLY Q batch in one launch (fp32 path: sdpa_dev_cvt_d2f_batch) -> the Q image"""
+        if self.precision != "f32" or min(K64_local.shape[0], Q64.shape[0]) == 0:
+            self.load_kv_shard_f64(K64_local, V64_local, n, dk, dv)
+            return self.convert_q(Q64)
+        self.n, self.dk, self.dv = n, dk, dv
+        self.n_local = K64_local.shape[0]
+        self.Kf, self.Vf, qf = self.be.cvt_d2f_batch([K64_local, V64_local, Q64])
+        return qf
+
     def convert_q(self, Q64):
         """Q batch fp64 -> operand image (attention-mpi.c:303,:325)."""
         return self.be.cvt_d2bf_q(Q64) if self.precision == "bf16" else self.be.cvt_d2f(Q64)
@@ -409,6 +452,11 @@ class ShardedAttention:
         if self.precision == "bf16":
             return self.be.shard_partial_bf16(Qf, self.Kf, self.Vf, self.n_local, self.dk, self.dv)
         return self.be.shard_partial(Qf, self.Kf, self.Vf, self.dk, self.dv)
+
+    def batch_attention_f64(self, Qf):
+        """one rank, no merge over ranks: the batch's finished fp64 rows in one call (fused kernel + ONE finishing pass)"""
+        assert self.dist is None and self.precision == "f32"
+        return self.be.shard_attention_f64(Qf, self.Kf, self.Vf, self.dk, self.dv)
 
     def batch_merge(self, contrib, lmax, lsum, async_reduce=False):
         """Steps 2-5 and 7 of the reference loop.  Returns (contrib, work): on the root `contrib`

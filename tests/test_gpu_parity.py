@@ -663,3 +663,27 @@ def test_steep_softmax_exercises_the_rescale_paths(m, n, dk, dv, pkg, be, orc, O
     check(got, orc.attention_f64(Q, K, V), V, "steep")
     # and through the host-level path with several in-GPU splits / batches
     check(pkg.attention(Q, K, V), orc.attention_f64(Q, K, V), V, "steep host")
+
+
+@pytest.mark.parametrize("m,n,dk,dv", [(8192, 8192, 128, 128), (700, 9000, 72, 40), (300, 5000, 200, 300), (4096, 4096, 64, 128), (256, 64, 128, 128)])
+def test_single_shard_call_with_the_fused_finish_equals_the_separate_kernels(m, n, dk, dv, pkg, be, O):
+    """sdpa_dev_shard_attention_f64 (round 6): the fused kernel, then ONE pass that merges the in-GPU splits, normalises (merge step 5
+    with gsum = lsum, attention-mpi.c:358-362) and writes fp64 (:373) -- against sdpa_dev_shard_partial_f32 + sdpa_dev_finish_f64
+    (split_merge, then finish): the same rows bit for bit, with and without in-GPU splits, padded dims included."""
+    Q, K, V = O.make_inputs(m, n, dk, dv, "D2", seed=m + n + dk)
+    sa = pkg.ShardedAttention(be)
+    sa.load_kv_from_root(K, V, n, dk, dv)
+    qf = sa.convert_q(torch.from_numpy(Q).cuda())
+    contrib, lmax, lsum = sa.batch_partial(qf)
+    want = be.finish_f64(contrib, lsum, dv)
+    got = sa.batch_attention_f64(qf)
+    assert torch.equal(got, want), "fused finish differs in %d values" % int((got != want).sum())
+    check(got.cpu().numpy(), O.numpy_attention_f64(Q, K, V), V, "single-shard call")
+
+
+def test_batched_convert_writes_the_single_converters_images(be):
+    """sdpa_dev_cvt_d2f_batch: three matrices of different shapes (dense and padded rows) in one launch == three sdpa_dev_cvt_d2f"""
+    xs = [torch.randn(r, c, dtype=torch.float64, device="cuda") * 3 for r, c in ((8192, 128), (700, 72), (33, 300))]
+    for got, x in zip(be.cvt_d2f_batch(xs), xs):
+        assert torch.equal(got, be.cvt_d2f(x))
+    assert torch.equal(be.cvt_d2f_batch(xs[:1])[0], be.cvt_d2f(xs[0]))
