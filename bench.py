@@ -497,9 +497,7 @@ def kernel_name_of(d, precision):
         return "sdpa::fused_pipelined_kernel<%d,%d,0,0>" % (d, d)
     if 128 < d <= 512:
         dks = 128 if d > 384 else 96 if d > 256 else 64
-        piped = os.environ.get("SDPA_DKSPLIT_PIPE", "1") != "0"
-        return ("sdpa::fused_dksplit_pipe_kernel<%d,%d,2>" if piped else "sdpa::fused_dksplit_kernel<%d,%d,2>") % (
-            dks, 128 if d > 256 else 64)
+        return "sdpa::fused_dksplit_pipe_kernel<%d,%d,2>" % (dks, 128 if d > 256 else 64)
     return "sdpa::fused_partial_kernel / generic_partial_kernel"
 
 

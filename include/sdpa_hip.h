@@ -25,6 +25,26 @@
  *      and a caller-supplied hipStream_t (passed as void*), for hosts that own
  *      device memory and collectives themselves (one process per GPU with RCCL
  *      through torch.distributed: bench.py, the package's Python host).
+ *
+ * Environment (the WHOLE list; read once per call on the calling thread; anything else lives in $SDPA_DEBUG):
+ *   SDPA_GPUS=N              use N devices (default: every visible one that passes the RCCL self-test)
+ *   SDPA_VIRTUAL_GPUS=P      P loopback ranks on ONE device (the P > 1 pipeline on a one-GPU machine; tests)
+ *   SDPA_PRECISION=bf16      as SDPA_F_BF16            SDPA_PLAN=qrows    as SDPA_F_PLAN_QROWS
+ *   SDPA_MERGE=allreduce     as SDPA_F_MERGE_ALLREDUCE  SDPA_EGRESS=root|scatter   who copies result rows home (P > 1)
+ *   SDPA_COMM_CUS=k          compute units left to RCCL's kernels when several ranks are driven (default 16)
+ *   SDPA_RCCL_SELFTEST_TIMEOUT_S   deadline of sdpa_init()'s self-test (default 60)
+ *   SDPA_QBATCH=rows         query rows per batch (default: the whole array up to 32768)
+ *   SDPA_STREAMED=0|1        the first batch as ONE persistent launch fed by the copy engine (default: when the start-up probe passed)
+ *   SDPA_STREAM_TIMEOUT_MS   how long such a launch waits for a chunk before it gives up and the call re-runs chunked (default 500)
+ *   SDPA_HOST_CVT=0|1|auto   fp64 -> operand converts on the device / on host threads / by the feed model (default auto)
+ *   SDPA_HOST_CVT_THREADS    size of the converter pool (default 2 x the cores the process may use, <= 128)
+ *   SDPA_HOST_WIDEN=0|1|auto result rows widened to fp64 on the device / on host threads (default auto)
+ *   SDPA_HOST_REGISTER=1     page-lock the caller's arrays for the call (off: INTEGRATION.md says why)
+ *   SDPA_PREPARE_WARM_MS     sdpa_prepare()'s clock warm-up (default 60, 0 = off)
+ *   SDPA_CLI_PREFETCH=1      the CLI hosts hand K/V rows over while they are still reading the file
+ *   SDPA_VERBOSE=1           one timing line per call on stderr
+ *   SDPA_DEBUG="name=value,..."    every test / tuning / experiment knob (csrc/sdpa_debug.h lists them; not an interface)
+ *   (the package's ctypes loader, bench.py and tools/ also read SDPA_HIP_LIB: the path of a differently built copy of this library)
  */
 #ifndef SDPA_HIP_H
 #define SDPA_HIP_H
@@ -115,7 +135,7 @@ struct sdpa_timing {
     int    last_grid;     /* its workgroups                                                          */
     int    streamed;      /* 1 = the first Q batch ran as ONE persistent launch that followed the K/V */
                           /* chunks as they arrived (round 5), 0 = one launch per chunk               */
-    int    host_convert_node; /* $SDPA_HOST_CVT_PIN=1 (opt-in): the NUMA node the converter pool's threads */
+    int    host_convert_node; /* $SDPA_DEBUG host_cvt_pin=1 (opt-in): the NUMA node the converter pool's threads */
                           /* were confined to for this call (where the source arrays' pages live);     */
                           /* -1 = every CPU the process may use (the default)                          */
 };
@@ -130,7 +150,7 @@ struct sdpa_timing {
  * transport passes the self-test; $SDPA_GPUS=N forces a count).
  * $SDPA_VIRTUAL_GPUS=P makes the engine P logical ranks that all live on
  * device 0 (own streams and buffers each, loopback collectives): the P > 1
- * pipeline on a one-GPU machine.  $SDPA_FORCE_COLLECTIVES=1 runs the merge
+ * pipeline on a one-GPU machine.  $SDPA_DEBUG force_collectives=1 runs the merge
  * collectives even with one rank (a one-rank RCCL communicator).
  *
  * Threading: the engine is one process-wide object; the host-level entry
@@ -157,7 +177,7 @@ SDPA_API const char *sdpa_version(void);
 #define SDPA_ABI_VERSION 6
 SDPA_API int sdpa_abi_version(void);
 
-/* The launch paths read their environment knobs ($SDPA_STREAMK, $SDPA_SPLIT_MERGE, $SDPA_DKSPLIT_PIPE,
+/* The launch paths read their knobs ($SDPA_DEBUG: streamk, split_merge)
  * from ONE snapshot, taken at first use and by every host-level entry point on the
  * calling thread: the launchers run on the engine's enqueue threads, and the C environment must not be
  * read there while the application may setenv().  A device-level host that changes one of these knobs
@@ -206,7 +226,7 @@ SDPA_API int sdpa_last_timing(struct sdpa_timing *out);
 /* Optional: size the engine for one problem before the timed call -- allocates every device
  * buffer sdpa_attention_f64(m,n,dk,dv,flags) will use and runs a small problem of the same
  * dk, dv through the same code path so that code objects are loaded, then keeps the matrix
- * cores busy for ~25 ms on zeroed operands ($SDPA_PREPARE_WARM_MS, 0 = off): from idle the core
+ * cores busy for ~60 ms on zeroed operands ($SDPA_PREPARE_WARM_MS, 0 = off): from idle the core
  * clock needs about that long to reach its plateau, and a host that makes ONE timed call would
  * time it on the ramp.  The analogue of the reference doing MPI_Init and its transport set-up
  * outside the timer (attention-mpi.c:10-17, :504); sdpa_attention_f64 works without it, the first
@@ -254,7 +274,7 @@ SDPA_API void  sdpa_host_free(void *p);
  * dv > 256 shape -- kind 1's values with 16-byte chunk c of row r (counted from dst, which must be an image row that is a multiple
  * of 16) stored at chunk position c ^ (r & min(15, ld/8 - 1)), ld = the padded dk.  flags bit 0: the plain C
  * rows instead of the AVX-512 ones; bit 1 / bit 2: streaming (non-temporal) stores for line-aligned
- * destination rows on / off (neither: the pool's default, $SDPA_HOST_CVT_NT) -- the same bytes either way.  This is what $SDPA_HOST_CVT=1 runs on a pool of host threads inside
+ * destination rows on / off (neither: the pool's default, streaming) -- the same bytes either way.  This is what $SDPA_HOST_CVT=1 runs on a pool of host threads inside
  * sdpa_attention_f64 (the reference's own placement of the converts, :224-225, :303); it needs no GPU.  */
 SDPA_API int sdpa_host_cvt_rows(const double *src, void *dst, long rows, int cols, int ld, int kind,
                                 double mult, int flags);

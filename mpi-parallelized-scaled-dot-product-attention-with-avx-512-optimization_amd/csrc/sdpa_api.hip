@@ -8,6 +8,7 @@
 #include "sdpa_errors.h"
 #include "sdpa_hostcvt.h"
 #include "sdpa_internal.h"
+#include "sdpa_debug.h"
 
 #include <stdint.h>
 #include <stdio.h>
@@ -66,12 +67,8 @@ namespace {
 std::atomic<const LaunchKnobs *> knobs_now{nullptr};
 const LaunchKnobs *read_knobs() {
     LaunchKnobs *k = new LaunchKnobs;      // (snapshots are never freed: a launcher on another thread may still hold one)
-    const char *v = getenv("SDPA_SPLIT_MERGE");
-    k->split_merge_kernel = (v && strcmp(v, "kernel") == 0) ? 1 : 0;
-    v = getenv("SDPA_DKSPLIT_PIPE");
-    k->dksplit_pipe = !(v && *v) || atoi(v) != 0;
-    v = getenv("SDPA_STREAMK");
-    k->streamk = (!(v && *v) || strcmp(v, "auto") == 0) ? -1 : (atoi(v) != 0 ? 1 : 0);
+    k->split_merge_kernel = sdpa_debug_is("split_merge", "kernel") ? 1 : 0;
+    k->streamk = (!sdpa_debug_find("streamk") || sdpa_debug_is("streamk", "auto")) ? -1 : (sdpa_debug_int("streamk", 0) != 0 ? 1 : 0);
     return k;
 }
 }  // namespace

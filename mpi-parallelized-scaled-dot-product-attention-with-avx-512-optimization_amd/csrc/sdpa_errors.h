@@ -1,5 +1,6 @@
 // sdpa_errors.h -- error plumbing shared by the C-ABI translation units (internal).
 #pragma once
+#include "sdpa_debug.h"
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -40,7 +41,7 @@ inline int round4(int x) { return (x + 3) / 4 * 4; }
 // of ONE shader engine per XCD while the dispatcher keeps dealing workgroups to the engines evenly, so a few
 // workgroups per XCD queue for a second round; the masked stream is also a BLOCKING stream (it synchronises
 // with the legacy NULL stream) and its bit -> XCD layout depends on the partition mode.
-// $SDPA_RESERVE_BY_MASK=1 keeps the masked form for A/B runs.  Kernels without a stream-K form (dk-split, bf16,
+// $SDPA_DEBUG reserve_by_mask=1 keeps the masked form for A/B runs.  Kernels without a stream-K form (dk-split, bf16,
 // 256-wide fp32) launch their full grids on such a stream as on any other.
 inline int create_masked_stream(hipStream_t *out, int reserve_cus) {
     int dev = 0;
@@ -54,8 +55,7 @@ inline int create_masked_stream(hipStream_t *out, int reserve_cus) {
     }
     int r = (reserve_cus + xcds - 1) / xcds * xcds;
     if (r > cus / 2) r = cus / 2 / xcds * xcds;
-    const char *by_mask = getenv("SDPA_RESERVE_BY_MASK");
-    if (by_mask && atoi(by_mask) != 0) {
+    if (sdpa_debug_int("reserve_by_mask", 0) != 0) {
         // (the mask's bits are dealt round-robin over the XCDs, bit i -> XCD i % xcds: the same number from each)
         unsigned mask[32] = {0};
         for (int i = 0; i < cus - r; ++i) mask[i / 32] |= 1u << (i % 32);

@@ -25,6 +25,7 @@
 //   * workgroup = 4 waves x 32 query rows, 32-row K/V tiles, register-staged double buffer,
 //     one barrier per tile (the structure of fused_partial_kernel).
 #include "sdpa_internal.h"
+#include "sdpa_debug.h"
 
 #include <math.h>
 #include <stdint.h>
@@ -1150,10 +1151,10 @@ int bf16_pad_dv(int dv) { const int ch = bf16_chunk_dv(dv); return (dv + ch - 1)
 long bf16_pad_n(long n) { return (n + 31) / 32 * 32; }
 
 // Which shapes take the two-query-blocks-per-wave kernel: dk and dv both within one 256-wide
-// operand (SDPA_BF16_DUO=0 keeps them on the general kernel -- both are exact paths; the switch
+// operand ($SDPA_DEBUG bf16_duo=0 keeps them on the general kernel -- both are exact paths; the switch
 // exists for A/B timing).
 bool bf16_uses_duo(int dk, int dv) {
-    static const int enabled = getenv("SDPA_BF16_DUO") ? atoi(getenv("SDPA_BF16_DUO")) : 1;
+    static const int enabled = sdpa_debug_int("bf16_duo", 1);
     return enabled && dk <= 256 && dv <= 256;
 }
 // kernels with a fixed reference exponent flag blocks for a second pass: one int per (split, 128-row block)
@@ -1333,8 +1334,8 @@ static hipError_t launch_shard_partial_bf16_impl(const Bf16Args &args, const Str
     hipError_t e = hipErrorInvalidValue;
     LaunchNote main_note = {};
     bool have_main = false;
-#ifdef SDPA_ABLATIONS   // tools/ builds only: the shipped library never reads $SDPA_TUNE
-    static const int tune = getenv("SDPA_TUNE") ? atoi(getenv("SDPA_TUNE")) : 0;
+#ifdef SDPA_ABLATIONS   // tools/ builds only: the shipped library never reads $SDPA_DEBUG tune
+    static const int tune = sdpa_debug_int("tune", 0);
     if (kp == 512 && vc == 256 && ((tune >> 8) & 15)) {   // timing-only ablations, pipelined kernel
         switch ((tune >> 8) & 15) {
             case 1: return launch_bf16_pipe<512, 256, 1>(a, s);     // no DMA / V staging
@@ -1351,7 +1352,7 @@ static hipError_t launch_shard_partial_bf16_impl(const Bf16Args &args, const Str
     if (vc == 512) {
         if ((reinterpret_cast<uintptr_t>(a.K) & 15) || (reinterpret_cast<uintptr_t>(a.Vt) & 15) || !a.redo)
             return hipErrorInvalidValue;
-#ifdef SDPA_ABLATIONS   // tools/ builds only ($SDPA_TUNE bit 12): the STREAM kernel on resident images, every ready word raised beforehand --
+#ifdef SDPA_ABLATIONS   // tools/ builds only ($SDPA_DEBUG tune bit 12): the STREAM kernel on resident images, every ready word raised beforehand --
         // what the persistent form's waits and extra arguments cost the kernel itself (profiles/r05/bf16_stream_kernel_resident_ab.log)
         static StreamArgs self_st = {};
         if (!st && (tune & 4096)) {

@@ -36,12 +36,13 @@
 //                                   accumulator file, asm score chains: 137 TFLOP/s at dk = dv = 256)
 //   fused_partial_kernel<DKP,DVP>   any dk <= 256 (padded to 32/64/128/256), any dv (chunks of <= 128
 //                                   columns): register-staged
-//   (fused_dksplit_kernel<DKS,DVS,QB>, 256 < dk <= 1024 and non-dense 128 < dk <= 256 with dv > 128, lives in
+//   (fused_dksplit_pipe_kernel<DKS,DVS,QB>, 256 < dk <= 1024 and non-dense 128 < dk <= 256 with dv > 128, lives in
 //    sdpa_fwd_f32_dksplit.hip)
 //   generic_partial_kernel          dk > 1024: VALU-only correctness path
 //   split_merge_kernel              merge of the in-GPU K/V splits
 //
 #include "sdpa_f32_device.h"
+#include "sdpa_debug.h"
 
 #include <math.h>
 #include <algorithm>
@@ -329,9 +330,9 @@ __global__ __launch_bounds__(256, (DKP > 128) ? 1 : 2) void fused_partial_kernel
 //     pieces left per tile are the (rare) accumulator rescale and the barrier.
 //   * K is staged two tiles ahead, V one tile ahead, in two buffers each.
 // ---------------------------------------------------------------------------
-// ABL: timing-only ablation switches (results are wrong when non-zero; $SDPA_TUNE selects them):
+// ABL: timing-only ablation switches (results are wrong when non-zero; $SDPA_DEBUG tune selects them):
 //   1 = no DMA / no barrier in the steady state, 2 = no LDS fragment reads, 4 = no softmax VALU
-// MERGE: 1 = the launch merges its K/V splits itself (arrival words, $SDPA_SPLIT_MERGE=kernel); the shipped
+// MERGE: 1 = the launch merges its K/V splits itself (arrival words, $SDPA_DEBUG split_merge=kernel); the shipped
 // default instantiation carries none of that code
 // SK: 1 = stream-K work distribution (round 4).  The launch's n_qblocks x ntiles tile steps (query block
 // major) are cut into gridDim.x equal runs of `kv_per_split` steps, one per workgroup = one per RESIDENT
@@ -567,7 +568,7 @@ F32Plan plan_f32_launch(int m, int n_local, int dk, int dv, int cus) {
     const double slab_s = 2.0 * m * (double)dense_ld(dv) * sizeof(float) / 3.0e12;
     p.splits = splits_for_full_rounds(blocks, slots, want, cap, kernel_s, slab_s);
 
-    // ---- stream-K instead?  (pipelined kernels only; $SDPA_STREAMK = 0 / 1 / auto)
+    // ---- stream-K instead?  (pipelined kernels only; $SDPA_DEBUG streamk = 0 / 1 / auto)
     const int knob = launch_knobs().streamk;
     if (knob == 0 || !streamk_dims(dk, dv)) return p;
     const long total = blocks * ntiles;          // tile steps of the launch (blocks = query blocks here)
@@ -702,7 +703,7 @@ static hipError_t launch_pipelined(const PartialArgs &a, hipStream_t s) {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     const float scale = 1.0f / sqrtf((float)a.dk);   // attention-mpi.c:208
     // kv_splits > 1: the partial triples are merged by split_merge_kernel right behind.  The kernel can
-    // also merge them itself ($SDPA_SPLIT_MERGE=kernel: the last workgroup of a query
+    // also merge them itself ($SDPA_DEBUG split_merge=kernel: the last workgroup of a query
     // block to arrive does it, one launch per step) -- same sums in the same order, bit for bit
     // (tests/test_gpu_parity.py) -- but measured SLOWER on MI355X (profiles/r03/split_merge_forms_ab.log:
     // config 2 0.301 vs 0.273 ms per step, a 1/8 rank share 1.013 vs 0.993): the separate pass spreads
@@ -792,8 +793,8 @@ hipError_t launch_shard_partial_streamed(const PartialArgs &a_in, const StreamAr
 hipError_t launch_shard_partial(const PartialArgs &a_in, hipStream_t s) {
     PartialArgs a = a_in;
     if (a.ws_rows <= 0) a.ws_rows = a.m;
-#ifdef SDPA_ABLATIONS   // tools/ builds only: the shipped library never reads $SDPA_TUNE
-    static const int tune_env = getenv("SDPA_TUNE") ? atoi(getenv("SDPA_TUNE")) : 0;
+#ifdef SDPA_ABLATIONS   // tools/ builds only: the shipped library never reads $SDPA_DEBUG tune
+    static const int tune_env = sdpa_debug_int("tune", 0);
     a.tune = tune_env;
 #else
     a.tune = 0;
@@ -801,7 +802,7 @@ hipError_t launch_shard_partial(const PartialArgs &a_in, hipStream_t s) {
     // Operand images whose rows are 64 / 128 / 256 floats wide (dims padded with zero columns, the
     // header's contract for columns [dk, ld)) take the software-pipelined LDS-DMA kernel of that width:
     // same padded MFMA work as the any-shape kernels, at the pipelined kernel's rate.  The softmax
-    // scale is 1/sqrt of the TRUE dk; contrib rows must hold the padded width ($SDPA_TUNE&4: off).
+    // scale is 1/sqrt of the TRUE dk; contrib rows must hold the padded width ($SDPA_DEBUG tune&4: off).
     const int kp = a.ldq, vp = a.ldv;
     const bool dense = a.ldq == a.ldk && (kp == 64 || kp == 128 || kp == 256) && kp >= a.dk &&
                        (vp == 64 || vp == 128 || vp == 256) && vp >= a.dv && a.ldo >= vp && a.ldo % 4 == 0 &&
@@ -812,7 +813,7 @@ hipError_t launch_shard_partial(const PartialArgs &a_in, hipStream_t s) {
         if (kp == 256 && vp == 128) return launch_pipelined<256, 128>(a, s);
         if (kp == 128 && vp == 256) return launch_pipelined<128, 256>(a, s);
     }
-    if (uses_dksplit(a.dk, a.dv) && !(a.tune & 8))     // $SDPA_TUNE&8: the kernels it replaced
+    if (uses_dksplit(a.dk, a.dv) && !(a.tune & 8))     // $SDPA_DEBUG tune&8: the kernels it replaced
         return launch_dksplit(a, s);                    // sdpa_fwd_f32_dksplit.hip
     if (a.dk > kMaxMfmaDk) {
         size_t lds = (size_t)4 * a.ldq * sizeof(float);

@@ -30,251 +30,9 @@ namespace sdpa {
 // 256 MFMAs of 64 cycles per wave and tile against 32 KiB of global reads: matrix-pipe bound.
 // Same outputs and the same online-softmax arithmetic as fused_partial_kernel.
 // ---------------------------------------------------------------------------
-// ONE kernel for both block counts.  The second block's statements are spelled out under
-// `if constexpr (QB == 2)` rather than looped over an array of score tiles: written as loops over
-// `sx[QB]`, hipcc vectorises the exchange sums differently and spills (-5 % at dk = dv = 512); this form
-// compiles, for QB = 2 and for QB = 1, to the instruction mix of the two kernels it replaces
-// (tests/test_kernel_isa.py).
-template <int DKS, int DVS, int QB>
-__global__ __launch_bounds__(256, 1) void fused_dksplit_kernel(
-    PartialArgs a, int kv_per_split, int n_qblocks, int n_chunks, float scale) {
-    SDPA_AUDIT_LAUNCH(g_dks_audit);
-    // DKS: dk slice of one wave (dk is treated as padded to 4*DKS = 256, 384, 512, 768 or 1024)
-    static_assert(QB == 1 || QB == 2, "one or two query blocks");
-    constexpr int ROWS = 32 * QB;
-    constexpr int NU = DKS / 8;         // 16-byte K reads (4 MFMA k-steps each) per tile per lane
-    constexpr int NT = DVS / 32;        // 32-row O^T blocks per wave; also floats per V read
-    constexpr int XLD = 20;             // floats per lane in the exchange buffer: 16 + pad, b128 conflict-free
-    constexpr int XBUF = 4 * QB * 64 * XLD;  // 4 waves x QB query blocks x 64 lanes
-    constexpr int PD = 4;               // fragment prefetch depth (16-byte reads in flight)
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][XBUF]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31;
-    const int hi = lane >> 5;
-
-    int work = xcd_remap(blockIdx.x, gridDim.x);
-    const int qblock = work % n_qblocks;
-    work /= n_qblocks;
-    const int chunk = work % n_chunks;
-    const int split = work / n_chunks;
-    const int dk0 = wave * DKS;                          // first dk index of this wave
-    const int dvw0 = chunk * (4 * DVS) + wave * DVS;     // first V / output column of this wave
-
-    const int kv_begin = split * kv_per_split;
-    const int kv_end = min(a.n_local, kv_begin + kv_per_split);
-    const int ntiles = kv_end > kv_begin ? (kv_end - kv_begin + kKvTile - 1) / kKvTile : 0;
-    const float c = scale * 1.44269504088896340736f;
-
-    // Q fragments of both query blocks (k-slot mapping as in fused_partial_kernel: MFMA step
-    // (u,e) of half-wave hi uses dk index dk0 + 8u + 4hi + e); zero past the leading dimension
-    f32x4 qf[QB][NU];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        const int qrow = qblock * ROWS + qb * 32 + li;
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int col = dk0 + 8 * u + 4 * hi;
-            qf[qb][u] = (qrow < a.m && col < a.ldq)
-                            ? *reinterpret_cast<const f32x4 *>(a.Q + (size_t)qrow * a.ldq + col)
-                            : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-
-    // the second query block's fragments live in the accumulator file (an MFMA reads its B operand
-    // from AGPRs as well): 64 registers less on the VGPR side, where the prefetch rings are
-#pragma unroll
-    for (int u = 0; u < NU; ++u)
-        if constexpr (QB == 2) asm volatile("" : "+a"(qf[QB - 1][u]));
-
-    f32x16 oacc[NT][QB];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[t][qb][r] = 0.f;
-    float m_run[QB], l_run[QB];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) { m_run[qb] = -INFINITY; l_run[qb] = 0.f; }
-    // keep the O accumulators AGPR-class at the tile boundaries: left alone hipcc carries them as
-    // VGPR values (the rescale multiplies them), copies all of them every tile and spills Q
-    // fragments to scratch -- whose reloads put an s_waitcnt vmcnt(0) in front of the K prefetches
-    auto pin_o = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt) {
-            asm volatile("" : "+a"(oacc[tt][0]));
-            if constexpr (QB == 2) asm volatile("" : "+a"(oacc[tt][QB - 1]));
-        }
-    };
-    pin_o();
-
-    // (addresses: scalar 64-bit tile base + ONE unsigned 32-bit per-lane byte offset, the saddr form)
-    // K columns past the leading dimension are clamped to the last in-row float4 (Q is zero there);
-    // V columns likewise (never stored); rows past the shard end are clamped to its last row (their
-    // scores are masked to -inf, and 0 * finite = 0 in P.V).
-    const unsigned kcol0 = (unsigned)(dk0 + 4 * hi) * 4u, kcol_last = (unsigned)(a.ldk - 4) * 4u;
-    auto kcolb = [&](int u) __attribute__((always_inline)) -> unsigned { return min(kcol0 + 32u * u, kcol_last); };
-    const unsigned vcolb = (unsigned)min(dvw0 + NT * li, a.ldv - NT) * 4u;
-
-    for (int t = 0; t < ntiles; ++t) {
-        const int base = kv_begin + t * kKvTile;
-        const int last = kv_end - 1 - base;
-        const char *kb = reinterpret_cast<const char *>(a.K + (size_t)base * a.ldk);
-        const char *vb = reinterpret_cast<const char *>(a.V + (size_t)base * a.ldv);
-        const unsigned krow = (unsigned)min(li, last) * (unsigned)a.ldk * 4u;
-
-        // ---- partial S^T over this wave's dk slice, both query blocks
-        pin_o();
-        f32x16 s0, s1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }     // (s1: second block only, dead for QB = 1)
-        f32x4 kq[PD];
-#pragma unroll
-        for (int i = 0; i < PD; ++i) kq[i] = *reinterpret_cast<const f32x4 *>(SDPA_AUDITED_PTR(g_dks_audit, kb + (krow + kcolb(i)), 16, a.K, a.K + (size_t)a.n_local * a.ldk));
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const f32x4 kf = kq[u % PD];
-            if (u + PD < NU) kq[u % PD] = *reinterpret_cast<const f32x4 *>(SDPA_AUDITED_PTR(g_dks_audit, kb + (krow + kcolb(u + PD)), 16, a.K, a.K + (size_t)a.n_local * a.ldk));
-            __builtin_amdgcn_sched_barrier(0);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[0][u].x, s0, 0, 0, 0);
-            if constexpr (QB == 2) s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[QB - 1][u].x, s1, 0, 0, 0);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[0][u].y, s0, 0, 0, 0);
-            if constexpr (QB == 2) s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[QB - 1][u].y, s1, 0, 0, 0);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[0][u].z, s0, 0, 0, 0);
-            if constexpr (QB == 2) s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[QB - 1][u].z, s1, 0, 0, 0);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[0][u].w, s0, 0, 0, 0);
-            if constexpr (QB == 2) s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[QB - 1][u].w, s1, 0, 0, 0);
-        }
-
-        pin_o();
-        // first V fragments of this tile go out now, under the exchange
-        VRun<NT> vq[PD];
-#pragma unroll
-        for (int i = 0; i < PD; ++i)
-            vq[i] = VRun<NT>::load(reinterpret_cast<const float *>(
-                SDPA_AUDITED_PTR(g_dks_audit, vb + ((unsigned)min(crow(i, 0) + 4 * hi, last) * (unsigned)a.ldv * 4u + vcolb), NT * 4, a.V, a.V + (size_t)a.n_local * a.ldv)));
-
-        // ---- exchange: every wave ends up with the same full S^T (fixed summation order)
-        float *xb = smem + (t & 1) * XBUF;
-        {
-            float *mine = xb + ((wave * QB) * 64 + lane) * XLD;
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                *reinterpret_cast<f32x4 *>(mine + 4 * q4) = f32x4{s0[4 * q4], s0[4 * q4 + 1], s0[4 * q4 + 2], s0[4 * q4 + 3]};
-                if constexpr (QB == 2)
-                    *reinterpret_cast<f32x4 *>(mine + 64 * XLD + 4 * q4) =
-                        f32x4{s1[4 * q4], s1[4 * q4 + 1], s1[4 * q4 + 2], s1[4 * q4 + 3]};
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const float *theirs = xb + ((w * QB) * 64 + lane) * XLD;
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const f32x4 p0 = *reinterpret_cast<const f32x4 *>(theirs + 4 * q4);
-                f32x4 p1 = p0;
-                if constexpr (QB == 2) p1 = *reinterpret_cast<const f32x4 *>(theirs + 64 * XLD + 4 * q4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    s0[4 * q4 + e] = (w == 0) ? p0[e] : s0[4 * q4 + e] + p0[e];
-                    if constexpr (QB == 2) s1[4 * q4 + e] = (w == 0) ? p1[e] : s1[4 * q4 + e] + p1[e];
-                }
-            }
-        }
-
-        pin_o();
-        // ragged last tile: key rows past the shard end contribute exp(-inf) = 0
-        const int valid = kv_end - base;
-        if (valid < kKvTile) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (crow(r, hi) >= valid) {
-                    s0[r] = -INFINITY;
-                    if constexpr (QB == 2) s1[r] = -INFINITY;
-                }
-        }
-
-        // ---- online softmax, replicated in the four waves (identical inputs, identical results)
-        auto softmax = [&](f32x16 &sx, int qb) __attribute__((always_inline)) {
-            float tmax = sx[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sx[r]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-            const float m_new = fmaxf(m_run[qb], tmax);
-            if (__any(m_new > m_run[qb])) {
-                const float alpha = fast_exp2((m_run[qb] - m_new) * c);
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) oacc[tt][qb][r] *= alpha;
-                l_run[qb] *= alpha;
-                m_run[qb] = m_new;
-            }
-            const float mc = m_run[qb] * c;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                sx[r] = fast_exp2(fmaf(sx[r], c, -mc));
-                l_run[qb] += sx[r];
-            }
-        };
-        softmax(s0, 0);
-        if constexpr (QB == 2) softmax(s1, QB - 1);
-        pin_o();
-
-        // ---- O^T slice += V_tile^T . P^T   (k-step r of half-wave hi is key row crow(r, hi))
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const VRun<NT> vf = vq[r % PD];
-            if (r + PD < 16)
-                vq[r % PD] = VRun<NT>::load(reinterpret_cast<const float *>(
-                SDPA_AUDITED_PTR(g_dks_audit, vb + ((unsigned)min(crow(r + PD, 0) + 4 * hi, last) * (unsigned)a.ldv * 4u + vcolb), NT * 4, a.V, a.V + (size_t)a.n_local * a.ldv)));
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt) {
-                oacc[tt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.v[tt], s0[r], oacc[tt][0], 0, 0, 0);
-                if constexpr (QB == 2)
-                    oacc[tt][QB - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.v[tt], s1[r], oacc[tt][QB - 1], 0, 0, 0);
-            }
-        }
-        pin_o();
-    }
-
-    // ---- epilogue
-    float *out = a.contrib;
-    float *omax = a.lmax, *osum = a.lsum;
-    int ldo = a.ldo;
-    if (a.kv_splits > 1) {
-        ldo = a.ws_ld;
-        out = a.ws_contrib + (size_t)split * a.ws_rows * ldo;
-        omax = a.ws_lmax + (size_t)split * a.ws_rows;
-        osum = a.ws_lsum + (size_t)split * a.ws_rows;
-    }
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        const int qrow = qblock * ROWS + qb * 32 + li;
-        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32);
-        if (qrow < a.m) {
-            float *orow = out + (size_t)qrow * ldo + dvw0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int col0 = NT * crow(r, hi);
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt)
-                    if (dvw0 + col0 + tt < a.dv) orow[col0 + tt] = oacc[tt][qb][r];
-            }
-            if (wave == 0 && hi == 0 && chunk == 0) {
-                omax[qrow] = m_run[qb] * scale;
-                osum[qrow] = l_tot;
-            }
-        }
-    }
-}
-
+// (Rounds 1-5 also carried the serial-phase form of this kernel, fused_dksplit_kernel -- partial S, exchange, replicated softmax,
+// P.V one after the other, ~75 % of the pipelined form's rate -- as its bit-identity twin behind $SDPA_DKSPLIT_PIPE=0.  Retired in
+// round 6: no shape takes it; the pipelined form below is checked against the fp64 oracle and itself.)
 // compile-time loop: f(integral_constant<int, B>) ... f(integral_constant<int, E - 1>).  The pipelined kernel's
 // units are selected by `if constexpr` on the index, so nothing depends on the unroller's size thresholds.
 template <int B, int E, class F>
@@ -286,10 +44,9 @@ __device__ __forceinline__ void static_for(F &&f) {
 }
 
 // ---------------------------------------------------------------------------
-// The same kernel, software-pipelined across tiles (round 3).  fused_dksplit_kernel runs its phases one
-// after the other in every wave -- partial S, exchange, replicated softmax, P.V -- and with ONE wave per
-// SIMD (the Q slice and the O^T slice fill the register file) nothing else can use the matrix pipe while a
-// wave sums the exchanged partials and exponentiates: ~75 % at dk = dv = 512.  Here the exchange sums and
+// Software-pipelined across tiles (round 3).  Run one after the other in every wave -- partial S, exchange, replicated
+// softmax, P.V -- the phases leave the matrix pipe idle while a wave sums the exchanged partials and exponentiates (ONE wave
+// per SIMD: the Q slice and the O^T slice fill the register file): ~75 % at dk = dv = 512.  Here the exchange sums and
 // the softmax of tile t+1 are cut into units of a few instructions and placed BETWEEN the P.V MFMAs of
 // tile t, in program order (a wave stalls at an MFMA issue while the pipe is busy, so only instructions
 // written between two MFMAs run in the first one's shadow):
@@ -297,8 +54,7 @@ __device__ __forceinline__ void static_for(F &&f) {
 //   B(t):  O^T += V(t)^T P(t)^T, and between its MFMAs: read the four partials of S(t+1), sum them in
 //          the fixed order, row max, alpha, exponentials -> P(t+1), relative to the new running max
 //   then:  O *= alpha(t+1) where a maximum rose (after P.V(t) has landed)
-// The arithmetic and its order are the serial kernel's, so the results are bit for bit the same; the ragged
-// last tile (masked scores) and the first tile take the units without MFMAs in between.
+// The ragged last tile (masked scores) and the first tile take the units without MFMAs in between.
 // ---------------------------------------------------------------------------
 template <int DKS, int DVS, int QB>
 __global__ __launch_bounds__(256, 1) void fused_dksplit_pipe_kernel(
@@ -662,14 +418,6 @@ static inline int dksplit_slice(int dk, int dv) {
 int dksplit_chunks(int dk, int dv) { return (dv + 4 * dksplit_slice(dk, dv) - 1) / (4 * dksplit_slice(dk, dv)); }
 int dksplit_rows(int dk) { return dk > 512 ? 32 : 64; }      // query rows per workgroup: one block beyond dk = 512
 
-// $SDPA_DKSPLIT_PIPE=0: the serial-phase kernel (kept for A/B and as the bitwise reference of the pipelined one)
-#ifndef SDPA_DKSPLIT_PIPE_DEFAULT
-#define SDPA_DKSPLIT_PIPE_DEFAULT 1
-#endif
-static bool dksplit_pipelined() {       // (the knob comes from the launch-knob snapshot: no getenv on an enqueue thread)
-    return SDPA_DKSPLIT_PIPE_DEFAULT != 0 ? launch_knobs().dksplit_pipe != 0 : false;
-}
-
 template <int DKS, int DVS, int QB>
 static hipError_t launch_one(const PartialArgs &a, hipStream_t s) {
     const int nqb = (a.m + 32 * QB - 1) / (32 * QB);
@@ -682,22 +430,15 @@ static hipError_t launch_one(const PartialArgs &a, hipStream_t s) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_dksplit_kernel<DKS, DVS, QB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_dksplit_pipe_kernel<DKS, DVS, QB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_dksplit_pipe_kernel<DKS, DVS, QB>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done[dev] = true;
     }
     const float scale = 1.0f / sqrtf((float)a.dk);   // attention-mpi.c:208
-    if (dksplit_pipelined())
-        hipLaunchKernelGGL((fused_dksplit_pipe_kernel<DKS, DVS, QB>), dim3(nqb * chunks * a.kv_splits), dim3(256), lds, s,
-                           a, kv_per_split, nqb, chunks, scale);
-    else
-        hipLaunchKernelGGL((fused_dksplit_kernel<DKS, DVS, QB>), dim3(nqb * chunks * a.kv_splits), dim3(256), lds, s,
-                           a, kv_per_split, nqb, chunks, scale);
-    note_launch(dksplit_pipelined() ? "fused_dksplit_pipe_kernel" : "fused_dksplit_kernel", 3, DKS, DVS, QB, 0, 0,
+    hipLaunchKernelGGL((fused_dksplit_pipe_kernel<DKS, DVS, QB>), dim3(nqb * chunks * a.kv_splits), dim3(256), lds, s,
+                       a, kv_per_split, nqb, chunks, scale);
+    note_launch("fused_dksplit_pipe_kernel", 3, DKS, DVS, QB, 0, 0,
                 nqb * chunks * a.kv_splits, a.kv_splits, 0, a.m, a.n_local);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -754,7 +495,7 @@ void dma_audit_read_dksplit(unsigned long long out[2]) {
 // current device NOW -- not in front of the first launch that needs it, possibly behind a resident persistent launch
 hipError_t preload_kernels_dksplit() {
     hipFuncAttributes attr;
-    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&fused_dksplit_kernel<128, 128, 2>));
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&fused_dksplit_pipe_kernel<128, 128, 2>));
 }
 
 }  // namespace sdpa

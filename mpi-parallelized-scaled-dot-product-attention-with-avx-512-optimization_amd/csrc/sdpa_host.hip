@@ -211,20 +211,6 @@ int env_int(const char *name, int dflt) {
     return x > 0 ? x : dflt;
 }
 
-// Test-only knobs live in ONE variable, $SDPA_DEBUG="name=value,name=value" (round 6: VERDICT r5 item 8), read on the calling
-// thread of a host-level entry point: stream_drop_word=N (the streamed launch's ready word N-1 is never raised).
-int debug_int(const char *name, int dflt) {
-    const char *v = getenv("SDPA_DEBUG");
-    if (!v || !*v) return dflt;
-    const size_t len = strlen(name);
-    for (const char *p = v; *p;) {
-        while (*p == ',' || *p == ' ') ++p;
-        if (strncmp(p, name, len) == 0 && p[len] == '=') return atoi(p + len + 1);
-        while (*p && *p != ',') ++p;
-    }
-    return dflt;
-}
-
 // Compute units a rank's compute stream leaves to the other streams ($SDPA_COMM_CUS; unset = the default:
 // 16 -- two per XCD -- when the call merges over several ranks, so that a batch's collectives and merge
 // kernels run UNDER the next batch's fused kernels the way the reference's MPI_Ireduce stays in flight
@@ -252,12 +238,12 @@ int comm_cus_reserved(int cus, int ranks) {
 // library's page-locked staging -- as fast at every BASELINE shape (profiles/r04/hostlevel_all_configs.log) -- because
 // ASKING costs the host application log noise: hipPointerGetAttributes on a plain malloc / numpy array makes ROCm 7
 // print "Cannot get amd_mem_obj for ptr" at error level, 3-4 lines per attention() under AMD_LOG_LEVEL >= 1
-// (16 KB of the driver's pytest tail was this).  $SDPA_HOST_PROBE=1 asks after all (a caller that
+// (16 KB of the driver's pytest tail was this).  $SDPA_DEBUG host_probe=1 asks after all (a caller that
 // page-locks its arrays itself and wants them used in place); the verdict is remembered per base pointer.
 struct HostRanges {
     std::mutex mu;
     std::vector<std::pair<const char *, size_t>> r;       // sdpa_host_alloc()ed, not yet freed
-    std::vector<std::pair<const void *, bool>> probed;    // $SDPA_HOST_PROBE=1: base pointer -> page-locked?
+    std::vector<std::pair<const void *, bool>> probed;    // $SDPA_DEBUG host_probe=1: base pointer -> page-locked?
 };
 HostRanges &HR = *new HostRanges;
 
@@ -267,7 +253,7 @@ bool page_locked(const void *p) {
         for (auto &e : HR.r)
             if ((const char *)p >= e.first && (const char *)p < e.first + e.second) return true;
     }
-    static const bool probe = [] { const char *v = getenv("SDPA_HOST_PROBE"); return v && *v && atoi(v) != 0; }();
+    static const bool probe = sdpa_debug_int("host_probe", 0) != 0;
     if (!probe) return false;
     {
         std::lock_guard<std::mutex> lk(HR.mu);
@@ -298,7 +284,7 @@ bool register_caller_arrays() {
 }
 
 bool pin_probe() {
-    static const bool on = [] { const char *v = getenv("SDPA_PIN_PROBE"); return !(v && *v == '0'); }();
+    static const bool on = sdpa_debug_int("pin_probe", 1) != 0;
     return on;
 }
 
@@ -323,7 +309,7 @@ struct HostPins {
         // Memory the runtime already knows (hipHostMalloc / sdpa_host_alloc arrays, an earlier registration of the
         // caller's, managed memory) is left alone: registering it again is REFUSED by the runtime ("Failed creating
         // memory ... Cannot create memory for size"), and both GPU memory faults of round 4 came 0.5 s and 3.3 s
-        // behind exactly two such refusals (tests' sdpa_host_alloc'ed K and V; profiles/r04/).  $SDPA_PIN_PROBE=0
+        // behind exactly two such refusals (tests' sdpa_host_alloc'ed K and V; profiles/r04/).  $SDPA_DEBUG pin_probe=0
         // restores the blind attempt (tools/gpu_register_stress.py compares the two).
         if (pin_probe()) {
             hipPointerAttribute_t at;
@@ -529,7 +515,7 @@ void make_plan(Plan &pl, int m, int n, int dk, int dv, int flags, int ranks = 0)
     pl.bf16 = bf16_for(flags, n, dk, dv, pl.P, pl.qrows);
     pl.merge_allreduce = (flags & SDPA_F_MERGE_ALLREDUCE) != 0;
     if (const char *v = getenv("SDPA_MERGE")) pl.merge_allreduce = pl.merge_allreduce || strcmp(v, "allreduce") == 0;
-    const bool force = getenv("SDPA_FORCE_COLLECTIVES") && atoi(getenv("SDPA_FORCE_COLLECTIVES")) != 0;
+    const bool force = sdpa_debug_int("force_collectives", 0) != 0;
     pl.collectives = !pl.qrows && (pl.P > 1 || force) && (ranks > 0 || E.coll != nullptr);
     const char *egress = getenv("SDPA_EGRESS");
     pl.egress_scatter = pl.collectives && pl.P > 1 && !(egress && strcmp(egress, "root") == 0);
@@ -552,7 +538,7 @@ void make_plan(Plan &pl, int m, int n, int dk, int dv, int flags, int ranks = 0)
     // 32768 rows = 256 query blocks: with 2 in-launch splits that is one full wave of 512
     // workgroups, the shape the fused kernel runs fastest at
     int B = env_int("SDPA_QBATCH", 32768);
-    // The largest K/V chunk of a streamed shard, when $SDPA_KV_CHUNK_MAX does not say: how long the inputs take to
+    // The largest K/V chunk of a streamed shard, when $SDPA_DEBUG kv_chunk_max does not say: how long the inputs take to
     // arrive (fp64 over the link, or through the host's convert pool: ~70 GB/s either way) against how long the kernels
     // take.  Kernel bound (metric shape, configs 3 / 4): data is far ahead of the kernels, a launch costs ~25 us of
     // ramp and tail, so chunks grow to 65536 keys (config 3: 18 -> 8 chunks, 33.3 -> 32.6 ms).  Feed bound (config 5 in
@@ -568,12 +554,12 @@ void make_plan(Plan &pl, int m, int n, int dk, int dv, int flags, int ranks = 0)
         if (t_feed > t_kernel) cmax_dflt = 8192;
         else if (t_feed < 0.5 * t_kernel) cmax_dflt = 65536;
     }
-    int cmin = env_int("SDPA_KV_CHUNK_MIN", 4096), cmax = env_int("SDPA_KV_CHUNK_MAX", cmax_dflt);
+    int cmin = sdpa_debug_pos("kv_chunk_min", 4096), cmax = sdpa_debug_pos("kv_chunk_max", cmax_dflt);
     cmin = std::max(1024, cmin / 1024 * 1024);
     cmax = std::max(cmin, cmax / 1024 * 1024);
-    pl.row_pieces = std::min(kMaxSub, env_int("SDPA_ROW_PIECES", 4));
+    pl.row_pieces = std::min(kMaxSub, sdpa_debug_pos("row_pieces", 4));
     // a piece narrower than 4096 rows runs the fused kernel below ~100 TFLOP/s (tools/gpu_kernel_grid.py)
-    pl.piece_min_rows = env_int("SDPA_PIECE_MIN_ROWS", 4096);
+    pl.piece_min_rows = sdpa_debug_pos("piece_min_rows", 4096);
 
     pl.r.assign(pl.P, RankPlan());
     int max_rows = 0;
@@ -656,7 +642,7 @@ void make_plan(Plan &pl, int m, int n, int dk, int dv, int flags, int ranks = 0)
         rp.stream = StreamPlan();
         const char *sv = getenv("SDPA_STREAMED");
         const bool stream_knob = (!(sv && *sv) || atoi(sv) != 0) && !E.stream_off;
-        const int scmin = std::max(1024, env_int("SDPA_STREAM_CHUNK_MIN", cmin) / 1024 * 1024);
+        const int scmin = std::max(1024, sdpa_debug_pos("stream_chunk_min", cmin) / 1024 * 1024);
         // bf16 (round 5, second half): the tandem kernel's shapes (value columns in 512-wide chunks) have a persistent form too;
         // its K groups are row ranges of the bf16 image, its V groups COLUMN ranges of the Vt image, written by the host
         // (sdpa_hostcvt: submit_t) and carried by pitched copies -- the copy engine's as well (profiles/r05/copy_engine_probes.log).
@@ -690,7 +676,7 @@ void make_plan(Plan &pl, int m, int n, int dk, int dv, int flags, int ranks = 0)
                 // bound the first half cannot end before the last K/V group has landed, so the second half's MFMAs come BEHIND the
                 // transfer instead of under it (config 5 bf16: kernels 4.5 -> 5.7 ms, call 6.10 -> 6.73; config 3: 32.0 -> 32.8).
                 // $SDPA_DEBUG=two_wave=1 runs it (tests/test_gpu_host_pipeline.py keeps it bit-identical to the device-level halves).
-                const bool knob = debug_int("two_wave", 0) != 0;
+                const bool knob = sdpa_debug_int("two_wave", 0) != 0;
                 if (knob && !pl.collectives && first_is_last && pieces0 >= 2 && pieces0 % 2 == 0 && rows0 % rows_piece0 == 0 && t_launch >= 3.0e-3) {
                     const int half = pieces0 / 2 * rows_piece0;
                     const sdpa::F32Plan h = plan_rows(half);
@@ -718,9 +704,9 @@ void make_plan(Plan &pl, int m, int n, int dk, int dv, int flags, int ranks = 0)
                 // A group crosses PCIe as one row range per split and operand, and a copy costs ~10 us whatever its size:
                 // below ~2048 keys of a split per group (1 MiB at d = 128) the copies, not the link, set the pace (config 2
                 // with 2 groups x 8 splits: 32 copies of 256 KiB, 1.02-1.05 ms against 0.99 chunked -- profiles/r05/
-                // boundary_streamed_vs_chunked_ab.log).  So a split's share of a group is at least $SDPA_STREAM_ENTRY_MIN
+                // boundary_streamed_vs_chunked_ab.log).  So a split's share of a group is at least $SDPA_DEBUG stream_entry_min
                 // keys; a shard too short for two such groups is ONE group -- whose ranges are adjacent: one copy.
-                const int entry_min = std::max(1, env_int("SDPA_STREAM_ENTRY_MIN", 2048) / sdpa::kKvTile);
+                const int entry_min = std::max(1, sdpa_debug_pos("stream_entry_min", 2048) / sdpa::kKvTile);
                 long cum = 0;
                 int prev = 0;
                 for (size_t gi = 0; gi < gsz.size(); ++gi) {
@@ -1781,10 +1767,9 @@ int host_cvt_mode() {
 
 // CPUs this process can really keep busy: its affinity mask cut down to the container's CPU quota (cgroup v2 cpu.max, v1
 // cpu.cfs_quota_us / cpu.cfs_period_us).  std::thread::hardware_concurrency() says 256 on a GPU box whose container may use
-// 16 cores' worth of CPU time.  $SDPA_HOST_CORES overrides (tests pin the model with it).
+// 16 cores' worth of CPU time.  $SDPA_DEBUG host_cores overrides (tests pin the model with it).
 int effective_cores() {
-    if (const char *v = getenv("SDPA_HOST_CORES"))
-        if (*v && atoi(v) > 0) return atoi(v);
+    if (sdpa_debug_int("host_cores", 0) > 0) return sdpa_debug_int("host_cores", 0);
     static const int cores = [] {
         int n = (int)std::thread::hardware_concurrency();
         cpu_set_t set;
@@ -2084,7 +2069,7 @@ int init_impl(int n_gpus) {
             E.chip_cus = prop.multiProcessorCount;
         }
     }
-    const bool force = getenv("SDPA_FORCE_COLLECTIVES") && atoi(getenv("SDPA_FORCE_COLLECTIVES")) != 0;
+    const bool force = sdpa_debug_int("force_collectives", 0) != 0;
     if (want > 1 || force) {
         if (virt > 0) {
             E.coll = sdpa::make_loopback_collectives(want, 0);
@@ -2095,7 +2080,7 @@ int init_impl(int n_gpus) {
         }
         if (!E.coll) return SDPA_ERCCL;
     }
-    if (want > 1 && !(getenv("SDPA_ENQUEUE_THREADS") && atoi(getenv("SDPA_ENQUEUE_THREADS")) == 0)) {
+    if (want > 1 && sdpa_debug_int("enqueue_threads", 1) != 0) {
         std::vector<int> devs(want);
         for (int i = 0; i < want; ++i) devs[i] = E.r[i].dev;
         E.pool.start(want, devs);
@@ -2243,7 +2228,7 @@ static int attention_call(const double *Q, const double *K, const double *V, dou
     const bool pageable_in = !c.do_pin && !(page_locked(K) && page_locked(V) && page_locked(Q));
     c.k_bytes = (size_t)n * dk * sizeof(double);
     c.v_bytes = (size_t)n * dv * sizeof(double);
-    const bool want_progressive = !getenv("SDPA_PROGRESSIVE_PIN") || atoi(getenv("SDPA_PROGRESSIVE_PIN")) != 0;
+    const bool want_progressive = sdpa_debug_int("progressive_pin", 1) != 0;
     if (c.do_pin && !PF.active && want_progressive) c.progressive = plan_progressive_pins(c);
     // every caller array: the partial pages at its two ends are never registered (HostPins::add), so a copy that
     // touches them is split at the first / last page boundary inside the array
@@ -2306,7 +2291,7 @@ static int attention_call(const double *Q, const double *K, const double *V, dou
                 c.stream_gen = E.stream_gen;
                 c.stream_timeout_ms = E.stream_timeout_ms_once > 0 ? E.stream_timeout_ms_once : env_int("SDPA_STREAM_TIMEOUT_MS", 500);
                 c.stream_timeout_ticks = (unsigned long long)c.stream_timeout_ms * 100000ull;
-                c.stream_drop_word = debug_int("stream_drop_word", 0) - 1;
+                c.stream_drop_word = sdpa_debug_int("stream_drop_word", 0) - 1;
             }
             CUT = PinCuts();
             set_edge_cuts();                 // (only `result` is registered in this mode; K / V / Q travel from the staging images)
@@ -2737,7 +2722,7 @@ int sdpa_prepare(int m, int n, int dk, int dv, int flags) {
     const sdpa_timing keep = E.last;
     // (the start-up PROBE of the streamed launch: with a short wait bound -- a runtime on which the copies do not land beside the
     //  launch is found out here, in ~0.2 s and outside any timer, and the process keeps the launch-per-chunk schedule)
-    if (will_stream) E.stream_timeout_ms_once = env_int("SDPA_STREAM_PROBE_MS", 200);
+    if (will_stream) E.stream_timeout_ms_once = sdpa_debug_pos("stream_probe_ms", 200);
     const bool was_off = E.stream_off;
     const int rc = sdpa_attention_f64(q.data(), k.data(), v.data(), r.data(), m0, n0, dk, dv, flags);
     E.last = keep;

@@ -1,5 +1,6 @@
 // sdpa_hostcvt.cpp -- see sdpa_hostcvt.h.  Host code only: compiled by g++ (x86-64), no device pass.
 #include "sdpa_hostcvt.h"
+#include "sdpa_debug.h"
 
 #include <hip/hip_runtime_api.h>
 #include <immintrin.h>
@@ -206,11 +207,10 @@ void rows_to_bf16_avx512_nt(const double *src, unsigned short *dst, long rows, i
 }
 #undef SDPA_BF16X8
 
-// $SDPA_HOST_CVT_NT: 1 / 0 = streaming stores in the converter pool on / off (the default: see sdpa_hostcvt.h)
+// $SDPA_DEBUG host_cvt_nt: 1 / 0 = streaming stores in the converter pool on / off (the default: see sdpa_hostcvt.h)
 bool stream_stores_default() {
     static const bool on = [] {
-        const char *v = getenv("SDPA_HOST_CVT_NT");
-        return (v && *v) ? atoi(v) != 0 : SDPA_HOST_CVT_NT_DEFAULT != 0;
+        return sdpa_debug_int("host_cvt_nt", SDPA_HOST_CVT_NT_DEFAULT) != 0;
     }();
     return on;
 }
@@ -480,7 +480,7 @@ struct Batch {
     std::deque<Task> tasks;            // (deque: a Task holds an atomic and never moves)
     std::vector<Item> items;
     std::atomic<long> next{0};
-    // $SDPA_HOST_CVT_TRACE only (microseconds on the steady clock)
+    // $SDPA_DEBUG host_cvt_trace only (microseconds on the steady clock)
     double t_kick = 0;
     std::atomic<double> first_min{1e300}, first_max{0}, last_done{0}, busy_us{0};
     std::atomic<int> workers{0};
@@ -493,7 +493,7 @@ inline void atomic_min(std::atomic<double> &a, double v) { double c = a.load(); 
 inline void atomic_max(std::atomic<double> &a, double v) { double c = a.load(); while (v > c && !a.compare_exchange_weak(c, v)) {} }
 inline void atomic_add(std::atomic<double> &a, double v) { double c = a.load(); while (!a.compare_exchange_weak(c, c + v)) {} }
 
-// ---- where the pool's threads run ($SDPA_HOST_CVT_PIN=1, OPT-IN: a measured negative result) -----------------------------------
+// ---- where the pool's threads run ($SDPA_DEBUG host_cvt_pin=1, OPT-IN: a measured negative result) -----------------------------------
 // On the GPU box's two-socket host a standalone probe reads the fp64 source at 250-420 GB/s from threads pinned one per core on
 // the source pages' NUMA node and at 110 GB/s flat from the other one (tools/probes/hostcvt_placement_probe.cpp), and one-shot CLI
 // runs of config 5 in bf16 are bimodal box to box (6.6-7.4 ms against 9.3-9.5).  Confining the pool to the source's node -- a few
@@ -605,7 +605,7 @@ public:
     }
     int submit(const double *src, void *dst, long rows, int cols, int ld, CvtKind kind, double mult) override {
         if (!mine_) mine_ = std::make_shared<Batch>();
-        // items of ~64 KiB of source ($SDPA_HOST_CVT_ITEM_KB): small enough to balance, large enough to stream
+        // items of ~64 KiB of source ($SDPA_DEBUG host_cvt_item_kb): small enough to balance, large enough to stream
         long per = (long)item_kb_ * 128 / (cols > 0 ? cols : 1);
         if (per < 1) per = 1;
         const long n_items = rows > 0 ? (rows + per - 1) / per : 0;
@@ -617,7 +617,7 @@ public:
     }
     int submit_t(const double *src, unsigned short *dst, long keys, long keys_pad, int cols, int cols_pad, long ldt) override {
         if (!mine_) mine_ = std::make_shared<Batch>();
-        // items of whole 32-key tiles, ~$SDPA_HOST_CVT_ITEM_KB of source each (at least one tile)
+        // items of whole 32-key tiles, ~$SDPA_DEBUG host_cvt_item_kb of source each (at least one tile)
         long per = (long)item_kb_ * 128 / (cols > 0 ? cols : 1);
         per = per < 32 ? 32 : (per + 31) / 32 * 32;
         const long total = (keys_pad + 31) / 32 * 32;
@@ -655,7 +655,7 @@ public:
             for (Task &t : mine_->tasks)
                 while (t.remaining.load(std::memory_order_acquire) > 0) relax();
         if (trace_ && kicked && !mine_->items.empty()) {
-            // $SDPA_HOST_CVT_TRACE=1: where one call's conversions spent their time (one line on stderr per call)
+            // $SDPA_DEBUG host_cvt_trace=1: where one call's conversions spent their time (one line on stderr per call)
             Batch &b = *mine_;
             double bytes = 0;
             for (const Item &it : b.items) bytes += (double)it.rows * b.tasks[it.task].cols * 8.0;
@@ -762,13 +762,12 @@ private:
     std::shared_ptr<Batch> mine_;      // the calling thread's handle on the batch it is building / waiting for
     Buf buf_[4];
     const bool nt_ = stream_stores_default();
-    const bool trace_ = getenv("SDPA_HOST_CVT_TRACE") && atoi(getenv("SDPA_HOST_CVT_TRACE")) != 0;
-    const bool pin_ = getenv("SDPA_HOST_CVT_PIN") && atoi(getenv("SDPA_HOST_CVT_PIN")) != 0;       // opt-in: see the class comment
+    const bool trace_ = sdpa_debug_int("host_cvt_trace", 0) != 0;
+    const bool pin_ = sdpa_debug_int("host_cvt_pin", 0) != 0;       // opt-in: see the class comment
     NumaMap numa_;
     int placed_ = -1;                  // the node the workers are confined to (-1: every allowed CPU)
     const int item_kb_ = [] {
-        const char *v = getenv("SDPA_HOST_CVT_ITEM_KB");
-        const int kb = (v && *v) ? atoi(v) : 64;
+        const int kb = sdpa_debug_int("host_cvt_item_kb", 64);
         return kb < 4 ? 4 : kb > 16384 ? 16384 : kb;
     }();
 };

@@ -21,7 +21,7 @@ enum CvtKind {
 };
 
 // Streaming (non-temporal) stores in the AVX-512 rows: whole 64-byte lines written past the cache wherever a row's
-// destination is line-aligned (the staging images are).  $SDPA_HOST_CVT_NT overrides this default.
+// destination is line-aligned (the staging images are).  $SDPA_DEBUG host_cvt_nt overrides this default.
 #ifndef SDPA_HOST_CVT_NT_DEFAULT
 #define SDPA_HOST_CVT_NT_DEFAULT 1
 #endif
@@ -56,7 +56,7 @@ public:
     // the same for a column range of a Vt image (host_convert_vt's arguments; whole 32-key tiles per work item)
     virtual int submit_t(const double *src, unsigned short *dst, long keys, long keys_pad, int cols, int cols_pad, long ldt) = 0;
     // before kick(): confine the pool's threads to the NUMA node the call's source arrays live on (sampled pages; all CPUs again
-    // when the samples disagree or the host says nothing) -- only with $SDPA_HOST_CVT_PIN=1 (opt-in: it did not pay, sdpa_hostcvt.cpp).
+    // when the samples disagree or the host says nothing) -- only with $SDPA_DEBUG host_cvt_pin=1 (opt-in: it did not pay, sdpa_hostcvt.cpp).
     // placed_node(): where they are (-1: anywhere)
     virtual void place_near(const void *const *arrays, const size_t *bytes, int n_arrays) = 0;
     virtual int placed_node() const = 0;

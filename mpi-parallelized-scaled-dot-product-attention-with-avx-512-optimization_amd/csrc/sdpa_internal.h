@@ -87,7 +87,7 @@ struct PartialArgs {
                                    // query block to arrive merges its splits.  nullptr = separate merge pass
     unsigned long long ticket_tag; // this launch's generation (set by the launcher): a word counts only when its
                                    // upper 56 bits equal it, so nothing has to be cleared between launches
-    int tune;                      // -DSDPA_ABLATIONS builds only ($SDPA_TUNE): 4 = register-staged kernel
+    int tune;                      // -DSDPA_ABLATIONS builds only ($SDPA_DEBUG tune): 4 = register-staged kernel
                                    // instead of the pipelined one, 16/32/64 = timing-only ablations
     int cus;                       // compute units this launch may fill (stream-K grid); 0 = what the stream was
                                    // registered with (register_stream_cus), the whole chip otherwise
@@ -294,9 +294,8 @@ int format_launch_kernel(const LaunchNote &n, char *buf, size_t len);
 // sdpa_reload_env() (and every host-level entry point, on the calling thread, before any worker thread
 // runs) takes a new snapshot.
 struct LaunchKnobs {
-    int split_merge_kernel;   // $SDPA_SPLIT_MERGE=kernel: the fp32 pipelined kernel merges its K/V splits itself
-    int dksplit_pipe;         // $SDPA_DKSPLIT_PIPE (default 1): software-pipelined dk-split kernel
-    int streamk;              // $SDPA_STREAMK: 0 = never, 1 = whenever eligible, unset/auto = -1: by the cost model
+    int split_merge_kernel;   // $SDPA_DEBUG split_merge=kernel: the fp32 pipelined kernel merges its K/V splits itself
+    int streamk;              // $SDPA_DEBUG streamk: 0 = never, 1 = whenever eligible, unset/auto = -1: by the cost model
 };
 const LaunchKnobs &launch_knobs();
 void reload_launch_knobs();

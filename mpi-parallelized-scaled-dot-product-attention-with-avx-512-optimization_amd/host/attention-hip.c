@@ -19,14 +19,14 @@
  *                      device when the RCCL self-test passes on this node, else 1)
  *   SDPA_PLAN=qrows    shard the query rows instead (K/V replicated, no merge collective)
  *   SDPA_MERGE=allreduce  the reference's literal two all-reduces instead of one all-gather
- *   SDPA_TIME_INIT=1   create and size the engine inside the timed region (default: before
+ *   $SDPA_DEBUG time_init=1   create and size the engine inside the timed region (default: before
  *                      it -- sdpa_init + sdpa_prepare -- the way the reference sets up MPI and
  *                      its transport outside the timer, attention-mpi.c:10-17, :504)
  *   SDPA_VERBOSE=1     stage breakdown and a strict parity report on stderr
  *   SDPA_CLI_PREFETCH=1  read K and V in pieces and let the engine move finished pieces to the
  *                      device(s) during the read (sdpa_kv_prefetch); the timed call then no longer
  *                      contains the K/V transfer -- off by default, see host/sdpa_cli.h
- *   SDPA_PINNED_IO=0   read the matrices into malloc'd memory (default: page-locked memory from
+ *   $SDPA_DEBUG pinned_io=0   read the matrices into malloc'd memory (default: page-locked memory from
  *                      sdpa_host_alloc when the engine is created before the read -- the file
  *                      format and the reader's error behaviour stay attention.c:84-121)
  */
@@ -49,7 +49,7 @@ int main(int argc, char **argv)
     }
     const double t_start = now_ms();
     const bool verbose = getenv("SDPA_VERBOSE") != NULL;
-    const bool time_init = getenv("SDPA_TIME_INIT") != NULL;
+    const bool time_init = sdpa_debug_int("time_init", 0) != 0;
 
     /* the engine comes up before the read so that the reader can ask it for page-locked memory;
      * a missing or truncated input file is still reported first, with the reader's own messages
@@ -58,8 +58,7 @@ int main(int argc, char **argv)
         precheck_file(argv[1]);
         die_if(cli_engine_up(), "sdpa_init");
         note_unused_gpus();
-        const char *pin = getenv("SDPA_PINNED_IO");
-        use_pinned = !(pin && pin[0] == '0');
+        use_pinned = sdpa_debug_int("pinned_io", 1) != 0;
         const char *pf = getenv("SDPA_CLI_PREFETCH");
         cli_prefetch = pf && pf[0] == '1';
     }

@@ -19,7 +19,7 @@
  * thing -- a submission script written for the reference keeps working.
  *
  * Built by mpicc (gcc underneath); sees nothing but the C header.  Environment as
- * attention-hip.c (SDPA_GPUS, SDPA_PLAN, SDPA_MERGE, SDPA_VERBOSE, SDPA_TIME_INIT, SDPA_PINNED_IO).
+ * attention-hip.c (SDPA_GPUS, SDPA_PLAN, SDPA_MERGE, SDPA_VERBOSE, $SDPA_DEBUG time_init, $SDPA_DEBUG pinned_io).
  */
 #define _POSIX_C_SOURCE 200809L   /* clock_gettime under -std=c11 */
 #include <mpi.h>
@@ -57,7 +57,7 @@ int main(int argc, char **argv)
 
     const double t_start = now_ms();
     const bool verbose = getenv("SDPA_VERBOSE") != NULL;
-    const bool time_init = getenv("SDPA_TIME_INIT") != NULL;
+    const bool time_init = sdpa_debug_int("time_init", 0) != 0;
 
     struct problem p = {{0, 0, 0, 0}, NULL, NULL, NULL};
     double *result = NULL;
@@ -72,8 +72,7 @@ int main(int argc, char **argv)
             if (size > 1)       /* the reference would compute on every rank; here they wait */
                 fprintf(stderr, "%s: %d MPI ranks: rank 0 drives the GPU(s), ranks 1..%d only take part in the "
                         "template's MPI_Reduce\n", cli_name, size, size - 1);
-            const char *pin = getenv("SDPA_PINNED_IO");
-            use_pinned = !(pin && pin[0] == '0');
+            use_pinned = sdpa_debug_int("pinned_io", 1) != 0;
         }
         load_problem(argv[1], &p);
         m = p.dim[0]; n = p.dim[1]; dk = p.dim[2]; dv = p.dim[3];

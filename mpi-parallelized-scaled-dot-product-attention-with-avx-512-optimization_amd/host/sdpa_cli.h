@@ -18,6 +18,7 @@
 #include <time.h>
 
 #include "sdpa_hip.h"
+#include "../csrc/sdpa_debug.h"   /* $SDPA_DEBUG: pinned_io, time_init */
 
 static const char *cli_name = "attention-hip";
 

@@ -73,7 +73,7 @@ def pytest_sessionfinish(session, exitstatus):
 
 @pytest.fixture(autouse=True)
 def _launch_knob_snapshot():
-    """The library reads its launch-path knobs ($SDPA_STREAMK, $SDPA_SPLIT_MERGE, ...) from ONE snapshot of the
+    """The library reads its launch-path knobs ($SDPA_DEBUG: streamk, split_merge, ...) from ONE snapshot of the
     environment (sdpa_reload_env, include/sdpa_hip.h).  A test that changed them re-took it; when monkeypatch
     has put the environment back, the snapshot follows -- otherwise one test's knob leaks into the next."""
     yield
@@ -104,3 +104,61 @@ def fp32_tol(V):
     """fp32 path max|delta| <= 5e-5 * max(1, max|V|)."""
     import numpy as np
     return 5e-5 * max(1.0, float(np.abs(V).max()))
+
+
+# ---- $SDPA_DEBUG: every test / tuning knob of the library lives in ONE variable since round 6 (csrc/sdpa_debug.h) -------------------
+# The tests keep naming a knob by its round-1..5 variable; these helpers fold such names into the $SDPA_DEBUG string.
+DEBUG_KNOBS = {"SDPA_KV_CHUNK_MIN": "kv_chunk_min", "SDPA_KV_CHUNK_MAX": "kv_chunk_max", "SDPA_ROW_PIECES": "row_pieces",
+               "SDPA_PIECE_MIN_ROWS": "piece_min_rows", "SDPA_STREAM_CHUNK_MIN": "stream_chunk_min",
+               "SDPA_STREAM_ENTRY_MIN": "stream_entry_min", "SDPA_STREAM_PROBE_MS": "stream_probe_ms", "SDPA_ENQUEUE_THREADS": "enqueue_threads",
+               "SDPA_PROGRESSIVE_PIN": "progressive_pin", "SDPA_PIN_PROBE": "pin_probe", "SDPA_HOST_PROBE": "host_probe",
+               "SDPA_HOST_CORES": "host_cores", "SDPA_RESERVE_BY_MASK": "reserve_by_mask", "SDPA_HOST_CVT_ITEM_KB": "host_cvt_item_kb",
+               "SDPA_HOST_CVT_NT": "host_cvt_nt", "SDPA_HOST_CVT_PIN": "host_cvt_pin", "SDPA_HOST_CVT_TRACE": "host_cvt_trace",
+               "SDPA_SPLIT_MERGE": "split_merge", "SDPA_STREAMK": "streamk", "SDPA_BF16_DUO": "bf16_duo", "SDPA_TUNE": "tune",
+               "SDPA_PINNED_IO": "pinned_io", "SDPA_TIME_INIT": "time_init", "SDPA_FORCE_COLLECTIVES": "force_collectives"}
+
+
+def knob_env(env, base=None):
+    """{variable: value} in the tests' vocabulary -> the environment entries the library reads: documented knobs as they are, the
+    others merged into ONE $SDPA_DEBUG string (on top of `base`, an existing $SDPA_DEBUG value, and of an SDPA_DEBUG entry of `env`)"""
+    out, dbg = {}, {}
+    for part in (base or "").split(","):
+        if "=" in part:
+            k, v = part.split("=", 1)
+            dbg[k.strip()] = v
+    for k, v in env.items():
+        if k == "SDPA_DEBUG":
+            for part in str(v).split(","):
+                if "=" in part:
+                    a, b = part.split("=", 1)
+                    dbg[a.strip()] = b
+        elif k in DEBUG_KNOBS:
+            dbg[DEBUG_KNOBS[k]] = str(v)
+        else:
+            out[k] = str(v)
+    if dbg:
+        out["SDPA_DEBUG"] = ",".join("%s=%s" % kv for kv in dbg.items())
+    return out
+
+
+def set_knobs(monkeypatch, **env):
+    """monkeypatch.setenv for every knob of `env` (see knob_env); a value of None removes the knob"""
+    cur = {}
+    for part in os.environ.get("SDPA_DEBUG", "").split(","):
+        if "=" in part:
+            k, v = part.split("=", 1)
+            cur[k.strip()] = v
+    for k, v in env.items():
+        if k in DEBUG_KNOBS:
+            if v is None:
+                cur.pop(DEBUG_KNOBS[k], None)
+            else:
+                cur[DEBUG_KNOBS[k]] = str(v)
+        elif v is None:
+            monkeypatch.delenv(k, raising=False)
+        else:
+            monkeypatch.setenv(k, str(v))
+    if cur:
+        monkeypatch.setenv("SDPA_DEBUG", ",".join("%s=%s" % kv for kv in cur.items()))
+    else:
+        monkeypatch.delenv("SDPA_DEBUG", raising=False)

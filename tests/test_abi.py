@@ -84,14 +84,14 @@ def test_bf16_image_geometry_helpers(pkg):
     assert s2 == 2 and lib.sdpa_dev_workspace_bytes_bf16(70000, 4096, 64, 64) == s2 * 70000 * (64 + 2) * 4 + 547 * s2 * 4
     assert lib.sdpa_dev_kv_splits_bf16(65536, 4096, 64, 64) == 1 and lib.sdpa_dev_workspace_bytes_bf16(65536, 4096, 64, 64) == 512 * 4
     # fp32: one round of workgroups keeps the count that fills the chip once; beyond one round the last round is filled
-    # (classic equal splits, $SDPA_STREAMK=0; the default since round 4 is stream-K for such shapes -- next test)
-    os.environ["SDPA_STREAMK"] = "0"
+    # (classic equal splits, $SDPA_DEBUG=streamk=0; the default since round 4 is stream-K for such shapes -- next test)
+    os.environ["SDPA_DEBUG"] = "streamk=0"
     pkg.reload_env()
     try:
         assert lib.sdpa_dev_kv_splits(40000, 65536, 128, 128) == 8       # 313 query blocks: 2 splits = 1.22 rounds (61 %), 8 = 4.9 (98 %)
         assert lib.sdpa_dev_kv_splits(32768, 65536, 256, 256) == 1 and lib.sdpa_dev_kv_splits(40000, 65536, 256, 256) == 4
     finally:
-        os.environ.pop("SDPA_STREAMK", None)
+        os.environ.pop("SDPA_DEBUG", None)
         pkg.reload_env()
     splits = lib.sdpa_dev_kv_splits_bf16(32768, 65536, 512, 512)
     assert splits == 1 and lib.sdpa_dev_workspace_bytes_bf16(32768, 65536, 512, 512) == 256 * 4
@@ -118,14 +118,14 @@ def test_stream_k_plan_arithmetic(pkg):
     assert lib.sdpa_dev_kv_splits(33000, 65536, 128, 128) == 3
     assert lib.sdpa_dev_kv_splits(40000, 65536, 128, 128) == 3
     # head dims outside the pipelined kernels are untouched (dk-split kernel, bf16 has its own picker)
-    os.environ["SDPA_STREAMK"] = "0"
+    os.environ["SDPA_DEBUG"] = "streamk=0"
     pkg.reload_env()
     try:
         classic = [lib.sdpa_dev_kv_splits(m, 65536, 512, 512) for m in (32768, 33000, 40000)]
         assert lib.sdpa_dev_kv_splits(33000, 65536, 128, 128) > 3
         assert lib.sdpa_dev_workspace_bytes(32768, 65536, 128, 128) >= ws(32768, 128, 2)    # (masked streams: many equal splits)
     finally:
-        os.environ.pop("SDPA_STREAMK", None)
+        os.environ.pop("SDPA_DEBUG", None)
         pkg.reload_env()
     assert [lib.sdpa_dev_kv_splits(m, 65536, 512, 512) for m in (32768, 33000, 40000)] == classic
 

@@ -9,6 +9,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import knob_env
+
 pytestmark = pytest.mark.gpu
 
 CASES = int(os.environ.get("SDPA_FUZZ_CASES", "60"))
@@ -97,8 +99,8 @@ def test_fuzz_host_boundary(prec, pkg, orc, O, monkeypatch):
                  # convert placement (round 3): device, host threads, or chosen per problem
                  "SDPA_HOST_CVT": str(rng.choice(["0", "1", "auto"])),
                  "SDPA_HOST_CVT_THREADS": int(rng.choice([1, 5, 32]))}
-        for k, v in knobs.items():
-            monkeypatch.setenv(k, str(v))
+        for k, v in knob_env(knobs).items():
+            monkeypatch.setenv(k, v)
         Q, K, V = O.make_inputs(m, n, dk, dv, dist, seed=9000 + it)
         got = pkg.attention(Q, K, V, precision=prec, flags=int(rng.integers(0, 2)))
         want = O.numpy_attention_f64(Q, K, V)
@@ -113,8 +115,7 @@ def test_fuzz_loopback_ranks(pkg, orc, O, monkeypatch):
     shapes with n < P (empty shards) and ragged batches"""
     assert torch.cuda.is_available()
     rng = np.random.default_rng(31337)
-    knob_names = ("SDPA_VIRTUAL_GPUS", "SDPA_QBATCH", "SDPA_KV_CHUNK_MIN", "SDPA_KV_CHUNK_MAX", "SDPA_ROW_PIECES",
-                  "SDPA_PIECE_MIN_ROWS", "SDPA_EGRESS", "SDPA_ENQUEUE_THREADS", "SDPA_HOST_CVT", "SDPA_PROGRESSIVE_PIN")
+    knob_names = ("SDPA_VIRTUAL_GPUS", "SDPA_QBATCH", "SDPA_EGRESS", "SDPA_HOST_CVT", "SDPA_DEBUG")
     try:
         for it in range(max(8, CASES // 4)):
             P = int(rng.choice([2, 3, 4, 5, 8, 16]))
@@ -132,8 +133,8 @@ def test_fuzz_loopback_ranks(pkg, orc, O, monkeypatch):
                      "SDPA_EGRESS": str(rng.choice(["root", "scatter"])), "SDPA_ENQUEUE_THREADS": int(rng.integers(0, 2)),
                      "SDPA_HOST_CVT": str(rng.choice(["0", "1"])), "SDPA_PROGRESSIVE_PIN": int(rng.integers(0, 2))}
             pkg.shutdown()
-            for k, v in knobs.items():
-                monkeypatch.setenv(k, str(v))
+            for k, v in knob_env(knobs).items():
+                monkeypatch.setenv(k, v)
             pkg.init(1)
             dist = ["D1", "D2", "D4"][int(rng.integers(0, 3))]
             Q, K, V = O.make_inputs(m, n, dk, dv, dist, seed=12000 + it)

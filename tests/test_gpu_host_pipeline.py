@@ -1,7 +1,7 @@
 """GPU (-m gpu): the host-level pipeline of sdpa_attention_f64 (csrc/sdpa_host.hip) -- K/V chunk
 streaming, the pieces of the last batch, and the P > 1 choreography of attention-mpi.c:340-399 run
 on ONE device through loopback ranks (SDPA_VIRTUAL_GPUS=P), plus the real RCCL calls on a one-rank
-communicator (SDPA_FORCE_COLLECTIVES=1).
+communicator ($SDPA_DEBUG force_collectives=1).
 
 Tolerance: max|got - fp64 oracle| <= 5e-5 * max(1, max|V|) for fp32
 compute, 1e-2 * max(1, max|V|) for the bf16 path; NaN/Inf anywhere fails."""
@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import fp32_tol
+from conftest import fp32_tol, knob_env, set_knobs
 
 pytestmark = pytest.mark.gpu
 
@@ -42,20 +42,18 @@ def engine(pkg, monkeypatch):
 
     def make(**env):
         pkg.shutdown()
-        for k in ("SDPA_VIRTUAL_GPUS", "SDPA_FORCE_COLLECTIVES", "SDPA_QBATCH", "SDPA_KV_CHUNK_MIN",
-                  "SDPA_KV_CHUNK_MAX", "SDPA_ROW_PIECES", "SDPA_PIECE_MIN_ROWS", "SDPA_PLAN", "SDPA_MERGE", "SDPA_PRECISION",
-                  "SDPA_EGRESS", "SDPA_ENQUEUE_THREADS", "SDPA_PROGRESSIVE_PIN", "SDPA_HOST_CVT", "SDPA_HOST_CVT_THREADS",
-                  "SDPA_COMM_CUS", "SDPA_HOST_WIDEN", "SDPA_HOST_REGISTER", "SDPA_STREAMED", "SDPA_STREAM_CHUNK_MIN",
-                  "SDPA_STREAM_TIMEOUT_MS", "SDPA_STREAM_PROBE_MS", "SDPA_DEBUG", "SDPA_HOST_CVT_PIN"):
+        for k in ("SDPA_VIRTUAL_GPUS", "SDPA_QBATCH", "SDPA_PLAN", "SDPA_MERGE", "SDPA_PRECISION", "SDPA_EGRESS",
+                  "SDPA_HOST_CVT", "SDPA_HOST_CVT_THREADS", "SDPA_COMM_CUS", "SDPA_HOST_WIDEN", "SDPA_HOST_REGISTER", "SDPA_STREAMED",
+                  "SDPA_STREAM_TIMEOUT_MS", "SDPA_DEBUG"):
             monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, str(v))
+        for k, v in knob_env(env).items():          # (round-1..5 variable names of test knobs go into ONE $SDPA_DEBUG string)
+            monkeypatch.setenv(k, v)
         pkg.init(1)
         return pkg
 
     yield make
     pkg.shutdown()
-    for k in ("SDPA_VIRTUAL_GPUS", "SDPA_FORCE_COLLECTIVES"):
+    for k in ("SDPA_VIRTUAL_GPUS", "SDPA_DEBUG"):
         monkeypatch.delenv(k, raising=False)
     pkg.init(1)
 
@@ -247,12 +245,12 @@ def test_engine_restores_the_callers_device_and_survives_reinit(engine, O, orc):
 
 def test_tune_env_cannot_change_the_shipped_library(engine, O, orc, monkeypatch):
     """$SDPA_TUNE selected timing-only ablation kernels in round 1; the shipped build must ignore it"""
-    monkeypatch.setenv("SDPA_TUNE", "112")
+    set_knobs(monkeypatch, SDPA_TUNE=112)
     pkg = engine()
     Q, K, V = O.make_inputs(300, 2000, 128, 128, "D2", seed=2)
     check(pkg.attention(Q, K, V), orc.attention_f64(Q, K, V), V, "SDPA_TUNE=112")
     Q, K, V = O.make_inputs(130, 1000, 512, 512, "D1", seed=2)
-    monkeypatch.setenv("SDPA_TUNE", str(15 << 8))
+    set_knobs(monkeypatch, SDPA_TUNE=15 << 8)
     check(pkg.attention(Q, K, V, precision="bf16"), orc.attention_f64(Q, K, V), V, "SDPA_TUNE bf16", 1e-2 * max(1.0, float(np.abs(V).max())))
 
 
@@ -264,7 +262,7 @@ def test_multi_rank_schedules_agree_bit_for_bit(P, m, n, d, batch, engine, orc, 
     per-batch collectives on the ranks' comm streams (batch b's merge under batch b+1's kernels,
     attention-mpi.c:364-380), the merged rows reduce-SCATTERED so that every rank sends its share home --
     against the schedule of round 2 (one thread, reduce to the root, $SDPA_EGRESS=root
-    $SDPA_ENQUEUE_THREADS=0): the loopback collectives sum in rank order either way, so the results must
+    $SDPA_DEBUG=enqueue_threads=0): the loopback collectives sum in rank order either way, so the results must
     be IDENTICAL bit for bit, both merges; and within tolerance of the fp64 oracle."""
     Q, K, V = O.make_inputs(m, n, d, d, "D4", seed=P * 1000 + m)
     want = orc.attention_f64(Q, K, V)
@@ -812,7 +810,7 @@ def test_streamed_bf16_shards_on_loopback_ranks(P, m, n, dk, dv, engine, O):
 
 
 def test_converter_pool_on_the_numa_node_of_the_source_arrays_is_opt_in(engine, O):
-    """$SDPA_HOST_CVT_PIN=1 confines the converter pool's threads to the NUMA node the call's fp64 arrays live on (sampled pages; numpy
+    """$SDPA_DEBUG=host_cvt_pin=1 confines the converter pool's threads to the NUMA node the call's fp64 arrays live on (sampled pages; numpy
     arrays written by this thread live on ONE node) -- opt-in, because it did not pay (profiles/r05/converter_pool_numa_pin_ab.log);
     by default the threads run where the scheduler puts them.  Same bytes either way."""
     import glob

@@ -21,7 +21,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import PKG, ROOT, fp32_tol
+from conftest import PKG, ROOT, fp32_tol, knob_env
 
 pytestmark = pytest.mark.gpu
 
@@ -113,8 +113,8 @@ def test_python_host_and_c_host_agree_bit_for_bit(world, m, n, B, streamed, tmp_
     if streamed:
         cenv = dict(env, SDPA_VIRTUAL_GPUS=str(world), SDPA_QBATCH=str(B))
     else:
-        cenv = dict(env, SDPA_VIRTUAL_GPUS=str(world), SDPA_QBATCH=str(B), SDPA_ROW_PIECES="1",
-                    SDPA_KV_CHUNK_MIN=str(1 << 22), SDPA_KV_CHUNK_MAX=str(1 << 22), SDPA_HOST_CVT="0")
+        cenv = dict(env, **knob_env(dict(SDPA_VIRTUAL_GPUS=str(world), SDPA_QBATCH=str(B), SDPA_ROW_PIECES="1",
+                                         SDPA_KV_CHUNK_MIN=str(1 << 22), SDPA_KV_CHUNK_MAX=str(1 << 22), SDPA_HOST_CVT="0")))
     # 16 compute units' worth of workgroup slots stay free for the comm streams when the call has a NEXT batch to hide a
     # collective tail under (csrc/sdpa_host.hip: comm_cus_reserved, make_plan); a one-batch call gets the whole chip
     cus = 240 if m > B else 256

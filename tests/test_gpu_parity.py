@@ -368,11 +368,11 @@ def test_cli_bf16_env_and_qbatch(tmp_path, O):
 
 def test_cli_io_modes_and_pinned_host_arrays(tmp_path, pkg, orc, O):
     """the CLI reads into page-locked memory by default, into malloc'd memory with
-    SDPA_PINNED_IO=0, and creates the engine inside the timed call with SDPA_TIME_INIT=1 -- same
+    $SDPA_DEBUG=pinned_io=0, and creates the engine inside the timed call with $SDPA_DEBUG=time_init=1 -- same
     verdict each way; sdpa_host_alloc memory works as caller arrays of the boundary call"""
     case = os.path.join(GOLD, "cfg1_small_D1.bin")
-    for env in ({}, {"SDPA_PINNED_IO": "0"}, {"SDPA_TIME_INIT": "1"}, {"SDPA_CLI_PREFETCH": "1"},
-                {"SDPA_CLI_PREFETCH": "1", "SDPA_PINNED_IO": "0", "SDPA_VIRTUAL_GPUS": "2"}):
+    for env in ({}, {"SDPA_DEBUG": "pinned_io=0"}, {"SDPA_DEBUG": "time_init=1"}, {"SDPA_CLI_PREFETCH": "1"},
+                {"SDPA_CLI_PREFETCH": "1", "SDPA_DEBUG": "pinned_io=0", "SDPA_VIRTUAL_GPUS": "2"}):
         r = subprocess.run([CLI, case], capture_output=True, text=True, env=dict(os.environ, **env))
         assert r.returncode == 0 and r.stdout.startswith("Correct!\nElapsed time: "), (env, r.stderr)
     import ctypes
@@ -454,7 +454,7 @@ def test_error_ratio_vs_reference_fp32_pipeline(pkg, be, orc, O):
 def test_race_screen_repeatability(pkg, be, orc, O):
     """The pipelined kernel hands K/V tiles between waves through LDS-DMA + barriers, and the partial
     triples of its in-GPU K/V splits between WORKGROUPS (different XCDs, non-coherent L2s) through an
-    agent-scope release / ticket / acquire when the kernel merges them itself ($SDPA_SPLIT_MERGE=kernel,
+    agent-scope release / ticket / acquire when the kernel merges them itself ($SDPA_DEBUG=split_merge=kernel,
     the second half of this screen); a missing wait or a stale line shows up as rare wrong tiles.
     Screen: 100 launches each of three shapes (in-GPU splits, ragged tails, both MFMA kernels) must be
     BITWISE identical to the first, which is checked against the oracle.  All shapes share one scratch
@@ -474,13 +474,13 @@ def test_race_screen_repeatability(pkg, be, orc, O):
         runs.append((sa, qf, dv, first))
     for it in range(1, 100):
         if it == 50:
-            os.environ["SDPA_SPLIT_MERGE"] = "kernel"
+            os.environ["SDPA_DEBUG"] = "split_merge=kernel"
             pkg.reload_env()
         for sa, qf, dv, first in runs:                 # interleaved: the scratch area changes hands every launch
             cur = sa.batch_partial(qf)
             assert all(torch.equal(a_[:, :dv] if a_.dim() == 2 else a_, b_[:, :dv] if b_.dim() == 2 else b_)
                        for a_, b_ in zip(cur, first)), "launch %d differs from launch 0" % it
-    os.environ.pop("SDPA_SPLIT_MERGE", None)
+    os.environ.pop("SDPA_DEBUG", None)
     pkg.reload_env()
 
 
@@ -490,7 +490,7 @@ def test_race_screen_repeatability(pkg, be, orc, O):
                                         (4096, 8192, 128, 64), (700, 9000, 64, 128), (900, 7000, 250, 120)])
 def test_in_kernel_split_merge_equals_the_separate_pass_bitwise(m, n, dk, dv, pkg, be, O, monkeypatch):
     """kv_splits > 1 on the pipelined kernels: split_merge_kernel merges the partial triples right behind
-    the fused launch (the default: measured faster).  With $SDPA_SPLIT_MERGE=kernel the last workgroup
+    the fused launch (the default: measured faster).  With $SDPA_DEBUG=split_merge=kernel the last workgroup
     of a query block to arrive merges the block's triples inside the fused launch (one launch per step):
     same weights, same sums in the same split order -- the two forms must agree bit for bit, 20 launches
     (under load from the neighbouring query blocks)."""
@@ -499,10 +499,10 @@ def test_in_kernel_split_merge_equals_the_separate_pass_bitwise(m, n, dk, dv, pk
     sa = pkg.ShardedAttention(be)
     sa.load_kv_from_root(K, V, n, dk, dv)
     qf = sa.convert_q(torch.from_numpy(Q).cuda())
-    monkeypatch.delenv("SDPA_SPLIT_MERGE", raising=False)
+    monkeypatch.delenv("SDPA_DEBUG", raising=False)
     pkg.reload_env()
     want = tuple(t.clone() for t in sa.batch_partial(qf))
-    monkeypatch.setenv("SDPA_SPLIT_MERGE", "kernel")
+    monkeypatch.setenv("SDPA_DEBUG", "split_merge=kernel")
     pkg.reload_env()
     for it in range(20):
         got = sa.batch_partial(qf)
@@ -522,28 +522,26 @@ def test_in_kernel_split_merge_equals_the_separate_pass_bitwise(m, n, dk, dv, pk
     (96, 777, 1024, 32, "D2"),         # 256-wide slices, ONE P.V MFMA per k-step: four units per gap
     (1024, 2049, 512, 200, "D3"),      # 64-wide dv slices (two units per gap), dv not a multiple of the chunk
     (96, 777, 700, 130, "D2"),
-    (200, 3000, 200, 256, "D2"),       # the non-dense 128 < dk <= 256 use of the kernel
+    (200, 3000, 200, 256, "D2"),       # 128 < dk <= 256 with dv = 256: NOT this kernel's (fused_pipelined_kernel<256,256>), same bar
+    (200, 3000, 300, 256, "D2"),       # just beyond: 96-wide dk slices of a padded dk = 384
     (33, 1, 640, 640, "D1"),           # a single key
 ])
-def test_f32_dksplit_pipelined_kernel_equals_the_serial_one_bit_for_bit(m, n, dk, dv, dist, pkg, be, orc, O, monkeypatch):
-    """dk > 256 in fp32: fused_dksplit_pipe_kernel (the default) places the exchange sums and the softmax of
-    tile t+1 between the P.V MFMAs of tile t; fused_dksplit_kernel ($SDPA_DKSPLIT_PIPE=0) runs the phases one
-    after the other.  Same operations in the same order on every value: the triples must be IDENTICAL
-    (5 launches), and within the fp32 tolerance of the fp64 oracle."""
+def test_f32_dksplit_pipelined_kernel_against_the_oracle_and_itself(m, n, dk, dv, dist, pkg, be, orc, O):
+    """dk > 256 in fp32: fused_dksplit_pipe_kernel places the exchange sums and the softmax of tile t+1 between the P.V MFMAs of
+    tile t (its serial-phase twin was retired in round 6).  Its partial score tiles cross LDS behind one barrier per tile: a
+    missing wait shows as rare wrong tiles -- 5 launches must be IDENTICAL -- and the result sits within the fp32 tolerance of
+    the fp64 oracle."""
     Q, K, V = O.make_inputs(m, n, dk, dv, dist, seed=m + n + dk)
     sa = pkg.ShardedAttention(be)
     sa.load_kv_from_root(K, V, n, dk, dv)
     qf = sa.convert_q(torch.from_numpy(np.ascontiguousarray(Q)).cuda())
-    monkeypatch.setenv("SDPA_DKSPLIT_PIPE", "0")
-    pkg.reload_env()
     want = tuple(t.clone() for t in sa.batch_partial(qf))
-    monkeypatch.setenv("SDPA_DKSPLIT_PIPE", "1")
-    pkg.reload_env()
+    assert ("fused_dksplit_pipe_kernel" if dk > 256 else "fused_pipelined_kernel<256,256") in pkg.last_launch()["kernel"]
     for it in range(5):
         got = sa.batch_partial(qf)
         for name, g, w in zip(("contrib", "lmax", "lsum"), got, want):
             g, w = (g[:, :dv], w[:, :dv]) if g.dim() == 2 else (g, w)
-            assert torch.equal(g, w), "launch %d: %s of the pipelined kernel differs from the serial one" % (it, name)
+            assert torch.equal(g, w), "launch %d: %s differs from the first launch" % (it, name)
     res = be.finish_f64(got[0], got[2], dv).cpu().numpy()
     check(res, orc.attention_f64(Q, K, V), V, "dk-split pipelined")
 

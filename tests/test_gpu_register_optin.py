@@ -25,14 +25,17 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
     sys.path.insert(0, p)
 import oracle as O
 pkg = importlib.import_module(PKG)
-KNOBS = ("SDPA_HOST_REGISTER", "SDPA_PROGRESSIVE_PIN", "SDPA_VIRTUAL_GPUS", "SDPA_QBATCH", "SDPA_EGRESS", "SDPA_HOST_CVT", "SDPA_HOST_WIDEN",
+KNOBS = ("SDPA_HOST_REGISTER", "SDPA_DEBUG", "SDPA_VIRTUAL_GPUS", "SDPA_QBATCH", "SDPA_EGRESS", "SDPA_HOST_CVT", "SDPA_HOST_WIDEN",
          "SDPA_STREAMED")
 def engine(**env):
     pkg.shutdown()
     for k in KNOBS:
         os.environ.pop(k, None)
     for k, v in env.items():
-        os.environ[k] = str(v)
+        if k == "SDPA_PROGRESSIVE_PIN":                 # (a test knob: lives in $SDPA_DEBUG since round 6)
+            os.environ["SDPA_DEBUG"] = "progressive_pin=%s" % v
+        else:
+            os.environ[k] = str(v)
     pkg.init(1)
 checked = 0
 for (m, n, d, prec, env) in [(1500, 9000, 128, None, {}),
@@ -72,7 +75,7 @@ print("registered paths agree with the default bit for bit: %d configurations" %
 
 def test_registered_caller_arrays_give_the_default_paths_result_bit_for_bit():
     env = dict(os.environ)
-    for k in ("SDPA_HOST_REGISTER", "SDPA_PROGRESSIVE_PIN", "SDPA_VIRTUAL_GPUS", "SDPA_QBATCH", "SDPA_EGRESS", "SDPA_STREAMED"):
+    for k in ("SDPA_HOST_REGISTER", "SDPA_DEBUG", "SDPA_VIRTUAL_GPUS", "SDPA_QBATCH", "SDPA_EGRESS", "SDPA_STREAMED"):
         env.pop(k, None)
     def child():
         return subprocess.run([sys.executable, "-c", CHILD, ROOT, PKG], capture_output=True, text=True, timeout=900, env=env)

@@ -5,6 +5,8 @@ owner_count / owner_disp (attention-mpi.c:19-27), chunks tile a shard exactly on
 operand image's tiling divides, slots are dense, and the environment knobs do what INTEGRATION.md says."""
 import pytest
 
+from conftest import set_knobs
+
 SDPA_F_NO_PIPELINE, SDPA_F_BF16, SDPA_F_PLAN_QROWS, SDPA_F_MERGE_ALLREDUCE = 1, 2, 4, 8
 
 SHAPES = [(32768, 65536, 128, 128), (8192, 8192, 128, 128), (512, 512, 64, 64), (131072, 65536, 128, 128),
@@ -14,8 +16,7 @@ SHAPES = [(32768, 65536, 128, 128), (8192, 8192, 128, 128), (512, 512, 64, 64), 
 
 @pytest.fixture(autouse=True)
 def clean_env(monkeypatch):
-    for k in ("SDPA_STREAMED", "SDPA_STREAM_CHUNK_MIN", "SDPA_QBATCH", "SDPA_KV_CHUNK_MIN", "SDPA_KV_CHUNK_MAX", "SDPA_ROW_PIECES", "SDPA_PIECE_MIN_ROWS",
-              "SDPA_PLAN", "SDPA_MERGE", "SDPA_PRECISION", "SDPA_FORCE_COLLECTIVES"):
+    for k in ("SDPA_STREAMED", "SDPA_DEBUG", "SDPA_QBATCH", "SDPA_PLAN", "SDPA_MERGE", "SDPA_PRECISION"):
         monkeypatch.delenv(k, raising=False)
 
 
@@ -156,17 +157,14 @@ def test_knobs(pkg, monkeypatch):
     monkeypatch.setenv("SDPA_QBATCH", "10000")
     assert pkg.plan(100000, 100000, 128, 128)["q_batches"] == 10
     monkeypatch.delenv("SDPA_QBATCH")
-    monkeypatch.setenv("SDPA_KV_CHUNK_MIN", "8192")
-    monkeypatch.setenv("SDPA_KV_CHUNK_MAX", "8192")
+    set_knobs(monkeypatch, SDPA_KV_CHUNK_MIN=8192, SDPA_KV_CHUNK_MAX=8192)          # (test knobs: $SDPA_DEBUG=kv_chunk_min=...,kv_chunk_max=...)
     ch = pkg.plan(32768, 65536, 128, 128)["r"][0]["chunks"]
     assert [c[1] for c in ch] == [8192] * 8
-    monkeypatch.setenv("SDPA_KV_CHUNK_MIN", "5000")          # rounded down to a multiple of 1024
-    monkeypatch.setenv("SDPA_KV_CHUNK_MAX", "5000")
+    set_knobs(monkeypatch, SDPA_KV_CHUNK_MIN=5000, SDPA_KV_CHUNK_MAX=5000)          # rounded down to a multiple of 1024
     assert [c[1] for c in pkg.plan(32768, 65536, 128, 128)["r"][0]["chunks"]][:3] == [4096] * 3
-    monkeypatch.delenv("SDPA_KV_CHUNK_MIN"); monkeypatch.delenv("SDPA_KV_CHUNK_MAX")
-    monkeypatch.setenv("SDPA_ROW_PIECES", "1")
+    set_knobs(monkeypatch, SDPA_KV_CHUNK_MIN=None, SDPA_KV_CHUNK_MAX=None, SDPA_ROW_PIECES=1)
     assert pkg.plan(32768, 65536, 128, 128)["r"][0]["piece_rows"] == 32768
-    monkeypatch.delenv("SDPA_ROW_PIECES")
+    set_knobs(monkeypatch, SDPA_ROW_PIECES=None)
     # SDPA_F_NO_PIPELINE: one batch, one chunk, no pieces (the round-1 structure)
     pl = pkg.plan(100000, 100000, 128, 128, SDPA_F_NO_PIPELINE)
     assert pl["q_batches"] == 1 and pl["q_batch"] == 100000 and len(pl["r"][0]["chunks"]) == 1 and pl["row_pieces"] == 1
@@ -241,10 +239,10 @@ CONFIG3, METRIC, CONFIG4 = (32768, 262144, 128, 128), (32768, 65536, 128, 128), 
                                                                             # stream-K grids have no streamed form: device converts, as before
 ])
 def test_feed_model_choice_for_the_baseline_shapes(shape, ranks, page_locked, pkg, monkeypatch):
-    """pinned for the GPU boxes' host as the library sees it: a 16-core CPU quota ($SDPA_HOST_CORES stands in for cgroup cpu.max here),
+    """pinned for the GPU boxes' host as the library sees it: a 16-core CPU quota ($SDPA_DEBUG=host_cores=16 stands in for cgroup cpu.max here),
     32 pool threads, ~170 GB/s of fp64 source (measured: profiles/r06/feed_model_p8.log).  Pageable caller arrays keep the pool at every P (device converts would pull them
     through the runtime's bounce buffers on the enqueueing threads); page-locked ones follow the model."""
-    monkeypatch.setenv("SDPA_HOST_CORES", "16")
+    set_knobs(monkeypatch, SDPA_HOST_CORES=16)
     for k in ("SDPA_HOST_CVT", "SDPA_HOST_CVT_THREADS", "SDPA_STREAMED"):
         monkeypatch.delenv(k, raising=False)
     m, n, dk, dv = shape
@@ -265,15 +263,15 @@ def test_feed_model_follows_the_hosts_real_core_count(pkg, monkeypatch):
     for k in ("SDPA_HOST_CVT", "SDPA_HOST_CVT_THREADS", "SDPA_STREAMED"):
         monkeypatch.delenv(k, raising=False)
     m, n, dk, dv = CONFIG3
-    monkeypatch.setenv("SDPA_HOST_CORES", "8")
+    set_knobs(monkeypatch, SDPA_HOST_CORES=8)
     f = pkg.plan(m, n, dk, dv, 0, 1)["feed"]
     assert f["pool_threads"] == 16 and f["pageable"] == "device" and f["page_locked"] == "device", f
-    monkeypatch.setenv("SDPA_HOST_CORES", "128")
+    set_knobs(monkeypatch, SDPA_HOST_CORES=128)
     f = pkg.plan(m, n, dk, dv, 0, 8)["feed"]
     assert f["pool_threads"] == 128 and f["pool_GBps"] == 240.0 and f["page_locked"] == "host", f      # 2.4 ms of pool under 4.2 ms of kernel
     # a pool that cannot keep up with eight ranks: page-locked arrays go to the device converts (every rank pulls its fp64 shard over
     # its own link, launch per chunk), pageable ones stay with the pool
-    monkeypatch.setenv("SDPA_HOST_CORES", "16")
+    set_knobs(monkeypatch, SDPA_HOST_CORES=16)
     monkeypatch.setenv("SDPA_HOST_CVT_THREADS", "16")
     f = pkg.plan(m, n, dk, dv, 0, 8)["feed"]
     assert f["t_host_ms"] > 1.1 * max(f["t_kernel_ms"], f["t_link_ms"]) and f["page_locked"] == "device" and f["pageable"] == "host", f
@@ -281,7 +279,7 @@ def test_feed_model_follows_the_hosts_real_core_count(pkg, monkeypatch):
     monkeypatch.delenv("SDPA_HOST_CVT_THREADS")
     monkeypatch.setenv("SDPA_HOST_CVT_THREADS", "12")
     assert pkg.plan(m, n, dk, dv, 0, 8)["feed"]["pool_threads"] == 12
-    monkeypatch.delenv("SDPA_HOST_CORES")
+    set_knobs(monkeypatch, SDPA_HOST_CORES=None)
     monkeypatch.delenv("SDPA_HOST_CVT_THREADS")
     f = pkg.plan(m, n, dk, dv, 0, 1)["feed"]                                                          # whatever this machine is: consistent
     import os

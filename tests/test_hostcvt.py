@@ -204,10 +204,10 @@ def test_host_vt_rejects_bad_arguments(pkg):
 
 @pytest.mark.parametrize("keys,cols,cols_pad,threads,item_kb", [(4096, 256, 256, 8, 64), (1000, 200, 256, 3, 4), (8192, 64, 64, 5, 1024)])
 def test_host_vt_on_a_pool_of_threads_is_the_single_thread_image(keys, cols, cols_pad, threads, item_kb, pkg, monkeypatch):
-    """the pool's work items (whole 32-key tiles, $SDPA_HOST_CVT_ITEM_KB of source each, taken by whichever thread is free) write the
+    """the pool's work items (whole 32-key tiles, $SDPA_DEBUG=host_cvt_item_kb of source each, taken by whichever thread is free) write the
     same image as one thread does, including the zero tail and the pad rows"""
     lib = pkg.load()
-    monkeypatch.setenv("SDPA_HOST_CVT_ITEM_KB", str(item_kb))
+    monkeypatch.setenv("SDPA_DEBUG", "host_cvt_item_kb=%d" % item_kb)
     V = np.random.default_rng(keys + threads).normal(0, 2, (keys, cols))
     keys_pad = (keys + 31) // 32 * 32 + 64
     one = np.full((cols_pad, keys_pad), 0x1234, np.uint16)
@@ -224,7 +224,7 @@ def test_host_vt_image_fuzz(pkg):
     import os
     lib = pkg.load()
     rng = np.random.default_rng(20260922)
-    old = os.environ.get("SDPA_HOST_CVT_ITEM_KB")
+    old = os.environ.get("SDPA_DEBUG")
     try:
         for case in range(60):
             keys = int(rng.integers(0, 700))
@@ -235,7 +235,7 @@ def test_host_vt_image_fuzz(pkg):
                 keys_pad = 32
             ldt = keys_pad + 32 * int(rng.integers(0, 3))
             threads = int(rng.choice([1, 1, 2, 5]))
-            os.environ["SDPA_HOST_CVT_ITEM_KB"] = str(int(rng.choice([4, 64, 300])))
+            os.environ["SDPA_DEBUG"] = "host_cvt_item_kb=%d" % int(rng.choice([4, 64, 300]))
             V = rng.normal(0, 3, (keys, cols))
             if keys:
                 V.flat[rng.integers(0, V.size, min(V.size, 6))] = [0.0, -0.0, 1e-45, -3.0e38, 65504.0, 1.0 + 2.0 ** -9][:min(V.size, 6)]
@@ -248,9 +248,9 @@ def test_host_vt_image_fuzz(pkg):
             assert (img[:cols_pad, keys_pad:] == 0x5A5A).all() and (img[cols_pad] == 0x5A5A).all(), (case, "wrote outside its range")
     finally:
         if old is None:
-            os.environ.pop("SDPA_HOST_CVT_ITEM_KB", None)
+            os.environ.pop("SDPA_DEBUG", None)
         else:
-            os.environ["SDPA_HOST_CVT_ITEM_KB"] = old
+            os.environ["SDPA_DEBUG"] = old
 
 
 # ---- the TILED images of dv > 256 (round 6: include/sdpa_hip.h) -----------------------------------------------------------------
@@ -318,7 +318,7 @@ def test_host_tiled_vt_image_is_the_documented_layout(keys, cols, cols_pad, extr
 @pytest.mark.parametrize("keys,cols,cols_pad,threads,item_kb", [(4096, 512, 512, 8, 64), (1000, 300, 512, 3, 4), (2048, 1000, 1024, 5, 256)])
 def test_host_tiled_vt_on_a_pool_of_threads_is_the_single_thread_image(keys, cols, cols_pad, threads, item_kb, pkg, monkeypatch):
     lib = pkg.load()
-    monkeypatch.setenv("SDPA_HOST_CVT_ITEM_KB", str(item_kb))
+    monkeypatch.setenv("SDPA_DEBUG", "host_cvt_item_kb=%d" % item_kb)
     V = np.random.default_rng(keys + threads).normal(0, 2, (keys, cols))
     keys_pad = (keys + 31) // 32 * 32 + 64
     one = np.full(cols_pad * keys_pad, 0x1234, np.uint16)

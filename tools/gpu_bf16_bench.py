@@ -35,4 +35,4 @@ for (m, n, d) in [(32768, 65536, d) for d in dims] + [(8192, 8192, 128)]:
     print(json.dumps({"shape": [m, n, d], "kernel_ms": ms, "tflops": flop / ms / 1e9,
                       "frac_of_2.5PF": flop / ms / 1e9 / 2500.0,
                       "kv_splits": pkg.load().sdpa_dev_kv_splits_bf16(m, n, d, d),
-                      "duo": os.environ.get("SDPA_BF16_DUO", "1")}), flush=True)
+                      "debug": os.environ.get("SDPA_DEBUG", "")}), flush=True)

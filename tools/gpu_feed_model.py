@@ -2,7 +2,7 @@
 ranks -- with SDPA_VIRTUAL_GPUS=8 it converts exactly what eight real ranks would ask it for, in the same order.  For config 3, the
 metric shape and config 4, pageable and page-locked caller arrays: the plan's feed model (sdpa_plan_describe: t_host / t_link / t_kernel
 and its choice), then the call with the model's choice, with host converts forced and with device converts forced; the pool's own
-wall time per call comes from $SDPA_HOST_CVT_TRACE (stderr).  The kernels of eight loopback ranks share one chip and one PCIe link:
+wall time per call comes from $SDPA_DEBUG=host_cvt_trace=1 (stderr).  The kernels of eight loopback ranks share one chip and one PCIe link:
 total_ms is NOT a P = 8 prediction, the pool's "last item done" is.
     python tools/gpu_feed_model.py            -> profiles/r06/feed_model_p8.log"""
 import ctypes
@@ -64,7 +64,7 @@ for name, (m, n, d) in SHAPES.items():
         print(json.dumps({"shape": name, "plan_ranks": P, "feed": pkg.plan(m, n, d, d, 0, P)["feed"]}), flush=True)
     for mem in ("pageable", "pinned"):
         for tag, env in (("model's choice", {}), ("host converts forced", {"SDPA_HOST_CVT": "1"}), ("device converts forced", {"SDPA_HOST_CVT": "0"})):
-            e = dict(os.environ, SDPA_VIRTUAL_GPUS="8", SDPA_HOST_CVT_TRACE="1", **env)
+            e = dict(os.environ, SDPA_VIRTUAL_GPUS="8", SDPA_DEBUG="host_cvt_trace=1", **env)
             t0 = time.perf_counter()
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", name, mem], capture_output=True, text=True, env=e)
             traces = [l for l in r.stderr.split("\n") if "hostcvt trace" in l]

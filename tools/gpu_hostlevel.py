@@ -29,6 +29,8 @@ register = "--register" in sys.argv
 streamed = "--streamed" in sys.argv
 KNOBS = ("SDPA_STREAMED", "SDPA_STREAM_CHUNK_MIN", "SDPA_QBATCH", "SDPA_KV_CHUNK_MIN", "SDPA_KV_CHUNK_MAX", "SDPA_ROW_PIECES", "SDPA_PIECE_MIN_ROWS", "SDPA_HOST_REGISTER",
          "SDPA_PROGRESSIVE_PIN")
+DEBUG = {"SDPA_STREAM_CHUNK_MIN": "stream_chunk_min", "SDPA_KV_CHUNK_MIN": "kv_chunk_min", "SDPA_KV_CHUNK_MAX": "kv_chunk_max", "SDPA_ROW_PIECES": "row_pieces",
+         "SDPA_PIECE_MIN_ROWS": "piece_min_rows", "SDPA_PROGRESSIVE_PIN": "progressive_pin"}      # -> $SDPA_DEBUG="name=value,..."
 SWEEP = [{},
          {"SDPA_ROW_PIECES": 1},
          {"SDPA_ROW_PIECES": 2},
@@ -75,8 +77,13 @@ for name in args or ["headline", "config2", "config1"]:
     for knobs in (SWEEP if sweep else WID if widen else REG if register else STR if streamed else CVT):
         for k in KNOBS + (("SDPA_HOST_CVT", "SDPA_HOST_CVT_THREADS", "SDPA_HOST_WIDEN") if (hostcvt or widen or register) else ()):
             os.environ.pop(k, None)           # (outside those modes a caller's $SDPA_HOST_CVT_THREADS etc. stay in force)
+        os.environ.pop("SDPA_DEBUG", None)
+        dbg = ["%s=%s" % (DEBUG[k], v) for k, v in knobs.items() if k in DEBUG]     # the tuning knobs live in ONE variable
+        if dbg:
+            os.environ["SDPA_DEBUG"] = ",".join(dbg)
         for k, v in knobs.items():
-            os.environ[k] = str(v)
+            if k not in DEBUG:
+                os.environ[k] = str(v)
         if hostcvt or widen or register or streamed:
             pkg.shutdown()
             pkg.init(1)
