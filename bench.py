@@ -890,7 +890,8 @@ OTHER_CONFIGS = (("config2", "config2", "f32"), ("config4", "config4", "f32"),
 def other_configs(pkg, be, dev, args):
     """N = 1: BASELINE configs 2, 4 and 5 (bf16 = the config as named; fp32 = its dims on the fp32 path) measured the way the
     headline is -- the same step on resident fp64 inputs, HIP events around the fused launch, 16 rows against the fp64
-    restatement -- plus the boundary call (host fp64 in/out).  5 timed steps each; every record is fenced."""
+    restatement -- plus the boundary call (host fp64 in/out).  5 timed steps each (more for the sub-millisecond step of config 2);
+    every record is fenced."""
     import copy
     out = {}
     inputs = {}
@@ -902,7 +903,9 @@ def other_configs(pkg, be, dev, args):
             a2 = copy.copy(args)
             a2.precision, a2.plan, a2.emulate_ranks = prec, "kv", 0
             j = Job(pkg, be, None, 1, 0, dev, m, n, d, a2, q_batch=0)
-            steps = 5
+            # (at least 5 steps and at least ~25 ms of them: five steps of config 2 are 1.5 ms between two host fences,
+            #  and the fences' ~50 us would be 3 % of the figure)
+            steps = max(5, min(100, prewarm_step_count(m, n, d, prec, 25.0)))
             e, r = j.timed(steps, 1, j.prewarm_steps(min(args.prewarm_ms, 40.0)))
             k_ms, k_flop, n_l = j.kernel_stats()
             launch = launched_kernel(pkg, d, prec)

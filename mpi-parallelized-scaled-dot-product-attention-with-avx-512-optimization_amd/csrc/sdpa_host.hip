@@ -84,6 +84,8 @@ struct Rank {
     hipStream_t s_cp = nullptr, s_in = nullptr, s_run = nullptr, s_out = nullptr, s_comm = nullptr;
     DevBuf k64, v64;                     // fp64 staging of the WHOLE shard (a copy never waits for a convert)
     DevBuf kf, vf;                       // operand image of the whole shard
+    bool vf_view = false;                // fp32: vf is the second half of kf's allocation (V image right behind the K image: one
+                                         // pitched copy can then carry a K/V group of the streamed launch into both, stage_chunk)
     DevBuf ws;                           // the fused kernel's own scratch (splits of a direct launch, redo flags)
     DevBuf slots;                        // partial triples of the streamed batch: [slot][row][ldo] + 2 x [slot][row]
     DevBuf q64[2], qf[2], contrib[2], stat[2], gstat[2], red[2], out64[2];
@@ -391,6 +393,10 @@ struct Chunk {
     int splits;         // in-launch K/V splits of the full-row launch
     int slot0;          // first slot it writes
     int group = 0;      // streamed form: the ready word that announces it
+    // streamed form, interleaved groups (round 6): the entry is ONE contiguous key range [k0, k0+keys) of the caller's shard that
+    // lands as `slices` row ranges of `keys / slices` keys each, `slice_pitch` keys apart, from key row `dst_k0` of the device image
+    // (one pitched copy per operand).  slices == 1: a plain range at dst_k0 == k0.
+    int dst_k0 = 0, slices = 1, slice_pitch = 0;
     // streamed form, bf16: the entry's columns of the Vt image travel as a PACKED block [padded dv rows][keys_pad] of the host
     // staging, `img_off` elements into it; keys_pad = whole 32-key tiles (the shard's last entry: up to the image's row length)
     long img_off = 0;
@@ -414,6 +420,18 @@ struct StreamPlan {
     int splits = 1, tiles_per_split = 0;
     std::vector<int> end_tile;          // per group
     std::vector<Chunk> entries;         // staging units in arrival order (group major, split minor)
+    // Round 6: INTERLEAVED groups (fp32, shards that are a whole number of tiles per split).  Which keys a split walks is free --
+    // softmax(QK^T)V does not care about the order of the keys, only that K row j and V row j stay a pair -- so group c is simply the
+    // c-th CONTIGUOUS key range of the caller's shard, and its `splits` equal slices go to tiles [end_tile[c-1], end_tile[c]) of the
+    // splits' ranges of the device image: ONE pitched copy per operand and group instead of `splits` row ranges.  The image is then a
+    // permutation of the shard (plan_describe: "interleaved": 1; the triples are the device-level launch's on the PERMUTED shard, bit
+    // for bit).  With one copy a group the groups can be small: config 2 (8 splits of 1024 keys) crosses PCIe in 4 groups instead of
+    // one, and its kernel starts after the first quarter of K/V instead of after all of it.
+    bool interleaved = false;
+    // ... and where the call is FEED bound (config 2: 0.36 ms of inputs for 0.26 ms of kernel) the Q rows travel as ONE copy between
+    // group 0 and group 0's ready word, which then announces both: a ready word is a copy of its own (64 KiB, ~7 us + ~8 us of engine
+    // turnaround either side), and no workgroup can do anything before it has its Q rows AND group 0 anyway.
+    bool q_with_group0 = false;
 };
 
 struct RankPlan {
@@ -706,22 +724,52 @@ void make_plan(Plan &pl, int m, int n, int dk, int dv, int flags, int ranks = 0)
                 // with 2 groups x 8 splits: 32 copies of 256 KiB, 1.02-1.05 ms against 0.99 chunked -- profiles/r05/
                 // boundary_streamed_vs_chunked_ab.log).  So a split's share of a group is at least $SDPA_DEBUG stream_entry_min
                 // keys; a shard too short for two such groups is ONE group -- whose ranges are adjacent: one copy.
-                const int entry_min = std::max(1, sdpa_debug_pos("stream_entry_min", 2048) / sdpa::kKvTile);
+                int entry_min = std::max(1, sdpa_debug_pos("stream_entry_min", 2048) / sdpa::kKvTile);
+                std::vector<int> gsz_i;
+                const bool interleave = !pl.bf16 && sp.splits > 1 && sdpa_debug_int("stream_interleave", 1) != 0 &&
+                                        (long)sp.splits * sp.tiles_per_split * sdpa::kKvTile == (long)rp.key_cnt;
+                if (interleave) {
+                    // one pitched copy per group and operand whatever the split count: a GROUP (not a split's share of it) is at
+                    // least stream_entry_min keys, and the groups may be as small as that
+                    entry_min = std::max(1, entry_min / sp.splits);
+                    const int smin = std::max(1024, sdpa_debug_pos("stream_interleave_min", 2048) / 1024 * 1024);
+                    // feed bound (the inputs take longer to arrive than the kernel takes: config 2): what counts is how little work is
+                    // left when the LAST group lands -- equal small groups; kernel bound: start early, then grow (fewer waits)
+                    const double t_feed_r = ((double)rows0 * dk + (double)rp.key_cnt * (dk + dv)) * 8.0 / 70e9;
+                    const double t_kern_r = 2.0 * rows0 * (double)rp.key_cnt * (dk + dv) / (dk <= 256 ? 1.3e14 : 1.0e14);
+                    const int smax = sdpa_debug_pos("stream_interleave_max", t_feed_r > t_kern_r ? smin : gmax);
+                    gsz_i = chunk_sizes(rp.key_cnt, std::min(scmin, smin), std::max(std::min(scmin, smin), std::max(smax, (int)(((long)rp.key_cnt / 12 + 1023) / 1024 * 1024))));
+                    sp.q_with_group0 = t_feed_r > t_kern_r && halves == 1 && sdpa_debug_int("stream_q_with_group0", 1) != 0;
+                }
+                const std::vector<int> &gsz_use = interleave ? gsz_i : gsz;
                 long cum = 0;
                 int prev = 0;
-                for (size_t gi = 0; gi < gsz.size(); ++gi) {
-                    cum += gsz[gi];
+                for (size_t gi = 0; gi < gsz_use.size(); ++gi) {
+                    cum += gsz_use[gi];
                     int end = (int)(((double)cum / rp.key_cnt) * sp.tiles_per_split + 0.5);
                     end = std::max(end, prev + entry_min);
-                    if (gi + 1 == gsz.size() || sp.tiles_per_split - end < entry_min) end = sp.tiles_per_split;
+                    if (gi + 1 == gsz_use.size() || sp.tiles_per_split - end < entry_min) end = sp.tiles_per_split;
                     end = std::min(sp.tiles_per_split, end);
                     if (end > prev) sp.end_tile.push_back(end);
                     prev = end;
                     if (prev >= sp.tiles_per_split) break;
                 }
                 if (!sp.end_tile.empty() && sp.end_tile.back() < sp.tiles_per_split) sp.end_tile.back() = sp.tiles_per_split;
+                sp.interleaved = interleave && sp.end_tile.size() >= 2 && (int)sp.end_tile.size() <= sdpa::kStreamMaxChunks;
+                sp.q_with_group0 = sp.q_with_group0 && sp.interleaved;
+                if (interleave && !sp.interleaved && sp.end_tile.size() > 1) sp.end_tile.assign(1, sp.tiles_per_split);
+                if (sp.interleaved) {
+                    for (size_t gi = 0; gi < sp.end_tile.size(); ++gi) {
+                        const int t0 = gi ? sp.end_tile[gi - 1] : 0, t1 = sp.end_tile[gi];
+                        Chunk e;
+                        e.k0 = sp.splits * t0 * sdpa::kKvTile; e.keys = sp.splits * (t1 - t0) * sdpa::kKvTile;
+                        e.splits = sp.splits; e.slot0 = -1; e.group = (int)gi;
+                        e.dst_k0 = t0 * sdpa::kKvTile; e.slices = sp.splits; e.slice_pitch = sp.tiles_per_split * sdpa::kKvTile;
+                        sp.entries.push_back(e);
+                    }
+                }
                 if (sp.end_tile.size() >= 1 && (int)sp.end_tile.size() <= sdpa::kStreamMaxChunks) {
-                    for (size_t gi = 0; gi < sp.end_tile.size(); ++gi)
+                    for (size_t gi = 0; gi < sp.end_tile.size() && !sp.interleaved; ++gi)
                         for (int sx = 0; sx < sp.splits; ++sx) {
                             const long t0 = gi ? sp.end_tile[gi - 1] : 0, t1 = sp.end_tile[gi];
                             const long k0 = ((long)sx * sp.tiles_per_split + t0) * sdpa::kKvTile;
@@ -734,6 +782,7 @@ void make_plan(Plan &pl, int m, int n, int dk, int dv, int flags, int ranks = 0)
                             }
                             Chunk e;
                             e.k0 = (int)k0; e.keys = (int)(k1 - k0); e.splits = sp.splits; e.slot0 = -1; e.group = (int)gi;
+                            e.dst_k0 = e.k0;
                             sp.entries.push_back(e);
                         }
                     if (pl.bf16) {
@@ -764,11 +813,18 @@ int ensure_buffers(const Plan &pl) {
         SDPA_TRY(ensure(rk.k64, (size_t)rp.key_cnt * pl.dk * sizeof(double)));
         SDPA_TRY(ensure(rk.v64, (size_t)rp.key_cnt * pl.dv * sizeof(double)));
         // (bf16: whole 32-key tiles of K rows -- the tiled image's last tile is read to its end, sdpa_internal.h)
-        SDPA_TRY(ensure(rk.kf, (size_t)(pl.bf16 ? sdpa::bf16_pad_n(rp.key_cnt) : rp.key_cnt) * pl.ldk * pl.kv_elem));
-        if (pl.bf16)
+        if (pl.bf16) {
+            if (rk.vf_view) { rk.vf = DevBuf(); rk.vf_view = false; }
+            SDPA_TRY(ensure(rk.kf, (size_t)sdpa::bf16_pad_n(rp.key_cnt) * pl.ldk * pl.kv_elem));
             SDPA_TRY(ensure(rk.vf, (size_t)sdpa::bf16_pad_dv(pl.dv) * sdpa::bf16_pad_n(rp.key_cnt) * sizeof(unsigned short)));
-        else
-            SDPA_TRY(ensure(rk.vf, (size_t)rp.key_cnt * pl.ldv * sizeof(float)));
+        } else {            // fp32: ONE allocation, the V image right behind the K image
+            const size_t kb = (size_t)rp.key_cnt * pl.ldk * sizeof(float), vb = (size_t)rp.key_cnt * pl.ldv * sizeof(float);
+            if (!rk.vf_view && rk.vf.p) { HIP_TRY(hipFree(rk.vf.p)); rk.vf = DevBuf(); }
+            SDPA_TRY(ensure(rk.kf, kb + vb));
+            rk.vf.p = (char *)rk.kf.p + kb;
+            rk.vf.cap = 0;
+            rk.vf_view = true;
+        }
         SDPA_TRY(ensure(rk.ws, rp.ws_bytes));
         const size_t B = (size_t)pl.B;
         if (rp.n_slots > 1) SDPA_TRY(ensure(rk.slots, (size_t)rp.n_slots * B * (pl.ldo + 2) * sizeof(float)));
@@ -911,6 +967,9 @@ struct HostImages {
     int ldv_host = 0;                                      // row stride of the host V image (bf16: dense dv)
     std::vector<size_t> v_rank_off;                        // bf16, streamed: byte offset of rank g's packed Vt image in `v`
     std::vector<char> streamed;                            // [rank]: chunk indices below name rp.stream.entries, not rp.chunks
+    bool pair = false;                                     // fp32, every rank streamed with interleaved groups, K and V images equally wide: `k` holds
+                                                           // group after group [K rows][V rows] (the group of shard keys [k0, k0+keys) at row 2*k0), and
+                                                           // ONE pitched copy carries a group into both device images (stage_chunk)
     std::vector<std::vector<int>> k_task, v_task;          // [rank][chunk]
     std::vector<std::vector<std::vector<int>>> q_task;     // [rank][batch][row piece]
 };
@@ -933,6 +992,12 @@ int stage_half(const Plan &pl, Rank &rk, const RankPlan &rp, const double *src, 
         if (!is_v || !pl.bf16) {
             const int ld = is_v ? pl.ldv : pl.ldk;
             const size_t el = is_v ? sizeof(float) : pl.kv_elem;
+            if (bare && ch.slices > 1) {       // an interleaved group: its slices land in the splits' ranges -- ONE pitched copy
+                const size_t slice = (size_t)(ch.keys / ch.slices) * ld * el;
+                HIP_TRY(hipMemcpy2DAsync((char *)(is_v ? rk.vf.p : rk.kf.p) + (size_t)ch.dst_k0 * ld * el, (size_t)ch.slice_pitch * ld * el,
+                                         (is_v ? HI.v : HI.k) + row0 * ld * el, slice, slice, (size_t)ch.slices, hipMemcpyHostToDevice, rk.s_cp));
+                return SDPA_OK;
+            }
             char *img = (char *)(is_v ? rk.vf.p : rk.kf.p) + (size_t)ch.k0 * ld * el;
             HIP_TRY(hipMemcpyAsync(img, (is_v ? HI.v : HI.k) + row0 * ld * el, (size_t)ch.keys * ld * el,
                                    hipMemcpyHostToDevice, rk.s_cp));
@@ -1010,6 +1075,27 @@ Prefetched &PF = *new Prefetched;
 
 // Both halves of chunk c (skipping what a prefetch already moved), then the chunk's ready event.
 int stage_chunk(const Plan &pl, Rank &rk, const RankPlan &rp, int g, const double *K, const double *V, int c) {
+    if (HI.cv && HI.pair && g >= 0 && g < (int)HI.streamed.size() && HI.streamed[g]) {
+        // an interleaved group of the streamed launch, K and V rows side by side in the staging: its `slices` K slices go to the
+        // splits' ranges of the K image, its V slices to the same places of the V image, which lies right behind (ensure_buffers):
+        // 2 * slices rows of ONE pitched copy (a copy costs ~8 us of engine turnaround whatever its size: profiles/r06/
+        // config2_boundary_timeline_*.txt)
+        const Chunk &ch = rp.stream.entries[c];
+        const size_t rowb = (size_t)pl.ldk * sizeof(float), slice = (size_t)(ch.keys / ch.slices) * rowb;
+        char *dst = (char *)rk.kf.p + (size_t)ch.dst_k0 * rowb;
+        const char *src = HI.k + 2 * ((size_t)rp.key_off + ch.k0) * rowb;
+        const size_t pitch = (size_t)ch.slice_pitch * rowb;
+        HI.cv->wait(HI.k_task[g][c]);
+        if (ch.group == 0) {      // the first group: its K half leaves as soon as it is converted (the converters have only just woken up)
+            HIP_TRY(hipMemcpy2DAsync(dst, pitch, src, slice, slice, (size_t)ch.slices, hipMemcpyHostToDevice, rk.s_cp));
+            HI.cv->wait(HI.v_task[g][c]);
+            HIP_TRY(hipMemcpy2DAsync(dst + ch.slices * pitch, pitch, src + ch.slices * slice, slice, slice, (size_t)ch.slices, hipMemcpyHostToDevice, rk.s_cp));
+            return SDPA_OK;
+        }
+        HI.cv->wait(HI.v_task[g][c]);
+        HIP_TRY(hipMemcpy2DAsync(dst, pitch, src, slice, slice, 2 * (size_t)ch.slices, hipMemcpyHostToDevice, rk.s_cp));
+        return SDPA_OK;
+    }
     const bool have_k = PF.active && PF.k_done[g][c], have_v = PF.active && PF.v_done[g][c];
     if (!have_k) SDPA_TRY(stage_half(pl, rk, rp, K, c, false, g));
     if (!have_v) SDPA_TRY(stage_half(pl, rk, rp, V, c, true, g));
@@ -1146,8 +1232,10 @@ int ship_rows_f32(Call &c, Rank &rk, size_t row0, int rows, const float *src32, 
         HIP_TRY(sdpa::launch_finish_f32(src32, ld, lsum, dense32, rows, dv, produced_on));
         from = dense32;
     }
-    HIP_TRY(hipEventRecord(produced, produced_on));
-    HIP_TRY(hipStreamWaitEvent(st, produced, 0));
+    if (st != produced_on) {
+        HIP_TRY(hipEventRecord(produced, produced_on));
+        HIP_TRY(hipStreamWaitEvent(st, produced, 0));
+    }
     HIP_TRY(hipMemcpyAsync(c.w_base + row0 * dv, from, (size_t)rows * dv * sizeof(float), hipMemcpyDeviceToHost, st));
     if (rk.ev_w_used == (int)rk.ev_w.size()) {
         hipEvent_t e;
@@ -1268,15 +1356,16 @@ bool plan_progressive_pins(Call &c) {
 // Rows [j0, j0+jr) of the batch in slot s are complete in contrib[s]/stat[s]: step 5 with gsum = lsum fused with the
 // writeback (attention-mpi.c:358-362, :373), then they go home -- as fp32 rows that the host widens, or as fp64 rows.
 // `finished`: the dense rows are in out64[s] already (the launch's fused merge + finish pass wrote them): only the copy home is left.
-int finish_rows(Call &c, int g, int s, int bs, size_t i0, int ev, int j0, int jr, bool finished = false) {
+int finish_rows(Call &c, int g, int s, int bs, size_t i0, int ev, int j0, int jr, bool finished = false, bool in_order = false) {
     const Plan &pl = c.pl;
     Rank &rk = E.r[g];
     const int dv = c.dv;
     need_pin(c, 3);                  // behind the enqueue of (nearly) all of the batch's kernels
     if (c.widen) {
-        if (finished)
+        if (finished)   // (in_order: nothing is left to run under the copy -- it goes into the compute stream itself, behind the pass that
+                        //  wrote the rows, and starts without the ~20 us a cross-stream event costs)
             return ship_rows_f32(c, rk, i0 + j0, jr, (const float *)rk.out64[s].p + (size_t)j0 * dv, dv, nullptr,
-                                 (float *)rk.out64[s].p + (size_t)j0 * dv, rk.s_run, rk.ev_sub[s][ev], rk.s_out);
+                                 (float *)rk.out64[s].p + (size_t)j0 * dv, rk.s_run, rk.ev_sub[s][ev], in_order ? rk.s_run : rk.s_out);
         return ship_rows_f32(c, rk, i0 + j0, jr, (const float *)rk.contrib[s].p + (size_t)j0 * pl.ldo, pl.ldo,
                              (const float *)rk.stat[s].p + bs + j0, (float *)rk.out64[s].p + (size_t)j0 * dv,
                              rk.s_run, rk.ev_sub[s][ev], rk.s_out);
@@ -1339,12 +1428,17 @@ int rank_batch0_streamed(Call &c, int g) {
     st.n_chunks = (int)sp.end_tile.size();
     for (int i = 0; i < st.n_chunks; ++i) st.chunk_end[i] = sp.end_tile[i];
     st.q_piece_blocks = std::max(1, (pr + sdpa::kQRowsPerBlock - 1) / sdpa::kQRowsPerBlock);
+    const bool q_with_group0 = sp.q_with_group0 && halves == 1 && HI.cv != nullptr;
+    if (q_with_group0) st.q_piece_blocks = 0;          // (no Q word: group 0's word announces the Q rows too)
     st.timeout_ticks = c.stream_timeout_ticks;
     st.status = rk.h_status;
     st.abort = rk.sflags + (size_t)(sdpa::kStreamMaxChunks + sdpa::kStreamMaxPieces) * sdpa::kStreamFlagStride;
     // a rank that finishes its own rows: the launch's merge pass also normalises and writes the dense rows that go home (round 6:
     // split_merge_finish_kernel -- the finish kernels of the row pieces and a round trip through contrib are gone)
     const bool fused_finish = finisher && sp.splits > 1;
+    // (sending the rows home from that pass itself -- streaming stores into the page-locked staging, no device-to-host copies -- was
+    //  built and measured in round 6: stores from a kernel cross PCIe at 36-40 GB/s against the copies' 55; config 2 0.76 -> 0.76-0.79 ms,
+    //  the metric shape 8.92-8.97 -> 8.94-8.95: not kept, profiles/r06/config2_boundary_steps.log)
     auto fin_of = [&](size_t r0) -> sdpa::FinishTarget {
         sdpa::FinishTarget f = {nullptr, nullptr};
         if (c.widen) f.out32 = (float *)rk.out64[s].p + r0 * c.dv;
@@ -1415,14 +1509,19 @@ int rank_batch0_streamed(Call &c, int g) {
     };
     const int E_n = (int)sp.entries.size();
     int e = 0;
-    auto stage_group = [&](int gi) -> int {
+    auto stage_group = [&](int gi, bool announce = true) -> int {
         for (; e < E_n && sp.entries[e].group == gi; ++e) SDPA_TRY(stage_chunk(pl, rk, rp, g, c.K, c.V, e));
-        return raise(gi);
+        return announce ? raise(gi) : SDPA_OK;
     };
     need_pin(c, 0);
-    SDPA_TRY(stage_group(0));
+    SDPA_TRY(stage_group(0, !q_with_group0));
     need_pin(c, 1);
-    for (int j = 0; j < pieces; ++j) {
+    if (q_with_group0) {          // group 0, the batch's Q rows as ONE copy, then the word that announces both
+        for (int j = 0; j < pieces; ++j) HI.cv->wait(HI.q_task[g][0][j]);
+        HIP_TRY(hipMemcpyAsync(rk.qf[s].p, HI.q + i0 * pl.ldq * pl.q_elem, (size_t)bs * pl.ldq * pl.q_elem, hipMemcpyHostToDevice, rk.s_cp));
+        SDPA_TRY(raise(0));
+    }
+    for (int j = 0; j < pieces && !q_with_group0; ++j) {
         SDPA_TRY(stage_q_rows(pl, rk, c.Q, s, i0, j * pr, std::min(pr, bs - j * pr), rk.ev_qh[j], rk.ev_qp[j],
                               HI.q_task[g][0][j], true));
         SDPA_TRY(raise(sdpa::kStreamMaxChunks + j));
@@ -1448,9 +1547,10 @@ int rank_batch0_streamed(Call &c, int g) {
 
     // ---- 3. its rows: merged by the launcher's split-merge pass; a rank that finishes its own rows sends them home
     //      in row pieces (finish + D2H of piece j under the host's widening of piece j-1)
+    const bool egress_in_order = fused_finish && pl.nb == 1 && sdpa_debug_int("egress_in_order", 1) != 0;
     if (finisher)
         for (int j = halves == 2 ? pieces_launch : 0; j < pieces; ++j)
-            SDPA_TRY(finish_rows(c, g, s, bs, i0, j, j * pr, std::min(pr, bs - j * pr), fused_finish));
+            SDPA_TRY(finish_rows(c, g, s, bs, i0, j, j * pr, std::min(pr, bs - j * pr), fused_finish, egress_in_order));
     HIP_TRY(hipEventRecord(rk.ev_run[s], rk.s_run));
     if (finisher) HIP_TRY(hipEventRecord(rk.ev_out[s], rk.s_out));
     return SDPA_OK;
@@ -1953,6 +2053,7 @@ int check_plan(const Plan &pl) {
 void destroy_rank(Rank &g) {
     if (hipSetDevice(g.dev) != hipSuccess) return;
     (void)hipDeviceSynchronize();
+    if (g.vf_view) { g.vf = DevBuf(); g.vf_view = false; }
     DevBuf *single[] = {&g.k64, &g.v64, &g.kf, &g.vf, &g.ws, &g.slots};
     for (DevBuf *b : single) if (b->p) (void)hipFree(b->p);
     for (int s = 0; s < 2; ++s) {
@@ -2263,12 +2364,17 @@ static int attention_call(const double *Q, const double *K, const double *V, dou
         const size_t kel = pl.kv_elem, qel = pl.q_elem;
         const int ldv_h = pl.bf16 ? dv : pl.ldv;
         const size_t vel = pl.bf16 ? sizeof(unsigned short) : sizeof(float);
-        char *hk = (char *)E.hc->staging(0, (size_t)n * pl.ldk * kel);
+        // (fp32, every rank streamed with interleaved groups, images equally wide: K and V share ONE staging, group by group -- HostImages::pair)
+        bool pair = !pl.bf16 && pl.ldk == pl.ldv && sdpa_debug_int("stream_pair", 1) != 0;
+        for (int g = 0; g < P && pair; ++g)
+            pair = pl.r[g].stream.on && pl.r[g].stream.interleaved && E.r[g].vf_view &&
+                   (char *)E.r[g].vf.p == (char *)E.r[g].kf.p + (size_t)pl.r[g].key_cnt * pl.ldk * sizeof(float);
+        char *hk = (char *)E.hc->staging(0, (size_t)n * pl.ldk * kel * (pair ? 2 : 1));
         // bf16, first batch streamed: the staging holds the Vt IMAGES themselves (padded dv rows x padded keys per rank, packed
         // entry by entry: Chunk::img_off), not dense rows -- all ranks or none (a call never mixes the two V stagings)
         bool bf16_images = pl.bf16;
         for (int g = 0; g < P && bf16_images; ++g) bf16_images = pl.r[g].stream.on;
-        size_t hv_bytes = (size_t)n * ldv_h * vel;
+        size_t hv_bytes = pair ? 64 : (size_t)n * ldv_h * vel;
         std::vector<size_t> hv_rank_off(P, 0);
         if (bf16_images) {
             hv_bytes = 0;
@@ -2286,6 +2392,7 @@ static int attention_call(const double *Q, const double *K, const double *V, dou
             for (int g = 0; g < P; ++g)
                 if (pl.r[g].stream.on && (!pl.bf16 || bf16_images)) HI.streamed[g] = 1, c.streamed = true;
             HI.v_rank_off = hv_rank_off;
+            HI.pair = pair;
             if (c.streamed) {
                 if (++E.stream_gen == 0) ++E.stream_gen;
                 c.stream_gen = E.stream_gen;
@@ -2312,6 +2419,11 @@ static int attention_call(const double *Q, const double *K, const double *V, dou
                 const size_t row0 = (size_t)rp.key_off + cc.k0;
                 // (bf16, dv > 256: rows of the TILED K image -- chunk swizzle by the row's place in its tile; chunks and entries
                 //  start on tile boundaries of the rank's image, so the task's own row count gives it)
+                if (pair) {            // [K rows of the group][V rows of the group] at row 2 * row0 of the shared staging
+                    HI.k_task[g].push_back(E.hc->submit(K + row0 * dk, hk + 2 * row0 * pl.ldk * kel, cc.keys, dk, pl.ldk, kind, 1.0));
+                    HI.v_task[g].push_back(E.hc->submit(V + row0 * dv, hk + (2 * row0 + cc.keys) * pl.ldk * kel, cc.keys, dv, pl.ldv, kind, 1.0));
+                    return;
+                }
                 HI.k_task[g].push_back(E.hc->submit(K + row0 * dk, hk + row0 * pl.ldk * kel, cc.keys, dk, pl.ldk,
                                                      pl.bf16 && sdpa::bf16_tiled(dv) ? sdpa::kCvtBf16Swz : kind, 1.0));
                 if (pl.bf16 && HI.streamed[g])        // the entry's columns of the Vt image, as a packed block of the staging
@@ -2602,8 +2714,9 @@ int sdpa_plan_describe(int m, int n, int dk, int dv, int flags, int ranks, char 
         // the streamed form of the first batch, where the shape allows it (taken when the call runs host converts):
         // splits of the ONE launch, tiles per split, the tile each group ends at, and the row ranges [first key, keys,
         // group] in the order they cross PCIe
-        snprintf(t, sizeof t, "], \"stream\": {\"on\": %d, \"halves\": %d, \"rows_per_launch\": %d, \"splits\": %d, \"tiles_per_split\": %d, \"end_tile\": [",
-                 rp.stream.on ? 1 : 0, rp.stream.halves, rp.stream.rows_per_launch, rp.stream.splits, rp.stream.tiles_per_split);
+        snprintf(t, sizeof t, "], \"stream\": {\"on\": %d, \"halves\": %d, \"rows_per_launch\": %d, \"splits\": %d, \"tiles_per_split\": %d, \"interleaved\": %d, \"q_with_group0\": %d, \"end_tile\": [",
+                 rp.stream.on ? 1 : 0, rp.stream.halves, rp.stream.rows_per_launch, rp.stream.splits, rp.stream.tiles_per_split, rp.stream.interleaved ? 1 : 0,
+                 rp.stream.q_with_group0 ? 1 : 0);
         o += t;
         for (size_t c = 0; c < rp.stream.end_tile.size(); ++c) {
             snprintf(t, sizeof t, "%s%d", c ? ", " : "", rp.stream.end_tile[c]);
@@ -2649,7 +2762,8 @@ int sdpa_prepare(int m, int n, int dk, int dv, int flags) {
         if (pl.bf16)                      // (a streamed bf16 first batch stages the Vt images: padded dv rows x padded keys per rank)
             for (const RankPlan &rp : pl.r)
                 if (rp.stream.on) v_bytes += (size_t)(sdpa::bf16_pad_dv(dv) - dv) * rp.key_cnt * 2 + (size_t)sdpa::bf16_pad_dv(dv) * 64;
-        if (!E.hc->staging(0, (size_t)n * pl.ldk * pl.kv_elem) || !E.hc->staging(1, v_bytes) ||
+        // (fp32 with equally wide images: K and V may share staging 0, group by group -- HostImages::pair)
+        if (!E.hc->staging(0, (size_t)n * pl.ldk * pl.kv_elem * ((!pl.bf16 && pl.ldk == pl.ldv) ? 2 : 1)) || !E.hc->staging(1, v_bytes) ||
             !E.hc->staging(2, (size_t)m * pl.ldq * pl.q_elem))
             return SDPA_ENOMEM;
     }

@@ -491,6 +491,22 @@ def stream_halves(pkg, m, n, dk, dv, precision="f32"):
     return (sp["halves"], sp["rows_per_launch"]) if sp["on"] else (1, 0)
 
 
+def stream_key_order(pkg, m, n, dk, dv, precision="f32"):
+    """image row j of the streamed launch holds key order[j] of the shard: the identity, or -- interleaved groups (round 6) -- group c
+    = the c-th contiguous key range, its `splits` slices at tiles [end_tile[c-1], end_tile[c]) of the splits' ranges"""
+    sp = pkg.plan(m, n, dk, dv, 2 if precision == "bf16" else 0, 1)["r"][0]["stream"]
+    order = np.arange(n)
+    if sp["on"] and sp["interleaved"]:
+        tps, S = sp["tiles_per_split"], sp["splits"]
+        for (k0, keys, c), a, b in zip(sp["entries"], [0] + sp["end_tile"], sp["end_tile"]):
+            sl = keys // S
+            assert sl == (b - a) * 32
+            for sx in range(S):
+                order[(sx * tps + a) * 32:(sx * tps + b) * 32] = np.arange(k0 + sx * sl, k0 + (sx + 1) * sl)
+        assert np.array_equal(np.sort(order), np.arange(n))
+    return order
+
+
 def device_level(pkg, Q, K, V, batch, precision="f32"):
     """the device-level path on resident inputs, batch after batch: converts, ONE fused launch per batch on the whole
     shard (sdpa_dev_shard_partial_f32 / _bf16), finish -- what the streamed launch must reproduce bit for bit.  Where the
@@ -500,7 +516,8 @@ def device_level(pkg, Q, K, V, batch, precision="f32"):
     sa = pkg.ShardedAttention(be, precision=precision)
     n, dk = K.shape
     dv = V.shape[1]
-    sa.load_kv_shard_f64(torch.from_numpy(K).cuda(), torch.from_numpy(V).cuda(), n, dk, dv)
+    order = stream_key_order(pkg, Q.shape[0], n, dk, dv, precision)      # (the keys in the order the host's images hold them)
+    sa.load_kv_shard_f64(torch.from_numpy(np.ascontiguousarray(K[order])).cuda(), torch.from_numpy(np.ascontiguousarray(V[order])).cuda(), n, dk, dv)
     halves, rows_launch = stream_halves(pkg, Q.shape[0], n, dk, dv, precision)
     out = []
     for i0 in range(0, Q.shape[0], batch):
@@ -514,7 +531,9 @@ def device_level(pkg, Q, K, V, batch, precision="f32"):
 
 
 @pytest.mark.parametrize("m,n,dk,dv,dist,env", [
-    (8192, 8192, 128, 128, "D2", {}),                       # BASELINE config 2: 8 splits, 2 groups, 16 row ranges per operand
+    (8192, 8192, 128, 128, "D2", {}),                       # BASELINE config 2: 8 splits, 3 interleaved groups (one pitched copy each)
+    (8192, 8192, 128, 128, "D4", {"SDPA_DEBUG": "stream_interleave=0"}),    # ... and round 5's form of it: one group
+    (32768, 65536, 128, 128, "D2", {}),                     # the metric shape: 2 splits, 6 interleaved groups
     (16384, 20000, 128, 128, "D2", {}),                     # 4 splits of 157 tiles: ragged last split and last tile
     (32768, 16384, 64, 64, "D1", {}),                       # 2 splits, 64-wide images
     (8192, 12000, 100, 72, "D3", {}),                       # padded dims (images 128 wide), peaky scores
@@ -652,7 +671,7 @@ def test_streamed_launch_that_loses_a_ready_word_falls_back_to_the_chunked_sched
     pkg = engine(SDPA_STREAMED=0)
     want = pkg.attention(Q, K, V)
     pkg = engine(SDPA_STREAM_TIMEOUT_MS=200, SDPA_DEBUG="stream_drop_word=2")  # the second K/V group is never announced
-    assert len(pkg.plan(8192, 32768, 128, 128, 0, 1)["r"][0]["stream"]["end_tile"]) == 2
+    assert len(pkg.plan(8192, 32768, 128, 128, 0, 1)["r"][0]["stream"]["end_tile"]) >= 2
     t0 = time.perf_counter()
     got = pkg.attention(Q, K, V)
     assert time.perf_counter() - t0 < 2.0, "one timeout (200 ms) + the chunked re-run"

@@ -111,7 +111,9 @@ def test_python_host_and_c_host_agree_bit_for_bit(world, m, n, B, streamed, tmp_
 
     c_out = str(tmp_path / "c_host.npy")
     if streamed:
-        cenv = dict(env, SDPA_VIRTUAL_GPUS=str(world), SDPA_QBATCH=str(B))
+        # (the persistent launch with its K/V groups as ROW RANGES in key order, round 5's form: the interleaved groups of round 6 hold
+        #  the shard's keys in another order -- the same sums in another order, equal within the tolerance, not bit for bit)
+        cenv = dict(env, SDPA_VIRTUAL_GPUS=str(world), SDPA_QBATCH=str(B), SDPA_DEBUG="stream_interleave=0")
     else:
         cenv = dict(env, **knob_env(dict(SDPA_VIRTUAL_GPUS=str(world), SDPA_QBATCH=str(B), SDPA_ROW_PIECES="1",
                                          SDPA_KV_CHUNK_MIN=str(1 << 22), SDPA_KV_CHUNK_MAX=str(1 << 22), SDPA_HOST_CVT="0")))

@@ -59,6 +59,18 @@ def check_stream(pl, rp):
     ntiles = -(-rp["key_cnt"] // 32)
     assert tps == -(-ntiles // st["splits"])
     assert 1 <= len(ends) <= 16 and ends == sorted(set(ends)) and ends[-1] == tps and ends[0] >= 1
+    if st["interleaved"]:
+        # round 6: group c is the c-th CONTIGUOUS key range of the shard (one pitched copy per operand puts its `splits` slices at
+        # tiles [ends[c-1], ends[c]) of the splits' ranges); fp32, more than one split, a whole number of tiles per split; a group
+        # is at least 2048 keys
+        assert not pl["bf16"] and st["splits"] > 1 and len(ends) >= 2 and st["splits"] * tps * 32 == rp["key_cnt"]
+        at = 0
+        for c, (a, b) in enumerate(zip([0] + ends, ends)):
+            keys = st["splits"] * (b - a) * 32
+            assert keys >= 2048 and st["entries"][c] == [at, keys, c]
+            at += keys
+        assert at == rp["key_cnt"] and len(st["entries"]) == len(ends)
+        return
     # a split's share of a group is at least 2048 keys (64 tiles) unless it is the split's whole range (one group)
     for a, b in zip([0] + ends, ends):
         assert b - a >= 64 or len(ends) == 1
@@ -204,9 +216,18 @@ def test_streamed_first_batch_plan_on_the_baseline_shapes(pkg, monkeypatch):
             assert st["on"] == 1, (m, n, d, ranks)
             assert st["splits"] == lib.sdpa_dev_kv_splits(min(m, 32768), rp["key_cnt"], d, d)
             check_stream(pl, rp)
-    assert pkg.plan(32768, 65536, 128, 128, 0, 1)["r"][0]["stream"]["end_tile"] == [64, 128, 256, 512, 1024]
-    c2 = pkg.plan(8192, 8192, 128, 128, 0, 1)["r"][0]["stream"]          # config 2: 8 splits of 1024 keys -> ONE group, one copy
-    assert c2["splits"] == 8 and c2["end_tile"] == [32] and c2["entries"] == [[0, 8192, 0]]
+    hd = pkg.plan(32768, 65536, 128, 128, 0, 1)["r"][0]["stream"]
+    assert hd["interleaved"] == 1 and hd["splits"] == 2 and hd["end_tile"] == [32, 64, 128, 256, 512, 1024] and len(hd["entries"]) == 6
+    # config 2: 8 splits of 1024 keys.  Rounds 5: ONE group (16 row ranges of 256 KiB per group cost more than they hid); interleaved
+    # groups are one pitched copy each.  The call is FEED bound (0.36 ms of inputs for 0.26 ms of kernel): four EQUAL groups of 2048
+    # keys (what counts is how little work is left when the last one lands), and the Q rows ride in front of group 0's ready word
+    c2 = pkg.plan(8192, 8192, 128, 128, 0, 1)["r"][0]["stream"]
+    assert c2["splits"] == 8 and c2["interleaved"] == 1 and c2["q_with_group0"] == 1 and c2["end_tile"] == [8, 16, 24, 32]
+    assert c2["entries"] == [[0, 2048, 0], [2048, 2048, 1], [4096, 2048, 2], [6144, 2048, 3]]
+    assert hd["q_with_group0"] == 0                           # kernel bound: the Q row pieces keep their own words (early starts)
+    # a ragged shard (not a whole number of tiles per split) keeps the row ranges of round 5
+    rg = pkg.plan(32768, 65536 + 40, 128, 128, 0, 1)["r"][0]["stream"]
+    assert rg["on"] == 1 and rg["interleaved"] == 0
     # bf16 (second half of round 5): the tandem kernel's shapes (dv > 256) have a persistent form -- config 5 in bf16 is ONE launch over
     # 9 groups, with the device-level launch's split count; narrower value matrices (duo / pipe kernels) keep the launch per chunk
     c5 = pkg.plan(32768, 65536, 512, 512, SDPA_F_BF16, 1)

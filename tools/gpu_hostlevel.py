@@ -29,6 +29,7 @@ register = "--register" in sys.argv
 streamed = "--streamed" in sys.argv
 KNOBS = ("SDPA_STREAMED", "SDPA_STREAM_CHUNK_MIN", "SDPA_QBATCH", "SDPA_KV_CHUNK_MIN", "SDPA_KV_CHUNK_MAX", "SDPA_ROW_PIECES", "SDPA_PIECE_MIN_ROWS", "SDPA_HOST_REGISTER",
          "SDPA_PROGRESSIVE_PIN")
+BASE_DEBUG = os.environ.get("SDPA_DEBUG", "")      # the caller's own $SDPA_DEBUG stays in force under every row
 DEBUG = {"SDPA_STREAM_CHUNK_MIN": "stream_chunk_min", "SDPA_KV_CHUNK_MIN": "kv_chunk_min", "SDPA_KV_CHUNK_MAX": "kv_chunk_max", "SDPA_ROW_PIECES": "row_pieces",
          "SDPA_PIECE_MIN_ROWS": "piece_min_rows", "SDPA_PROGRESSIVE_PIN": "progressive_pin"}      # -> $SDPA_DEBUG="name=value,..."
 SWEEP = [{},
@@ -78,7 +79,7 @@ for name in args or ["headline", "config2", "config1"]:
         for k in KNOBS + (("SDPA_HOST_CVT", "SDPA_HOST_CVT_THREADS", "SDPA_HOST_WIDEN") if (hostcvt or widen or register) else ()):
             os.environ.pop(k, None)           # (outside those modes a caller's $SDPA_HOST_CVT_THREADS etc. stay in force)
         os.environ.pop("SDPA_DEBUG", None)
-        dbg = ["%s=%s" % (DEBUG[k], v) for k, v in knobs.items() if k in DEBUG]     # the tuning knobs live in ONE variable
+        dbg = ([BASE_DEBUG] if BASE_DEBUG else []) + ["%s=%s" % (DEBUG[k], v) for k, v in knobs.items() if k in DEBUG]     # the tuning knobs live in ONE variable
         if dbg:
             os.environ["SDPA_DEBUG"] = ",".join(dbg)
         for k, v in knobs.items():
