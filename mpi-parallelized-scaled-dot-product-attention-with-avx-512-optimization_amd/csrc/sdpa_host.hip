@@ -739,6 +739,7 @@ void make_plan(Plan &pl, int m, int n, int dk, int dv, int flags, int ranks = 0)
                     const double t_kern_r = 2.0 * rows0 * (double)rp.key_cnt * (dk + dv) / (dk <= 256 ? 1.3e14 : 1.0e14);
                     const int smax = sdpa_debug_pos("stream_interleave_max", t_feed_r > t_kern_r ? smin : gmax);
                     gsz_i = chunk_sizes(rp.key_cnt, std::min(scmin, smin), std::max(std::min(scmin, smin), std::max(smax, (int)(((long)rp.key_cnt / 12 + 1023) / 1024 * 1024))));
+                    // (forced at the metric shape -- kernel bound -- it LOSES: 8.82 8.84 -> 9.02 9.00 ms; the row pieces' early starts matter there)
                     sp.q_with_group0 = t_feed_r > t_kern_r && halves == 1 && sdpa_debug_int("stream_q_with_group0", 1) != 0;
                 }
                 const std::vector<int> &gsz_use = interleave ? gsz_i : gsz;
