@@ -67,8 +67,35 @@ import sys
 import tempfile
 import time
 
-import numpy as np
-import torch
+
+def _usable_cores():
+    """cores this process may actually use: the affinity mask cut by the cgroup CPU quota (cgroup v2 cpu.max / v1 cfs_quota)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        if os.path.exists("/sys/fs/cgroup/cpu.max"):
+            q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if q != "max":
+                n = min(n, max(1, int(float(q) / float(period) + 0.5)))
+        else:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and period > 0:
+                n = min(n, max(1, int(q / period + 0.5)))
+    except Exception:  # noqa: BLE001
+        pass
+    return n
+
+
+# The GPU boxes show 256 CPUs and grant 16 cores' worth of time (CFS quota).  numpy's BLAS would start one SPINNING thread per visible
+# CPU for the parity checks, spend the process's CPU budget of the current 100 ms period in a few milliseconds, and the kernel
+# launches that follow would be throttled on the HOST side: measured (round 6, same box, --no-boundary vs default) config 2's
+# bracket 0.272 -> 0.295 ms, config 5 / bf16 3.13 -> 3.33 with one 12.6 ms step.  Cap the math libraries' pools at what the
+# process may use -- before numpy / torch are imported.
+for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, str(max(1, min(16, _usable_cores() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))))))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = "mpi-parallelized-scaled-dot-product-attention-with-avx-512-optimization_amd"

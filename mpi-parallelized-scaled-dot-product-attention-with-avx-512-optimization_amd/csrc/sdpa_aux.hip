@@ -20,6 +20,20 @@ static inline unsigned stream_grid(long work_items, int block = 256) {
     return (unsigned)g;
 }
 
+// The converters read their fp64 source ONCE: streaming (non-temporal) loads keep it out of the Infinity Cache, where the operand
+// images written here should stay for the fused kernel that follows (sdpa_fwd_bf16.hip: cvt_src_load has the measurement).
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+#ifndef SDPA_CVT_NT
+#define SDPA_CVT_NT 1
+#endif
+#if SDPA_CVT_NT
+__device__ __forceinline__ f64x2 stream_load2(const double *p) { return __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(p)); }
+__device__ __forceinline__ double stream_load(const double *p) { return __builtin_nontemporal_load(p); }
+#else
+__device__ __forceinline__ f64x2 stream_load2(const double *p) { return *reinterpret_cast<const f64x2 *>(p); }
+__device__ __forceinline__ double stream_load(const double *p) { return *p; }
+#endif
+
 // dst[r*ld + c] = (float)src[r*cols + c], c < cols; zero for cols <= c < ld.
 // __double2float_rn == RNE == what _mm512_cvtpd_ps does under the default MXCSR.
 __global__ void cvt_d2f_kernel(const double *__restrict__ src, float *__restrict__ dst, long rows,
@@ -31,18 +45,18 @@ __global__ void cvt_d2f_kernel(const double *__restrict__ src, float *__restrict
          idx += (long)gridDim.x * blockDim.x) {
         float4 o;
         if (flat) {
-            const double2 a = reinterpret_cast<const double2 *>(src)[2 * idx];
-            const double2 b = reinterpret_cast<const double2 *>(src)[2 * idx + 1];
+            const f64x2 a = stream_load2(src + 4 * idx);
+            const f64x2 b = stream_load2(src + 4 * idx + 2);
             o = make_float4(__double2float_rn(a.x), __double2float_rn(a.y),
                             __double2float_rn(b.x), __double2float_rn(b.y));
         } else {
             const long r = idx / c4n;
             const int c = (int)(idx - r * c4n) * 4;
             const double *s = src + r * cols + c;
-            o.x = c + 0 < cols ? __double2float_rn(s[0]) : 0.f;
-            o.y = c + 1 < cols ? __double2float_rn(s[1]) : 0.f;
-            o.z = c + 2 < cols ? __double2float_rn(s[2]) : 0.f;
-            o.w = c + 3 < cols ? __double2float_rn(s[3]) : 0.f;
+            o.x = c + 0 < cols ? __double2float_rn(stream_load(s + 0)) : 0.f;
+            o.y = c + 1 < cols ? __double2float_rn(stream_load(s + 1)) : 0.f;
+            o.z = c + 2 < cols ? __double2float_rn(stream_load(s + 2)) : 0.f;
+            o.w = c + 3 < cols ? __double2float_rn(stream_load(s + 3)) : 0.f;
         }
         reinterpret_cast<float4 *>(dst)[idx] = o;
     }
@@ -65,17 +79,17 @@ __global__ void cvt_d2f_batch_kernel(CvtBatch b) {
         const double *src = b.src[k];
         float4 o;
         if (cols == b.ld[k]) {
-            const double2 x = reinterpret_cast<const double2 *>(src)[2 * i];
-            const double2 y = reinterpret_cast<const double2 *>(src)[2 * i + 1];
+            const f64x2 x = stream_load2(src + 4 * i);
+            const f64x2 y = stream_load2(src + 4 * i + 2);
             o = make_float4(__double2float_rn(x.x), __double2float_rn(x.y), __double2float_rn(y.x), __double2float_rn(y.y));
         } else {
             const long r = i / c4n;
             const int c = (int)(i - r * c4n) * 4;
             const double *s = src + r * cols + c;
-            o.x = c + 0 < cols ? __double2float_rn(s[0]) : 0.f;
-            o.y = c + 1 < cols ? __double2float_rn(s[1]) : 0.f;
-            o.z = c + 2 < cols ? __double2float_rn(s[2]) : 0.f;
-            o.w = c + 3 < cols ? __double2float_rn(s[3]) : 0.f;
+            o.x = c + 0 < cols ? __double2float_rn(stream_load(s + 0)) : 0.f;
+            o.y = c + 1 < cols ? __double2float_rn(stream_load(s + 1)) : 0.f;
+            o.z = c + 2 < cols ? __double2float_rn(stream_load(s + 2)) : 0.f;
+            o.w = c + 3 < cols ? __double2float_rn(stream_load(s + 3)) : 0.f;
         }
         reinterpret_cast<float4 *>(b.dst[k])[i] = o;
     }

@@ -1091,6 +1091,21 @@ __global__ __launch_bounds__(256, 1) void fused_bf16_duo_kernel(
 // converts: fp64 -> bf16 (RNE), row-major with zero-padded columns, and the transposed V image -- in the layout the
 // shape's kernel reads (sdpa_internal.h: row images for dv <= 256, tiled images for dv > 256)
 // ---------------------------------------------------------------------------
+// The converters read their source ONCE: streaming (non-temporal) loads keep the fp64 arrays out of the Infinity Cache, where the
+// operand images they write should stay for the fused kernel that follows -- measured on config 5 in bf16, same box: the tandem
+// kernel 3.04 ms back to back, 3.21-3.23 behind plain-load converts (behind the Q convert alone: 134 MB of fp64 through the cache),
+// and no slower than back to back behind streaming ones (profiles/r06/bf16_kernel_behind_converts.log).
+#ifndef SDPA_CVT_NT
+#define SDPA_CVT_NT 1
+#endif
+template <typename T> __device__ __forceinline__ T cvt_src_load(const T *p) {
+#if SDPA_CVT_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 // rows [0, rows) converted, rows [rows, rows_pad) zero; 16-byte chunk c of row r lands at chunk position c ^ (r & swz)
 // (swz = 0: plain rows; the tiled K image: bf16_k_swz -- r counts from the image's first row, a multiple of 16 for `dst`)
 __global__ void cvt_d2bf_kernel(const double *__restrict__ src, unsigned short *__restrict__ dst,
@@ -1100,7 +1115,7 @@ __global__ void cvt_d2bf_kernel(const double *__restrict__ src, unsigned short *
          idx += (long)gridDim.x * blockDim.x) {
         const long r = idx / ld;
         const int cidx = (int)(idx - r * ld);
-        const unsigned short v = (r < rows && cidx < cols) ? (unsigned short)f32_to_bf16_rne(__double2float_rn(src[r * cols + cidx] * mult)) : (unsigned short)0;
+        const unsigned short v = (r < rows && cidx < cols) ? (unsigned short)f32_to_bf16_rne(__double2float_rn(cvt_src_load(&src[r * cols + cidx]) * mult)) : (unsigned short)0;
         const int at = ((((cidx >> 3) ^ ((int)r & swz)) << 3) | (cidx & 7));
         dst[r * ld + at] = v;
     }
@@ -1125,7 +1140,7 @@ __global__ void cvt_d2bf_t_kernel(const SRC *__restrict__ src, unsigned short *_
     for (int k = ty; k < 32; k += 8) {
         const long r = r0 + k;
         const int cc = c0 + tx;
-        tile[k][tx] = (r < rows && cc < cols) ? to_bf16_elem(src[r * cols + cc]) : (unsigned short)0;
+        tile[k][tx] = (r < rows && cc < cols) ? to_bf16_elem(cvt_src_load(&src[r * cols + cc])) : (unsigned short)0;
     }
     __syncthreads();
     for (int k = ty; k < 32; k += 8) {
