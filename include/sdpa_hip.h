@@ -266,6 +266,14 @@ SDPA_API int sdpa_kv_prefetch(const double *K, const double *V, int m, int n, in
  * Returns NULL when there is no usable device or the allocation fails.  SURVEY.md 8(f)-2.       */
 SDPA_API void *sdpa_host_alloc(size_t bytes);
 SDPA_API void  sdpa_host_free(void *p);
+/* A caller whose arrays are page-locked by OTHER means (hipHostMalloc, a pinned torch tensor, hipHostRegister of its own) declares the
+ * range [p, p + bytes): it is then treated like a sdpa_host_alloc range.  Why declare: since round 5 the library takes every pointer it
+ * does not know for pageable WITHOUT asking the runtime (hipPointerGetAttributes on a plain malloc makes ROCm 7 log an error-level line
+ * per pointer); results are the same either way, an undeclared pinned array merely travels through the staging like a pageable one.
+ * The range must stay page-locked until sdpa_host_forget_pinned(p).  No device needed.  SDPA_EINVAL: null pointer / zero size / a
+ * pointer that was never declared.                                                                                                  */
+SDPA_API int   sdpa_host_declare_pinned(const void *p, size_t bytes);
+SDPA_API int   sdpa_host_forget_pinned(const void *p);
 
 /* The host-side converter: `rows` rows of fp64 -> rows of an operand image, on the calling thread, with
  * the device converters' roundings bit for bit.  kind 0: float rows of `ld` floats, pad columns zero

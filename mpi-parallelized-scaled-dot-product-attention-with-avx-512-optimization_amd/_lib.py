@@ -66,6 +66,8 @@ _PROTOS = {
     "sdpa_kv_prefetch": (_c_int, [_c_void_p, _c_void_p] + [_c_int] * 7),
     "sdpa_host_alloc": (_c_void_p, [ctypes.c_size_t]),
     "sdpa_host_free": (None, [_c_void_p]),
+    "sdpa_host_declare_pinned": (_c_int, [_c_void_p, _c_size_t]),
+    "sdpa_host_forget_pinned": (_c_int, [_c_void_p]),
     "sdpa_host_cvt_rows": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_int, _c_int, _c_int, ctypes.c_double, _c_int]),
     "sdpa_host_cvt_vt": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_long, _c_int, _c_int, _c_long, _c_int, _c_int]),
     "sdpa_host_widen": (_c_int, [_c_void_p, _c_void_p, ctypes.c_size_t, _c_int, _c_int]),

@@ -2327,6 +2327,10 @@ static int attention_call(const double *Q, const double *K, const double *V, dou
     struct ClearCuts { ~ClearCuts() { CUT = PinCuts(); } } clear_cuts;
     CUT = PinCuts();
     c.do_pin = register_caller_arrays();
+    {   // ($SDPA_DEBUG host_probe=1: a verdict about a pointer holds for ONE call -- the caller may have freed and reused the address)
+        std::lock_guard<std::mutex> lk(HR.mu);
+        HR.probed.clear();
+    }
     const bool pageable_in = !c.do_pin && !(page_locked(K) && page_locked(V) && page_locked(Q));
     c.k_bytes = (size_t)n * dk * sizeof(double);
     c.v_bytes = (size_t)n * dv * sizeof(double);
@@ -2682,6 +2686,26 @@ void sdpa_host_free(void *p) {
         HR.probed.clear();
     }
     if (hipHostFree(p) != hipSuccess) (void)hipGetLastError();
+}
+
+// A caller that page-locks its arrays ITSELF (hipHostMalloc, a pinned torch tensor, hipHostRegister) says so: the range joins the ones
+// sdpa_host_alloc() handed out and is used in place where that pays -- without the library asking the runtime about every pointer
+// (ADVICE r5).  No device needed; the caller keeps the range page-locked until it forgets it.
+int sdpa_host_declare_pinned(const void *p, size_t bytes) {
+    if (!p || bytes == 0) return SDPA_EINVAL;
+    std::lock_guard<std::mutex> lk(HR.mu);
+    for (auto &e : HR.r)
+        if (e.first == (const char *)p) { e.second = bytes; return SDPA_OK; }
+    HR.r.push_back({(const char *)p, bytes});
+    return SDPA_OK;
+}
+
+int sdpa_host_forget_pinned(const void *p) {
+    if (!p) return SDPA_EINVAL;
+    std::lock_guard<std::mutex> lk(HR.mu);
+    for (size_t i = 0; i < HR.r.size(); ++i)
+        if (HR.r[i].first == (const char *)p) { HR.r[i] = HR.r.back(); HR.r.pop_back(); return SDPA_OK; }
+    return SDPA_EINVAL;
 }
 
 // The schedule sdpa_attention_f64 would run for this problem on `ranks` ranks, as one JSON object.

@@ -130,6 +130,21 @@ def test_stream_k_plan_arithmetic(pkg):
     assert [lib.sdpa_dev_kv_splits(m, 65536, 512, 512) for m in (32768, 33000, 40000)] == classic
 
 
+def test_declared_pinned_ranges_need_no_device(pkg):
+    """sdpa_host_declare_pinned / sdpa_host_forget_pinned only keep a list: they work without a GPU and reject what
+    they cannot mean"""
+    import ctypes
+    lib = pkg.load()
+    buf = ctypes.create_string_buffer(4096)
+    p = ctypes.addressof(buf)
+    assert lib.sdpa_host_declare_pinned(None, 4096) < 0 and lib.sdpa_host_declare_pinned(p, 0) < 0
+    assert lib.sdpa_host_forget_pinned(p) < 0                   # never declared
+    assert lib.sdpa_host_declare_pinned(p, 4096) == 0
+    assert lib.sdpa_host_declare_pinned(p, 2048) == 0           # declared again: the new size replaces the old one
+    assert lib.sdpa_host_forget_pinned(p) == 0
+    assert lib.sdpa_host_forget_pinned(p) < 0
+
+
 def test_argument_validation_precedes_device_use(pkg):
     lib = pkg.load()
     a = np.zeros((4, 4))

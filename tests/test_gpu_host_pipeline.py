@@ -484,6 +484,36 @@ def test_convert_placement_is_chosen_per_problem(engine, orc, O):
     check(got, orc.attention_f64(Q, K, V), V, "two ranks, host converts", 1e-2 * max(1.0, float(np.abs(V).max())))
 
 
+def test_arrays_the_caller_pinned_itself_are_used_in_place_once_declared(engine, O):
+    """page-locked memory the library did not allocate (here: pinned torch tensors) is taken for pageable -- the library
+    does not ask the runtime about pointers it does not know -- until the caller declares it (sdpa_host_declare_pinned): then a
+    kernel-bound problem without a streamed form (d = 256) takes the direct path (fp64 over the link, device converts), as from
+    sdpa_host_alloc memory; the results are the same bits either way; forgetting the range brings the staging back."""
+    import os
+    big_host = (os.cpu_count() or 1) >= 16
+    pkg = engine()
+    lib = pkg.load()
+    rng = np.random.default_rng(4)
+    shapes = ((16384, 256), (16384, 256), (16384, 256))             # kernel bound (a copy-bound problem takes the host converts anyway)
+    T = [torch.from_numpy(rng.uniform(-1, 1, s)).pin_memory() for s in shapes]
+    Q, K, V = (t.numpy() for t in T)
+    want = pkg.attention(Q, K, V)
+    assert (pkg.last_timing()["host_convert_threads"] > 0) == big_host          # undeclared: staged like a pageable array
+    try:
+        for t in T:
+            assert lib.sdpa_host_declare_pinned(t.data_ptr(), t.numel() * 8) == 0
+        got = pkg.attention(Q, K, V)
+        t = pkg.last_timing()
+        assert t["host_convert_threads"] == 0 and t["streamed"] == 0 and t["register_us"] == 0, t
+        assert np.array_equal(got, want)
+    finally:
+        for t in T:
+            assert lib.sdpa_host_forget_pinned(t.data_ptr()) == 0
+    assert lib.sdpa_host_forget_pinned(T[0].data_ptr()) < 0                     # never declared (any more)
+    assert np.array_equal(pkg.attention(Q, K, V), want)
+    assert (pkg.last_timing()["host_convert_threads"] > 0) == big_host
+
+
 # ------------------------------------------------- the streamed first batch (round 5): ONE persistent launch that follows its inputs -----
 def stream_halves(pkg, m, n, dk, dv, precision="f32"):
     """how many launches the streamed first batch of this problem is (sdpa_plan_describe): 1, or 2 half-row launches (round 6)"""
