@@ -215,6 +215,30 @@ __global__ void finish_f32_kernel(const float *__restrict__ contrib, int ldo,
     }
 }
 
+// Operand-like bit patterns for sdpa_prepare()'s clock warm-up (sdpa_host.hip): word i = a hash of i turned into one fp32 in [-mag, mag)
+// (bf16 = 0) or two bf16 of that range (bf16 = 1).  Measured (round 6, profiles/r06/first_call_warmup.log): MFMAs on ZEROED operands draw
+// so little power that the part's power management does not leave its light-load state -- the first real call of a process ran its
+// kernel at 9.6-9.7 ms instead of 8.2 however long the zero warm-up was; 60 ms on data like this and it runs at 8.2.
+__global__ void fill_pattern_kernel(unsigned *dst, size_t words, int bf16, float mag) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)i * 2654435761u + 0x9e3779b9u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        if (!bf16) {
+            dst[i] = __float_as_uint(((float)(h >> 8) * (1.0f / 8388608.0f) - 1.0f) * mag);
+        } else {
+            const float a = ((float)(h >> 16) * (1.0f / 32768.0f) - 1.0f) * mag, b = ((float)(h & 0xffffu) * (1.0f / 32768.0f) - 1.0f) * mag;
+            dst[i] = (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xffff0000u);
+        }
+    }
+}
+
+hipError_t launch_fill_pattern(void *dst, size_t bytes, int bf16, float mag, hipStream_t s) {
+    const size_t words = bytes / 4;
+    if (words == 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_pattern_kernel, dim3(stream_grid((long)std::min<size_t>(words, (size_t)1 << 40))), dim3(256), 0, s, (unsigned *)dst, words, bf16, mag);
+    return hipGetLastError();
+}
+
 hipError_t launch_cvt_d2f(const double *src, float *dst, long rows, int cols, int ld, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
     const long work = rows * (ld / 4);

@@ -6,7 +6,8 @@
  *   planner     kv_chunk_min (4096), kv_chunk_max (per problem), row_pieces (4), piece_min_rows (4096), stream_chunk_min (= kv_chunk_min),
  *               stream_entry_min (2048), stream_interleave (1), stream_interleave_min (2048), stream_interleave_max (per problem), stream_pair (1), stream_q_with_group0 (1), egress_in_order (1), stream_probe_ms (200), two_wave (0), stream_drop_word (0 = none), enqueue_threads (1),
  *               progressive_pin (1), pin_probe (1), host_probe (0), host_cores (from the cgroup quota), reserve_by_mask (0),
- *               force_collectives (0: 1 = the merge's collectives run on one rank too, real RCCL on a one-rank communicator)
+ *               force_collectives (0: 1 = the merge's collectives run on one rank too, real RCCL on a one-rank communicator),
+ *               prepare_zero (0: 1 = sdpa_prepare() warms the clock on zeroed operands, as rounds 3-5)
  *   converters  host_cvt_item_kb (64), host_cvt_nt (1), host_cvt_pin (0), host_cvt_trace (0)
  *   launchers   split_merge (separate | kernel), streamk (auto | 0 | 1), bf16_duo (1), tune (0; -DSDPA_ABLATIONS builds only)
  *   CLI hosts   pinned_io (1), time_init (0)                                                                                        */

@@ -312,6 +312,8 @@ int dksplit_rows(int dk);
 hipError_t launch_shard_partial(const PartialArgs &a, hipStream_t s);
 
 hipError_t launch_cvt_d2f(const double *src, float *dst, long rows, int cols, int ld, hipStream_t s);
+// operand-like patterns (fp32 in [-mag, mag), or pairs of bf16) for sdpa_prepare()'s warm-up launches; bytes rounded down to words
+hipError_t launch_fill_pattern(void *dst, size_t bytes, int bf16, float mag, hipStream_t s);
 // up to three fp64 -> fp32 images in one launch (each exactly launch_cvt_d2f's)
 hipError_t launch_cvt_d2f_batch(int count, const double *const *src, float *const *dst, const long *rows, const int *cols, const int *ld,
                                 hipStream_t s);
